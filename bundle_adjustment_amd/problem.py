@@ -1,0 +1,124 @@
+"""Flat (structure-of-arrays) form of a bundle-adjustment window and the walk that
+builds it from a ``Map``.
+
+``BAProblem`` is what crosses the C-ABI (``include/ba_hip.h``): cameras ``(Nc,6)`` =
+``[rvec | tvec]`` (world->camera), points ``(Np,3)``, observations as
+``cam_idx[int32]``, ``pt_idx[int32]``, ``uv[f64,2]`` in the reference's residual row
+order, intrinsics ``(fx, fy, cx, cy)`` and the index of the fixed camera.
+
+``gather_window`` follows ``BundleAdjuster._gather_local_data``
+(``src/bundle_adjuster.py:195-218``): keyframes in the given order, each keyframe's
+``observations`` in insertion order, observations kept when the map point still exists,
+map-point ids sorted ascending, and for a repeated ``(keyframe, map point)`` pair the
+LAST keypoint wins for both rows (the reference stores pixels in a dict keyed by the
+pair).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from .rotations import matrices_to_rvecs
+
+
+@dataclass
+class BAProblem:
+    cams: np.ndarray        # (Nc,6) float64  [rvec | tvec]
+    pts: np.ndarray         # (Np,3) float64
+    cam_idx: np.ndarray     # (Nobs,) int32
+    pt_idx: np.ndarray      # (Nobs,) int32
+    uv: np.ndarray          # (Nobs,2) float64
+    K4: np.ndarray          # (4,) fx, fy, cx, cy
+    fixed_cam: int = 0      # index into cams, -1 = none fixed
+
+    @property
+    def n_cams(self):
+        return int(self.cams.shape[0])
+
+    @property
+    def n_pts(self):
+        return int(self.pts.shape[0])
+
+    @property
+    def n_obs(self):
+        return int(self.cam_idx.shape[0])
+
+    def validate(self):
+        """Shape / range checks done on the host before anything reaches a kernel."""
+        nc, npt, nobs = self.n_cams, self.n_pts, self.n_obs
+        if self.cams.shape != (nc, 6) or self.pts.shape != (npt, 3):
+            raise ValueError("cams must be (Nc,6) and pts (Np,3)")
+        if self.pt_idx.shape != (nobs,) or self.uv.shape != (nobs, 2):
+            raise ValueError("observation arrays disagree in length")
+        if nobs:
+            if self.cam_idx.min() < 0 or self.cam_idx.max() >= nc:
+                raise ValueError("cam_idx out of range")
+            if self.pt_idx.min() < 0 or self.pt_idx.max() >= npt:
+                raise ValueError("pt_idx out of range")
+        if not (-1 <= self.fixed_cam < nc):
+            raise ValueError("fixed_cam out of range")
+        return self
+
+
+def gather_window(gmap, local_kf_ids):
+    """-> (sorted map-point ids, observations [(kf_id, mp_id)], keypoints_2d dict)."""
+    mp_ids = set()
+    observations = []
+    keypoints_2d = {}
+    have = gmap.map_points
+    for kf_id in local_kf_ids:
+        kf = gmap.keyframes[kf_id]
+        kps = kf.keypoints
+        for mp_id, kp_idx in kf.observations:
+            if mp_id in have:
+                mp_ids.add(mp_id)
+                observations.append((kf_id, mp_id))
+                keypoints_2d[(kf_id, mp_id)] = kps[kp_idx].pt
+    return sorted(mp_ids), observations, keypoints_2d
+
+
+def flatten_window(gmap, local_kf_ids, mp_ids, observations, keypoints_2d, camera_matrix):
+    """Pack a gathered window into a ``BAProblem``.  Camera 0 of the result is
+    ``local_kf_ids[0]`` (the fixed keyframe, ``src/bundle_adjuster.py:141``)."""
+    kf_index = {kf: i for i, kf in enumerate(local_kf_ids)}
+    mp_index = {mp: i for i, mp in enumerate(mp_ids)}
+    nobs = len(observations)
+    cam_idx = np.fromiter((kf_index[k] for k, _ in observations), dtype=np.int32, count=nobs)
+    pt_idx = np.fromiter((mp_index[m] for _, m in observations), dtype=np.int32, count=nobs)
+    uv = np.array([keypoints_2d[o] for o in observations], dtype=np.float64).reshape(nobs, 2)
+    Rs = np.array([gmap.keyframes[k].R for k in local_kf_ids], dtype=np.float64)
+    ts = np.array([np.asarray(gmap.keyframes[k].t, dtype=np.float64).ravel() for k in local_kf_ids])
+    cams = np.concatenate([matrices_to_rvecs(Rs), ts], axis=1)
+    pts = np.array([np.asarray(gmap.map_points[m].position, dtype=np.float64).ravel() for m in mp_ids])
+    K = np.asarray(camera_matrix, dtype=np.float64)
+    K4 = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]])
+    return BAProblem(cams, pts.reshape(-1, 3), cam_idx, pt_idx, uv, K4, fixed_cam=0).validate()
+
+
+def shard_by_landmark(problem: BAProblem, n_shards: int):
+    """Split the points into ``n_shards`` contiguous index ranges balanced by
+    observation count.  Returns ``[(p_begin, p_end)]``; shard g owns those points and
+    every observation of them; cameras are replicated."""
+    npt = problem.n_pts
+    counts = np.bincount(problem.pt_idx, minlength=npt).astype(np.int64)
+    cum = np.concatenate([[0], np.cumsum(counts)])
+    total = cum[-1]
+    bounds = [0]
+    for g in range(1, n_shards):
+        target = total * g / n_shards
+        b = int(np.searchsorted(cum, target, side='left'))
+        bounds.append(min(max(b, bounds[-1]), npt))
+    bounds.append(npt)
+    return [(bounds[g], bounds[g + 1]) for g in range(n_shards)]
+
+
+def extract_shard(problem: BAProblem, p_begin: int, p_end: int):
+    """Sub-problem holding points [p_begin, p_end) (re-indexed from 0), their
+    observations in the original relative order, and ALL cameras.  Also returns the
+    positions of those observations in the full list."""
+    sel = np.nonzero((problem.pt_idx >= p_begin) & (problem.pt_idx < p_end))[0]
+    sub = BAProblem(problem.cams.copy(), problem.pts[p_begin:p_end].copy(),
+                    problem.cam_idx[sel].copy(), (problem.pt_idx[sel] - p_begin).astype(np.int32),
+                    problem.uv[sel].copy(), problem.K4.copy(), problem.fixed_cam)
+    return sub, sel
