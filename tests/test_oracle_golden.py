@@ -86,7 +86,8 @@ def test_reference_solver_trajectory(name):
 def test_rotation_roundtrips_and_edge_branches():
     rng = np.random.default_rng(0)
     for _ in range(200):
-        r = rng.normal(size=3) * rng.uniform(0, 3.0)
+        r = rng.normal(size=3)
+        r *= rng.uniform(0, 3.1) / np.linalg.norm(r)          # theta < pi
         R = o.rodrigues_to_mat(r)
         np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-14)
         np.testing.assert_allclose(o.rodrigues_to_vec(R), r, atol=1e-9)
