@@ -1,0 +1,227 @@
+// Device-side building blocks shared by every kernel: camera state, per-observation
+// geometry (projection + the factors of the analytic Jacobian blocks), small dense
+// algebra on packed symmetric blocks, and block-level sum reductions.
+//
+// Jacobian factorisation used everywhere (residual = observed - pi(R X + t), additive
+// rotation-vector update as scipy applies it, scipy/optimize/_lsq/trf.py:497-498):
+//     dpi = d pi / d Xc                      (2x3, two structural zeros)
+//     P   = dpi R                            (2x3)
+//     Jp  = -P                               d res / d X
+//     Jt  = -dpi                             d res / d t
+//     Jr  =  P [X]x M,  M = J_r(rvec)        d res / d rvec  (SO(3) right Jacobian)
+// so no per-observation matrix is ever stored: R, t, M come from the per-camera state and
+// X from the point, and every pass over the observation list recomputes P and dpi.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ba {
+
+constexpr int CS = 24;   // doubles of state per camera: R[9] t[3] M[9] pad[3]
+constexpr double DBL_EPS = 2.220446049250313e-16;
+constexpr double DIAG_FLOOR = 1e-12;
+
+// index of (i,j), i<=j, in the packed upper triangle of a symmetric 6x6 / 3x3
+__host__ __device__ constexpr int U6(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
+__host__ __device__ constexpr int S6(int i, int j) { return i <= j ? U6(i, j) : U6(j, i); }
+__host__ __device__ constexpr int U3(int i, int j) { return i * 3 - (i * (i - 1)) / 2 + (j - i); }
+__host__ __device__ constexpr int S3(int i, int j) { return i <= j ? U3(i, j) : U3(j, i); }
+
+// ---- camera state -----------------------------------------------------------------
+// R follows cv2.Rodrigues(vector): identity below DBL_EPSILON, else
+// cos I + (1-cos) k k^T + sin [k]x.  M = I - b [r]x + d [r]x^2 with series below 0.05 rad.
+__device__ inline void camera_state(const double* __restrict__ cam, double* __restrict__ cs) {
+  const double rx = cam[0], ry = cam[1], rz = cam[2];
+  const double t2 = rx * rx + ry * ry + rz * rz;
+  const double th = sqrt(t2);
+  double R[9];
+  if (th < DBL_EPS) {
+    R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+  } else {
+    const double c = cos(th), s = sin(th), c1 = 1.0 - c;
+    const double kx = rx / th, ky = ry / th, kz = rz / th;
+    R[0] = c + c1 * kx * kx;      R[1] = c1 * kx * ky - s * kz; R[2] = c1 * kx * kz + s * ky;
+    R[3] = c1 * kx * ky + s * kz; R[4] = c + c1 * ky * ky;      R[5] = c1 * ky * kz - s * kx;
+    R[6] = c1 * kx * kz - s * ky; R[7] = c1 * ky * kz + s * kx; R[8] = c + c1 * kz * kz;
+  }
+  double b, d;
+  if (th < 0.05) {
+    b = 0.5 - t2 / 24.0 + t2 * t2 / 720.0 - t2 * t2 * t2 / 40320.0;
+    d = 1.0 / 6.0 - t2 / 120.0 + t2 * t2 / 5040.0 - t2 * t2 * t2 / 362880.0;
+  } else {
+    b = (1.0 - cos(th)) / t2;
+    d = (th - sin(th)) / (t2 * th);
+  }
+  // [r]x^2 = r r^T - t2 I
+  double M[9];
+  M[0] = 1.0 + d * (rx * rx - t2); M[1] = b * rz + d * rx * ry;     M[2] = -b * ry + d * rx * rz;
+  M[3] = -b * rz + d * rx * ry;    M[4] = 1.0 + d * (ry * ry - t2); M[5] = b * rx + d * ry * rz;
+  M[6] = b * ry + d * rx * rz;     M[7] = -b * rx + d * ry * rz;    M[8] = 1.0 + d * (rz * rz - t2);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) cs[i] = R[i];
+  cs[9] = cam[3]; cs[10] = cam[4]; cs[11] = cam[5];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) cs[12 + i] = M[i];
+  cs[21] = 0; cs[22] = 0; cs[23] = 0;
+}
+
+// ---- per-observation geometry ------------------------------------------------------
+struct Geom {
+  double xh, yh;            // Xc.x / Xc.z, Xc.y / Xc.z
+  double d00, d02, d11, d12;  // dpi = [d00 0 d02; 0 d11 d12]
+  double P[6];              // dpi R, row-major 2x3
+};
+
+template <typename CamT>
+__device__ inline void obs_geom(const CamT* __restrict__ cs, const double X0, const double X1, const double X2,
+                                const double fx, const double fy, Geom& g) {
+  const double Xc0 = cs[0] * X0 + cs[1] * X1 + cs[2] * X2 + cs[9];
+  const double Xc1 = cs[3] * X0 + cs[4] * X1 + cs[5] * X2 + cs[10];
+  const double Xc2 = cs[6] * X0 + cs[7] * X1 + cs[8] * X2 + cs[11];
+  const double iz = (Xc2 != 0.0) ? 1.0 / Xc2 : 1.0;   // cv2.projectPoints guards z == 0 as 1
+  g.xh = Xc0 * iz;
+  g.yh = Xc1 * iz;
+  g.d00 = fx * iz;
+  g.d02 = -fx * g.xh * iz;
+  g.d11 = fy * iz;
+  g.d12 = -fy * g.yh * iz;
+  g.P[0] = g.d00 * cs[0] + g.d02 * cs[6];
+  g.P[1] = g.d00 * cs[1] + g.d02 * cs[7];
+  g.P[2] = g.d00 * cs[2] + g.d02 * cs[8];
+  g.P[3] = g.d11 * cs[3] + g.d12 * cs[6];
+  g.P[4] = g.d11 * cs[4] + g.d12 * cs[7];
+  g.P[5] = g.d11 * cs[5] + g.d12 * cs[8];
+}
+
+// projection only (trial-point cost and the residual entry point)
+template <typename CamT>
+__device__ inline void obs_project(const CamT* __restrict__ cs, const double X0, const double X1, const double X2,
+                                   double& xh, double& yh) {
+  const double Xc0 = cs[0] * X0 + cs[1] * X1 + cs[2] * X2 + cs[9];
+  const double Xc1 = cs[3] * X0 + cs[4] * X1 + cs[5] * X2 + cs[10];
+  const double Xc2 = cs[6] * X0 + cs[7] * X1 + cs[8] * X2 + cs[11];
+  const double iz = (Xc2 != 0.0) ? 1.0 / Xc2 : 1.0;
+  xh = Xc0 * iz;
+  yh = Xc1 * iz;
+}
+
+// Huber with threshold C (scipy least_squares.py:169-178 scaled by f_scale):
+// rho-term f_scale^2 rho((f/C)^2) and IRLS weight rho'.
+__device__ inline void huber(const double f, const double C, double& term, double& w) {
+  const double a = fabs(f);
+  if (a <= C) { term = f * f; w = 1.0; }
+  else        { term = 2.0 * C * a - C * C; w = C / a; }
+}
+
+// ---- small dense algebra -----------------------------------------------------------
+__device__ inline void sym3_inverse(const double* __restrict__ h, double* __restrict__ inv) {
+  // h, inv packed upper: 00 01 02 11 12 22
+  const double a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5];
+  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  const double det = a * c00 + b * c01 + c * c02;
+  const double id = 1.0 / det;
+  inv[0] = c00 * id; inv[1] = c01 * id; inv[2] = c02 * id;
+  inv[3] = (a * f - c * c) * id; inv[4] = (b * c - a * e) * id; inv[5] = (a * d - b * b) * id;
+}
+
+__device__ inline void sym3_mul(const double* __restrict__ h, const double* __restrict__ v, double* __restrict__ o) {
+  o[0] = h[0] * v[0] + h[1] * v[1] + h[2] * v[2];
+  o[1] = h[1] * v[0] + h[3] * v[1] + h[4] * v[2];
+  o[2] = h[2] * v[0] + h[4] * v[1] + h[5] * v[2];
+}
+
+__device__ inline void sym6_mul(const double* __restrict__ h, const double* __restrict__ v, double* __restrict__ o) {
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double s = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) s += h[S6(i, j)] * v[j];
+    o[i] = s;
+  }
+}
+
+// inverse of a symmetric positive definite 6x6 (packed upper in, packed upper out) by
+// Cholesky; a non-positive pivot is replaced by DIAG_FLOOR so the result stays finite.
+__device__ inline void spd6_inverse(const double* __restrict__ h, double* __restrict__ inv) {
+  double L[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) L[i][j] = 0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double s = h[U6(j, j)];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) if (k < j) s -= L[j][k] * L[j][k];
+    s = (s > DIAG_FLOOR) ? s : DIAG_FLOOR;
+    const double l = sqrt(s);
+    L[j][j] = l;
+    const double il = 1.0 / l;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) if (i > j) {
+      double t = h[U6(j, i)];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) if (k < j) t -= L[i][k] * L[j][k];
+      L[i][j] = t * il;
+    }
+  }
+  // Linv (lower)
+  double Li[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) Li[i][j] = 0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    Li[j][j] = 1.0 / L[j][j];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) if (i > j) {
+      double t = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) if (k >= j && k < i) t -= L[i][k] * Li[k][j];
+      Li[i][j] = t / L[i][i];
+    }
+  }
+  // inv = Li^T Li
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) if (j >= i) {
+      double t = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) if (k >= j) t += Li[k][i] * Li[k][j];
+      inv[U6(i, j)] = t;
+    }
+}
+
+// ---- reductions --------------------------------------------------------------------
+__device__ inline double wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+  return x;
+}
+
+// Sum v[0..N) over the block; result valid in thread 0.  sm needs N * (blockDim.x/64)
+// doubles.  Fixed order (lanes by shuffle tree, then waves 0..n-1): deterministic.
+template <int N>
+__device__ inline void block_sum(double (&v)[N], double* __restrict__ sm) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) sm[wv * N + k] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      double s = 0;
+      for (int w = 0; w < nw; ++w) s += sm[w * N + k];
+      v[k] = s;
+    }
+  }
+  __syncthreads();
+}
+
+}  // namespace ba

@@ -1,0 +1,159 @@
+/*
+ * ba_hip.h -- C ABI of libba_hip.so, the MI355X (gfx950) bundle-adjustment solve step.
+ *
+ * This is the boundary a maintainer of egirgin/bundle_adjustment binds (ctypes; see
+ * INTEGRATION.md) to replace the solve step of src/bundle_adjuster.py.  Each entry point
+ * names the reference interface it stands in for (paths relative to the reference root).
+ *
+ * Conventions: every function returns 0 on success and a negative ba_status on failure;
+ * ba_last_error() then holds a message for the calling thread.  All pointers are host
+ * pointers owned by the caller unless a function says "device"; the library copies in
+ * and out.  One handle = one GPU = one host thread at a time.  No callbacks, no global
+ * state besides the per-thread error string.
+ *
+ * Flat problem layout (what BundleAdjuster.run packs at src/bundle_adjuster.py:157-162,
+ * plus the fixed keyframe as an ordinary camera whose index is `fixed_cam`):
+ *   cams  double[Nc][6]   rvec(3) | tvec(3), world->camera (Xc = R(rvec) X + t)
+ *   pts   double[Np][3]
+ *   obs   cam_idx int32[Nobs], pt_idx int32[Nobs], uv double[Nobs][2]
+ *         row 2i, 2i+1 of the residual vector <-> observation i (src/bundle_adjuster.py:52-70)
+ *   K4    double[4]       fx, fy, cx, cy (the only entries of camera_matrix that
+ *                          cv2.projectPoints reads, src/bundle_adjuster.py:67)
+ */
+#ifndef BA_HIP_H
+#define BA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ba_handle ba_handle;
+
+enum ba_status {
+  BA_OK = 0,
+  BA_ERR_INVALID = -1,   /* bad argument / shape / index out of range */
+  BA_ERR_HIP = -2,       /* a HIP runtime call failed */
+  BA_ERR_STATE = -3,     /* call order (e.g. solve before set_problem) */
+  BA_ERR_NUMERIC = -4,   /* non-finite residuals or cost */
+  BA_ERR_COMM = -5       /* RCCL load / init / collective failure */
+};
+
+enum ba_loss { BA_LOSS_LINEAR = 0, BA_LOSS_HUBER = 1 };
+enum ba_precond { BA_PRECOND_JACOBI = 0, BA_PRECOND_SCHUR_JACOBI = 1 };
+
+/* Solver knobs.  The reference's literals at src/bundle_adjuster.py:170-174 are
+ * loss='huber' (f_scale 1), xtol = ftol = 1e-5, max_nfev = 50. */
+typedef struct ba_options {
+  int32_t loss;            /* ba_loss */
+  int32_t max_iters;       /* LM iterations (accepted + rejected) */
+  double f_scale;          /* Huber threshold in pixels */
+  double ftol;             /* stop when cost decrease <= ftol * cost (on an accepted step) */
+  double xtol;             /* stop when |step| <= xtol * (xtol + |x|) */
+  double gtol;             /* stop when max |gradient| <= gtol */
+  double initial_lambda;   /* Marquardt damping at the first iteration */
+  double pcg_tol;          /* PCG stops at sqrt(rz / rz0) <= pcg_tol */
+  int32_t pcg_max_iters;
+  int32_t pcg_min_iters;
+  int32_t preconditioner;  /* ba_precond */
+  int32_t jacobian_precision; /* 0 = f64 (default); 1 = f32 blocks, f64 accumulation */
+  int32_t pcg_check_every; /* host looks at the device convergence flag every n PCG iterations */
+  int32_t profile;         /* 1 = bracket every kernel with HIP events (see ba_get_profile) */
+  int32_t verbose;
+  int32_t reserved;
+} ba_options;
+
+typedef struct ba_summary {
+  int32_t iterations;      /* LM iterations done */
+  int32_t accepted;
+  int32_t pcg_iterations;  /* total over all LM iterations */
+  int32_t status;          /* 0 max_iters, 1 ftol, 2 xtol, 3 gtol, <0 ba_status */
+  double initial_sse;      /* sum r^2 at entry == the reference's "Initial Cost" (:165) */
+  double final_sse;        /* sum r^2 at exit  == "Final Cost" (:176) */
+  double initial_cost;     /* 0.5 * sum rho(r^2) */
+  double final_cost;
+  double final_lambda;
+  double seconds_total;    /* wall time of the solve loop */
+  double seconds_linearize;
+  double seconds_pcg;
+  double seconds_update;
+} ba_summary;
+
+/* Per-kernel event timing collected when ba_options.profile = 1. */
+#define BA_PROFILE_SLOTS 16
+typedef struct ba_profile {
+  int32_t launches[BA_PROFILE_SLOTS];
+  double total_ms[BA_PROFILE_SLOTS];
+} ba_profile;
+/* slot ids */
+enum ba_kernel_slot {
+  BA_K_CAM_PREPARE = 0, BA_K_RESIDUAL = 1, BA_K_LINEARIZE_CAM = 2, BA_K_LINEARIZE_PT = 3,
+  BA_K_POINT_INVERT = 4, BA_K_SCHUR_PT = 5, BA_K_SCHUR_CAM = 6, BA_K_PCG_UPDATE = 7,
+  BA_K_PRECOND = 8, BA_K_BACKSUB = 9, BA_K_MISC = 10, BA_K_ALLREDUCE = 11
+};
+
+const char* ba_last_error(void);
+const char* ba_kernel_name(int slot);
+
+/* Device / handle -------------------------------------------------------------------- */
+int ba_device_count(int* n);
+int ba_create(int device_id, ba_handle** out);   /* replaces BundleAdjuster.__init__ state, :20-22 */
+int ba_destroy(ba_handle* h);
+int ba_synchronize(ba_handle* h);
+
+/* Multi-GPU: one process per GPU; rank 0 makes the id, the host side ships the 128 bytes
+ * to the other ranks (bench.py uses torch.distributed's store), every rank calls init.
+ * With world == 1 nothing is loaded.  No reference counterpart. */
+int ba_comm_unique_id(void* id128);
+int ba_comm_init(ba_handle* h, int rank, int world, const void* id128);
+
+/* Problem upload: replaces the dict/list gather of _gather_local_data (:195-218) and the
+ * 0/1 jac_sparsity of _prepare_sparsity_matrix (:74-120) -- the library derives its own
+ * camera-sorted and point-sorted orderings once.  In a multi-rank job each rank passes
+ * ITS shard of points/observations (pt_idx local to the shard) and ALL cameras. */
+int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64_t n_obs,
+                   const int32_t* cam_idx, const int32_t* pt_idx, const double* uv,
+                   const double K4[4], int32_t fixed_cam);
+int ba_set_params(ba_handle* h, const double* cams, const double* pts);
+int ba_get_params(ba_handle* h, double* cams, double* pts);
+/* 3x3 rotation matrices of the current cameras, double[Nc][9] row-major: the
+ * cv2.Rodrigues(rvec) of _update_map (:235-236). */
+int ba_get_rotations(ba_handle* h, double* R);
+
+/* K1: residual vector in the caller's observation order == _cost_function (:24-72).
+ * r may be NULL.  sse = sum r^2 (":165"), cost = 0.5 sum rho(r^2) for `loss`. */
+int ba_residuals(ba_handle* h, int32_t loss, double f_scale, double* r, double* sse, double* cost);
+
+/* K2/K3: linearise at the current parameters.  Outputs (any may be NULL):
+ *   Hcc double[Nc][21]  upper triangle of Jc^T w Jc, row-major (00 01 .. 05 11 .. 55)
+ *   bc  double[Nc][6]   Jc^T w r
+ *   Hpp double[Np][6]   upper triangle of Jp^T w Jp (00 01 02 11 12 22)
+ *   bp  double[Np][3]   Jp^T w r
+ * The fixed camera's blocks are zero.  Replaces the finite-difference Jacobian scipy
+ * builds from jac_sparsity (scipy/optimize/_numdiff.py:628-705). */
+int ba_linearize(ba_handle* h, int32_t loss, double f_scale,
+                 double* Hcc, double* bc, double* Hpp, double* bp);
+
+/* K4 test hooks (need a prior ba_linearize): reduced camera system at damping lambda.
+ *   ba_schur_rhs:   g = -(bc - W (Hpp+lam Dp)^-1 bp)          double[Nc][6]
+ *   ba_schur_apply: out = S v, S = (Hcc+lam Dc) - W (Hpp+lam Dp)^-1 W^T
+ * The fixed camera's row is identity / zero. */
+int ba_schur_rhs(ba_handle* h, double lambda, double* g);
+int ba_schur_apply(ba_handle* h, double lambda, const double* v, double* out);
+
+/* K2-K7: the whole LM / Schur / PCG loop on the device; replaces the
+ * scipy.optimize.least_squares call at src/bundle_adjuster.py:170-174. */
+int ba_default_options(ba_options* opts);
+int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* summary);
+int ba_get_profile(ba_handle* h, ba_profile* out);
+int ba_reset_profile(ba_handle* h);
+
+/* Bench hook: run one kernel `reps` times back to back on the solver stream between two
+ * HIP events and return the mean duration in microseconds (state left as it was). */
+int ba_time_kernel(ba_handle* h, int slot, int reps, double* mean_us);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BA_HIP_H */
