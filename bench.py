@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: LM iterations/sec + final reprojection RMSE on the synthetic
+1k-camera / 100k-point / 1M-observation problem (BASELINE.json ``configs[2]``).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one Levenberg-Marquardt iteration (linearise, damped Schur system, PCG
+solve, back substitution, trial-point cost, accept/reject) of the HIP solver.  The timed
+region is one ``ba_solve`` call with ``max_iters = K`` and every stopping tolerance at 0,
+so exactly K iterations run; inputs (observation lists, parameters) are resident in HBM
+before it starts and the call returns after the stream has drained.  For N > 1 the
+driver launches one rank per GPU with torch.distributed.run; the points (and their
+observations) are sharded by landmark block, cameras are replicated and the reduced
+camera system is all-reduced with RCCL inside the library (torch.distributed is used
+only to ship the 128-byte RCCL id, for the barriers and for the max over ranks).
+
+One JSON line is printed by rank 0 (fields: see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(n_cams, n_pts, n_obs):
+    """SURVEY.md 8(d) minimum-traffic model, fp64, int32 indices (bytes)."""
+    P = 24 * n_pts + 48 * n_cams
+    V = 48 * n_cams
+    Q = 24 * n_pts
+    D = 48 * n_pts
+    b = dict(
+        schur_pt=8 * n_obs + P + D + Q + V,            # index pass by point: W^T v, Hpp^-1
+        schur_cam=8 * n_obs + P + Q + 3 * V,           # index pass by camera: W y, S v assembly
+        lin=24 * n_obs + P + D + Q + 168 * n_cams + V,
+        back=8 * n_obs + P + D + 2 * Q + V,
+        evalc=24 * n_obs + P,
+    )
+    b["pcg_iter"] = b["schur_pt"] + b["schur_cam"]
+    return b
+
+
+def cpu_baseline_port(prob, budget_s=20.0):
+    """Reference CPU path (per-observation Python loop + 2-point finite differences over
+    colour groups + TRF/LSMR, src/bundle_adjuster.py:24-72,170-174) timed on this host,
+    single thread, on a bounded sample: the residual sweep is timed on a contiguous
+    sample of observations and scaled to the full list; one TRF iteration costs
+    (n_groups + 1) sweeps (scipy/optimize/_numdiff.py:628-705) plus an LSMR solve that is
+    NOT timed (so the CPU figure is an upper bound on its throughput)."""
+    from oracle import ba_oracle as o
+    nobs = prob.n_obs
+    n_sample = min(nobs, 100_000)
+    obs = [(int(c), int(p)) for c, p in zip(prob.cam_idx[:n_sample], prob.pt_idx[:n_sample])]
+    kp = {ob: (float(u), float(v)) for ob, (u, v) in zip(obs, prob.uv[:n_sample])}
+    x0, adj = o.pack_reference_params(prob.cams, prob.pts, prob.fixed_cam)
+    K = np.array([[prob.K4[0], 0, prob.K4[2]], [0, prob.K4[1], prob.K4[3]], [0, 0, 1.0]])
+    fixed_pose = (o.rodrigues_to_mat(prob.cams[prob.fixed_cam, :3]), prob.cams[prob.fixed_cam, 3:].reshape(3, 1))
+    t0 = time.perf_counter()
+    done = 0
+    chunk = 20_000
+    while done < n_sample and (time.perf_counter() - t0) < budget_s:
+        sl = obs[done:done + chunk]
+        o.reference_cost_function(x0, fixed_pose, prob.fixed_cam, adj, list(range(prob.n_pts)), sl, kp, K)
+        done += len(sl)
+    dt = time.perf_counter() - t0
+    per_obs = dt / max(done, 1)
+    from scipy.optimize._numdiff import group_columns
+    tg = time.perf_counter()
+    A = o.flat_sparsity(prob.n_cams, prob.n_pts, prob.cam_idx, prob.pt_idx, prob.fixed_cam)
+    n_groups = int(group_columns(A).max()) + 1        # what least_squares does with jac_sparsity
+    tg = time.perf_counter() - tg
+    t_iter = (n_groups + 1) * per_obs * nobs
+    return dict(value=1.0 / t_iter, unit="LM iterations/s", cores=1, kind="port",
+                sample=f"{done} of {nobs} observations through the per-observation loop "
+                       f"({per_obs * 1e6:.1f} us/obs, {dt:.1f} s), x ({n_groups}+1) sweeps per TRF iteration; "
+                       f"colour groups counted by scipy group_columns in {tg:.1f} s; LSMR solve not timed; "
+                       f"host has {os.cpu_count()} cores")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C5"])
+    ap.add_argument("--loss", default="huber", choices=["huber", "linear"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--pcg-tol", type=float, default=0.1)
+    ap.add_argument("--pcg-max-iters", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist          # plumbing only: id exchange, barrier, max over ranks
+        dist.init_process_group(backend="gloo")
+
+    from bundle_adjustment_amd import hip_backend
+    from bundle_adjustment_amd.problem import extract_shard, shard_by_landmark
+    from bundle_adjustment_amd.synthetic import make_bal_like, make_config
+
+    prob = make_bal_like(seed=args.seed) if args.config == "C5" else make_config(args.config, seed=args.seed)
+    n_obs_total = prob.n_obs
+    shard = prob
+    if world > 1:
+        b, e = shard_by_landmark(prob, world)[rank]
+        shard, _ = extract_shard(prob, b, e)
+
+    solver = hip_backend.Solver(local_rank if world > 1 else 0)
+    if world > 1:
+        uid = [hip_backend.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        solver.comm_init(rank, world, uid[0])
+    solver.set_problem(shard)
+
+    kw = dict(loss=args.loss, ftol=0.0, xtol=0.0, gtol=0.0, pcg_tol=args.pcg_tol, pcg_max_iters=args.pcg_max_iters)
+
+    def barrier():
+        solver.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # warmup: W untimed LM iterations, then restore the initial guess
+    if args.warmup > 0:
+        solver.solve(max_iters=args.warmup, **kw)
+    solver.set_params(shard.cams, shard.pts)
+    barrier()
+    t0 = time.perf_counter()
+    out = solver.solve(max_iters=args.steps, **kw)
+    solver.synchronize()
+    dt = time.perf_counter() - t0
+    barrier()
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    steps_done = out["iterations"]
+    rmse = float(np.sqrt(out["final_sse"] / n_obs_total))
+
+    # per-kernel durations with HIP events on the solver's stream: same workload again
+    solver.set_params(shard.cams, shard.pts)
+    solver.profile(reset=True)
+    solver.solve(max_iters=args.steps, profile=1, **kw)
+    prof = solver.profile()
+    ab = algorithmic_bytes(prob.n_cams, shard.n_pts, shard.n_obs)
+    dom = max(("schur_pt", "schur_cam"), key=lambda k: prof.get(k, {}).get("total_ms", 0.0))
+    dom_us = prof[dom]["mean_us"]
+    achieved = ab[dom] / (dom_us * 1e-6) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom)
+        except Exception:
+            traffic = None
+    roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                    algorithmic_bytes_per_launch=ab[dom], mean_launch_us=round(dom_us, 3),
+                    launches=prof[dom]["launches"])
+
+    line = None
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline_port(prob)
+        line = {
+            "metric": "LM iterations/sec (final reprojection RMSE in config.final_rmse_px), 1k cams / 100k pts",
+            "value": round(steps_done / dt, 3), "unit": "LM iterations/s", "n_gpus": world, "steps": steps_done,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / max(steps_done, 1), 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: {prob.n_cams} cams / {prob.n_pts} pts / {n_obs_total} obs, "
+                                   f"loss={args.loss}, LM+Schur+PCG(tol {args.pcg_tol})",
+                       "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU",
+                       "final_rmse_px": round(rmse, 6), "initial_rmse_px": round(float(np.sqrt(out['initial_sse'] / n_obs_total)), 6),
+                       "pcg_iterations_per_lm": round(out["pcg_iterations"] / max(steps_done, 1), 2),
+                       "accepted_steps": out["accepted"],
+                       "seconds": {k: round(out[k], 6) for k in ("seconds_total", "seconds_linearize", "seconds_pcg", "seconds_update")}},
+            "roofline": roofline,
+            "kernel_profile_us": {k: round(v["mean_us"], 3) for k, v in prof.items()},
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line), flush=True)
+    solver.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
