@@ -109,18 +109,22 @@ struct ba_handle {
   double lin_fscale = 1.0;
   int Nc = 0, Np = 0, Nobs = 0, fixed = -1;
   double K4[4] = {1, 1, 0, 0};
-  // observation lists
-  DBuf<int> cam_off, c_pt, c_orig, pt_off, p_cam;
+  // observation lists (camera order, point order)
+  DBuf<int> offk, c_pt, c_orig, pt_off, p_cam;
   DBuf<double2> c_uv, p_uv, c_w, p_w;
-  // parameters (current / trial) and camera state
-  DBuf<double> cams[2], pts[2], cs[2];
+  // parameters (current / trial): cameras, camera state, point table
+  DBuf<double> cams[2], cs[2], ptab[2], stage;
   int cur = 0;
-  // normal equations
-  DBuf<double> Hcc, bc, Hpp, bp, Hppinv, y0, y, Hccd, Minv, E;
-  // PCG
-  DBuf<double> gvec, x, r, p, s, z, vtil, comm, partA, partV, partB, partC, partR, scal, rbuf;
+  // camera table of the point passes, normal equations
+  DBuf<double> camA, HccBc, Hpp, bp, Hppinv, y0, Hccd, Minv;
+  // partial sums
+  DBuf<double> partR, partL, part6, partE, partA, partB, partC, partV;
+  // PCG vectors, comm buffers (multi-rank), scalars
+  DBuf<double> gvec, x, r, p, s, z, vin, comm, commE, scal, rbuf;
   DBuf<PcgState> st;
-  int nblkA = 0, nblkV = 0;
+  int nblkP = 1, ppb = 1, nblkV = 1;
+  bool lds_tab = true;
+  size_t lds_bytes = 0;
   // pinned host mirror for scalars
   double* h_scal = nullptr;
   PcgState* h_st = nullptr;
@@ -146,6 +150,12 @@ extern "C" int ba_device_count(int* n) {
   return BA_OK;
 }
 
+// the LDS-table point passes need more than the default 64 KB of dynamic LDS
+template <typename F>
+static hipError_t allow_big_lds(F* f) {
+  return hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+}
+
 extern "C" int ba_create(int device_id, ba_handle** out) {
   if (!out) return fail(BA_ERR_INVALID, "null out pointer");
   int n = 0;
@@ -157,6 +167,12 @@ extern "C" int ba_create(int device_id, ba_handle** out) {
   HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHECK(hipHostMalloc((void**)&h->h_scal, 64 * sizeof(double)));
   HIPCHECK(hipHostMalloc((void**)&h->h_st, 2 * sizeof(PcgState)));
+  HIPCHECK(allow_big_lds(k_pt_linearize<true, true>));
+  HIPCHECK(allow_big_lds(k_pt_linearize<false, true>));
+  HIPCHECK(allow_big_lds(k_pt_schur<true, 0, true>));
+  HIPCHECK(allow_big_lds(k_pt_schur<false, 0, true>));
+  HIPCHECK(allow_big_lds(k_pt_schur<true, 1, true>));
+  HIPCHECK(allow_big_lds(k_pt_schur<false, 1, true>));
   *out = h;
   return BA_OK;
 }
@@ -169,14 +185,14 @@ extern "C" int ba_destroy(ba_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   if (h->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(h->nccl);
   for (auto e : h->ev) (void)hipEventDestroy(e);
-  DBuf<int>* ib[] = {&h->cam_off, &h->c_pt, &h->c_orig, &h->pt_off, &h->p_cam};
+  DBuf<int>* ib[] = {&h->offk, &h->c_pt, &h->c_orig, &h->pt_off, &h->p_cam};
   for (auto b : ib) b->release();
   DBuf<double2>* d2[] = {&h->c_uv, &h->p_uv, &h->c_w, &h->p_w};
   for (auto b : d2) b->release();
-  DBuf<double>* db[] = {&h->cams[0], &h->cams[1], &h->pts[0], &h->pts[1], &h->cs[0], &h->cs[1], &h->Hcc, &h->bc,
-                        &h->Hpp, &h->bp, &h->Hppinv, &h->y0, &h->y, &h->Hccd, &h->Minv, &h->E, &h->gvec, &h->x,
-                        &h->r, &h->p, &h->s, &h->z, &h->vtil, &h->comm, &h->partA, &h->partV, &h->partB,
-                        &h->partC, &h->partR, &h->scal, &h->rbuf};
+  DBuf<double>* db[] = {&h->cams[0], &h->cams[1], &h->cs[0], &h->cs[1], &h->ptab[0], &h->ptab[1], &h->stage,
+                        &h->camA, &h->HccBc, &h->Hpp, &h->bp, &h->Hppinv, &h->y0, &h->Hccd, &h->Minv,
+                        &h->partR, &h->partL, &h->part6, &h->partE, &h->partA, &h->partB, &h->partC, &h->partV,
+                        &h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin, &h->comm, &h->commE, &h->scal, &h->rbuf};
   for (auto b : db) b->release();
   h->st.release();
   if (h->h_scal) (void)hipHostFree(h->h_scal);
@@ -293,49 +309,82 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   }
   if (set_device(h)) return BA_ERR_HIP;
   const int Nc = n_cams, Np = n_pts, No = (int)n_obs;
-  // stable counting sorts: by camera and by point
-  std::vector<int> cam_off(Nc + 1, 0), pt_off(Np + 1, 0);
-  for (int i = 0; i < No; ++i) { cam_off[cam_idx[i] + 1]++; pt_off[pt_idx[i] + 1]++; }
-  for (int c = 0; c < Nc; ++c) cam_off[c + 1] += cam_off[c];
+  // point order: stable counting sort by point (keeps the caller's order inside a point)
+  std::vector<int> pt_off(Np + 1, 0);
+  for (int i = 0; i < No; ++i) pt_off[pt_idx[i] + 1]++;
   for (int p = 0; p < Np; ++p) pt_off[p + 1] += pt_off[p];
-  std::vector<int> c_pt(No), c_orig(No), p_cam(No);
-  std::vector<double2> c_uv(No), p_uv(No);
+  std::vector<int> p_cam(No), p_src(No);
+  std::vector<double2> p_uv(No);
   {
-    std::vector<int> cc(cam_off.begin(), cam_off.end() - 1), pc(pt_off.begin(), pt_off.end() - 1);
+    std::vector<int> pc(pt_off.begin(), pt_off.end() - 1);
     for (int i = 0; i < No; ++i) {
-      const int a = cc[cam_idx[i]]++;
-      c_pt[a] = pt_idx[i]; c_orig[a] = i; c_uv[a] = make_double2(uv[2 * (size_t)i], uv[2 * (size_t)i + 1]);
       const int b = pc[pt_idx[i]]++;
-      p_cam[b] = cam_idx[i]; p_uv[b] = c_uv[a];
+      p_cam[b] = cam_idx[i]; p_src[b] = i; p_uv[b] = make_double2(uv[2 * (size_t)i], uv[2 * (size_t)i + 1]);
     }
+  }
+  // camera order: stable counting sort of the POINT-ordered list by camera, so that every
+  // camera's observations are ascending in point index (needed by the partition split)
+  std::vector<int> cam_off(Nc + 1, 0);
+  for (int i = 0; i < No; ++i) cam_off[cam_idx[i] + 1]++;
+  for (int c = 0; c < Nc; ++c) cam_off[c + 1] += cam_off[c];
+  std::vector<int> c_pt(No), c_orig(No);
+  std::vector<double2> c_uv(No);
+  {
+    std::vector<int> cc(cam_off.begin(), cam_off.end() - 1);
+    for (int p = 0; p < Np; ++p)
+      for (int j = pt_off[p]; j < pt_off[p + 1]; ++j) {
+        const int a = cc[p_cam[j]]++;
+        c_pt[a] = p; c_orig[a] = p_src[j]; c_uv[a] = p_uv[j];
+      }
+  }
+  // partition split: offk[c][k] = first observation of camera c whose point is >= k * psz
+  std::vector<int> offk((size_t)Nc * (NPART + 1));
+  const int psz = std::max(1, (Np + NPART - 1) / NPART);
+  for (int c = 0; c < Nc; ++c) {
+    int i = cam_off[c];
+    for (int k = 0; k <= NPART; ++k) {
+      const long long lim = (k == NPART) ? (long long)Np + 1 : (long long)k * psz;
+      while (i < cam_off[c + 1] && c_pt[i] < lim) ++i;
+      offk[(size_t)c * (NPART + 1) + k] = i;
+    }
+    offk[(size_t)c * (NPART + 1)] = cam_off[c];
   }
   h->Nc = Nc; h->Np = Np; h->Nobs = No; h->fixed = fixed_cam;
   memcpy(h->K4, K4, sizeof h->K4);
-  h->nblkA = (Np + PT_BLOCK - 1) / PT_BLOCK;
   h->nblkV = (Nc + VEC_BLOCK - 1) / VEC_BLOCK;
+  h->lds_bytes = (size_t)Nc * TA * sizeof(double);
+  h->lds_tab = h->lds_bytes <= 150 * 1024;
+  const int pts_per_pass = PT_THREADS / LPP;
+  const int want = std::max(1, (Np + pts_per_pass - 1) / pts_per_pass);
+  h->nblkP = std::min(want, h->lds_tab ? 256 : 4096);
+  h->ppb = std::max(1, (Np + h->nblkP - 1) / h->nblkP);
   const size_t nobs1 = std::max(No, 1), np1 = std::max(Np, 1);
-  HIPCHECK(h->cam_off.alloc(Nc + 1)); HIPCHECK(h->pt_off.alloc(Np + 1));
+  HIPCHECK(h->offk.alloc((size_t)Nc * (NPART + 1))); HIPCHECK(h->pt_off.alloc(Np + 1));
   HIPCHECK(h->c_pt.alloc(nobs1)); HIPCHECK(h->c_orig.alloc(nobs1)); HIPCHECK(h->p_cam.alloc(nobs1));
   HIPCHECK(h->c_uv.alloc(nobs1)); HIPCHECK(h->p_uv.alloc(nobs1));
   HIPCHECK(h->c_w.alloc(nobs1)); HIPCHECK(h->p_w.alloc(nobs1));
   for (int k = 0; k < 2; ++k) {
-    HIPCHECK(h->cams[k].alloc(6 * (size_t)Nc)); HIPCHECK(h->pts[k].alloc(3 * np1)); HIPCHECK(h->cs[k].alloc(CS * (size_t)Nc));
+    HIPCHECK(h->cams[k].alloc(6 * (size_t)Nc)); HIPCHECK(h->cs[k].alloc(CS * (size_t)Nc));
+    HIPCHECK(h->ptab[k].alloc(PT * np1));
+    HIPCHECK(hipMemsetAsync(h->ptab[k].p, 0, PT * np1 * sizeof(double), h->stream));
   }
-  HIPCHECK(h->Hcc.alloc(27 * (size_t)Nc + 8));   // Hcc (21 Nc) | bc (6 Nc): one all-reduce
+  HIPCHECK(h->stage.alloc(3 * np1));
+  HIPCHECK(h->camA.alloc(TA * (size_t)Nc));
+  HIPCHECK(h->HccBc.alloc(27 * (size_t)Nc + 8));   // Hcc (21 Nc) | bc (6 Nc): one all-reduce
   HIPCHECK(h->Hpp.alloc(6 * np1)); HIPCHECK(h->bp.alloc(3 * np1)); HIPCHECK(h->Hppinv.alloc(6 * np1));
-  HIPCHECK(h->y0.alloc(3 * np1)); HIPCHECK(h->y.alloc(3 * np1));
-  HIPCHECK(h->Hccd.alloc(21 * (size_t)Nc)); HIPCHECK(h->Minv.alloc(21 * (size_t)Nc)); HIPCHECK(h->E.alloc(21 * (size_t)Nc));
-  DBuf<double>* v6[] = {&h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vtil};
+  HIPCHECK(h->y0.alloc(3 * np1));
+  HIPCHECK(h->Hccd.alloc(21 * (size_t)Nc)); HIPCHECK(h->Minv.alloc(21 * (size_t)Nc));
+  HIPCHECK(h->partR.alloc(2 * (size_t)NPART * Nc)); HIPCHECK(h->partL.alloc(27 * (size_t)NPART * Nc));
+  HIPCHECK(h->part6.alloc(6 * (size_t)NPART * Nc)); HIPCHECK(h->partE.alloc(21 * (size_t)NPART * Nc));
+  HIPCHECK(h->partA.alloc(h->nblkP)); HIPCHECK(h->partB.alloc(4 * (size_t)h->nblkP));
+  HIPCHECK(h->partC.alloc(5 * (size_t)h->nblkV)); HIPCHECK(h->partV.alloc(4 * (size_t)h->nblkV));
+  DBuf<double>* v6[] = {&h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin};
   for (auto b : v6) HIPCHECK(b->alloc(6 * (size_t)Nc));
-  HIPCHECK(h->comm.alloc(6 * (size_t)Nc + 8));
-  HIPCHECK(h->partA.alloc(std::max(h->nblkA, 1)));
-  HIPCHECK(h->partV.alloc(4 * (size_t)h->nblkV));
-  HIPCHECK(h->partB.alloc(4 * (size_t)std::max(h->nblkA, 1)));
-  HIPCHECK(h->partC.alloc(5 * (size_t)h->nblkV));
-  HIPCHECK(h->partR.alloc(2 * (size_t)Nc));
+  HIPCHECK(h->comm.alloc(6 * (size_t)Nc + 8)); HIPCHECK(h->commE.alloc(21 * (size_t)Nc));
   HIPCHECK(h->scal.alloc(64));
   HIPCHECK(h->st.alloc(2));
-  HIPCHECK(hipMemcpyAsync(h->cam_off.p, cam_off.data(), (Nc + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(hipMemsetAsync(h->camA.p, 0, TA * (size_t)Nc * sizeof(double), h->stream));
+  HIPCHECK(hipMemcpyAsync(h->offk.p, offk.data(), offk.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(hipMemcpyAsync(h->pt_off.p, pt_off.data(), (Np + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream));
   if (No > 0) {
     HIPCHECK(hipMemcpyAsync(h->c_pt.p, c_pt.data(), No * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -351,10 +400,8 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   return BA_OK;
 }
 
-static void launch_cam_prepare(ba_handle* h, int which) {
-  Scope sc(h, BA_K_CAM_PREPARE);
-  hipLaunchKernelGGL(k_cam_prepare, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->cams[which].p, h->cs[which].p, h->Nc);
-}
+static double* bc_ptr(ba_handle* h) { return h->HccBc.p + 21 * (size_t)h->Nc; }
+static int cam_grid(ba_handle* h) { return ((h->Nc + WPB - 1) / WPB) * NPART; }
 
 extern "C" int ba_set_params(ba_handle* h, const double* cams, const double* pts) {
   if (!h || !cams || (!pts && h->Np > 0)) return fail(BA_ERR_INVALID, "null argument");
@@ -362,9 +409,11 @@ extern "C" int ba_set_params(ba_handle* h, const double* cams, const double* pts
   if (set_device(h)) return BA_ERR_HIP;
   h->cur = 0;
   HIPCHECK(hipMemcpyAsync(h->cams[0].p, cams, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  if (h->Np > 0)
-    HIPCHECK(hipMemcpyAsync(h->pts[0].p, pts, 3 * (size_t)h->Np * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  launch_cam_prepare(h, 0);
+  if (h->Np > 0) {
+    HIPCHECK(hipMemcpyAsync(h->stage.p, pts, 3 * (size_t)h->Np * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_pack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->stage.p, h->Np, h->ptab[0].p);
+  }
+  hipLaunchKernelGGL(k_cam_prepare, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->cams[0].p, h->cs[0].p, h->Nc);
   HIPCHECK(hipStreamSynchronize(h->stream));
   h->have_params = true;
   h->linearized = false;
@@ -376,8 +425,10 @@ extern "C" int ba_get_params(ba_handle* h, double* cams, double* pts) {
   if (!h->have_params) return fail(BA_ERR_STATE, "no parameters set");
   if (set_device(h)) return BA_ERR_HIP;
   if (cams) HIPCHECK(hipMemcpyAsync(cams, h->cams[h->cur].p, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (pts && h->Np > 0)
-    HIPCHECK(hipMemcpyAsync(pts, h->pts[h->cur].p, 3 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (pts && h->Np > 0) {
+    hipLaunchKernelGGL(k_unpack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->ptab[h->cur].p, h->Np, h->stage.p);
+    HIPCHECK(hipMemcpyAsync(pts, h->stage.p, 3 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  }
   HIPCHECK(hipStreamSynchronize(h->stream));
   return BA_OK;
 }
@@ -395,77 +446,114 @@ extern "C" int ba_get_rotations(ba_handle* h, double* R) {
 // ---------------------------------------------------------------------- launch helpers
 static void launch_residual(ba_handle* h, int which, bool robust, double fscale, double* r_out) {
   Scope sc(h, BA_K_RESIDUAL);
-  auto kern = robust ? k_residual_cam<true> : k_residual_cam<false>;
-  hipLaunchKernelGGL(kern, dim3(h->Nc), dim3(CAM_BLOCK), 0, h->stream, h->cs[which].p, h->pts[which].p, h->cam_off.p,
-                     h->c_pt.p, h->c_uv.p, h->c_orig.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, r_out,
+  auto kern = robust ? k_cam_residual<true> : k_cam_residual<false>;
+  hipLaunchKernelGGL(kern, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[which].p, h->ptab[which].p, h->offk.p,
+                     h->c_pt.p, h->c_uv.p, h->c_orig.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, r_out,
                      h->partR.p);
 }
-static void launch_reduce(ba_handle* h, const double* part, int nrows, int ncols, double* out) {
+// fold the partial arrays of a step into `scal` (residual always; point / camera parts optional)
+static void launch_scalars(ba_handle* h, bool with_step) {
   Scope sc(h, BA_K_MISC);
-  hipLaunchKernelGGL(k_reduce_cols, dim3(1), dim3(256), 0, h->stream, part, nrows, ncols, out);
+  hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, h->stream, h->partR.p, NPART * h->Nc, h->partB.p,
+                     (with_step && h->Np > 0) ? h->nblkP : 0, h->partC.p, with_step ? h->nblkV : 0, h->scal.p);
 }
 static void launch_linearize(ba_handle* h, bool robust, double fscale) {
   const int w = h->cur;
   {
     Scope sc(h, BA_K_LINEARIZE_CAM);
-    auto kern = robust ? k_linearize_cam<true> : k_linearize_cam<false>;
-    hipLaunchKernelGGL(kern, dim3(h->Nc), dim3(CAM_BLOCK), 0, h->stream, h->cs[w].p, h->pts[w].p, h->cam_off.p,
-                       h->c_pt.p, h->c_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->fixed, h->Hcc.p,
-                       h->Hcc.p + 21 * (size_t)h->Nc, h->c_w.p);
+    auto kern = robust ? k_cam_linearize<true> : k_cam_linearize<false>;
+    hipLaunchKernelGGL(kern, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[w].p, h->ptab[w].p, h->offk.p,
+                       h->c_pt.p, h->c_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, h->c_w.p, h->partL.p);
+  }
+  {
+    Scope sc(h, BA_K_MISC);
+    hipLaunchKernelGGL(k_lin_finalize, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->partL.p, h->cs[w].p, h->Nc,
+                       h->fixed, h->HccBc.p, bc_ptr(h), h->camA.p);
   }
   if (h->Np > 0) {
     Scope sc(h, BA_K_LINEARIZE_PT);
-    auto kern = robust ? k_linearize_pt<true> : k_linearize_pt<false>;
-    hipLaunchKernelGGL(kern, dim3(h->nblkA), dim3(PT_BLOCK), 0, h->stream, h->cs[w].p, h->pts[w].p, h->pt_off.p,
-                       h->p_cam.p, h->p_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Np, h->Hpp.p,
-                       h->bp.p, h->p_w.p);
+#define LP_ARGS h->camA.p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, \
+                h->Np, h->Nc, h->ppb, h->Hpp.p, h->bp.p, h->p_w.p
+    const size_t lds = h->lds_tab ? h->lds_bytes : 0;
+    if (h->lds_tab) {
+      if (robust) hipLaunchKernelGGL((k_pt_linearize<true, true>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, LP_ARGS);
+      else        hipLaunchKernelGGL((k_pt_linearize<false, true>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, LP_ARGS);
+    } else {
+      if (robust) hipLaunchKernelGGL((k_pt_linearize<true, false>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, LP_ARGS);
+      else        hipLaunchKernelGGL((k_pt_linearize<false, false>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, LP_ARGS);
+    }
+#undef LP_ARGS
   }
 }
-static double* bc_ptr(ba_handle* h) { return h->Hcc.p + 21 * (size_t)h->Nc; }
-
-static void launch_damp(ba_handle* h, double lambda) {
-  {
-    Scope sc(h, BA_K_MISC);
-    hipLaunchKernelGGL(k_damp_cameras, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->Hcc.p, lambda, h->Nc,
-                       h->fixed, h->Hccd.p);
-  }
-  if (h->Np > 0) {
-    Scope sc(h, BA_K_POINT_INVERT);
-    hipLaunchKernelGGL(k_point_invert, dim3(h->nblkA), dim3(PT_BLOCK), 0, h->stream, h->Hpp.p, h->bp.p, lambda,
-                       h->Np, h->Hppinv.p, h->y0.p);
-  }
+static void launch_point_invert(ba_handle* h, double lambda) {
+  if (h->Np == 0) return;
+  Scope sc(h, BA_K_POINT_INVERT);
+  hipLaunchKernelGGL(k_point_invert, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp.p, h->bp.p, lambda,
+                     h->Np, h->Hppinv.p, h->y0.p, h->ptab[h->cur].p);
 }
-// camera pass on `yvec`; MODE 1 = unconditional (rhs / test hooks), MODE 0 = PCG iteration k
-static void launch_schur_cam(ba_handle* h, bool robust, int mode, const double* yvec, int k, double tol2, int min_iters) {
-  Scope sc(h, BA_K_SCHUR_CAM);
+// camera pass of the Schur product on the y slot of the current point table
+//   diag: also the Schur-Jacobi blocks; pcg: iteration k with early exit
+static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int k, double tol2, int min_iters) {
+  Scope sc(h, diag ? BA_K_PRECOND : BA_K_SCHUR_CAM);
   const int w = h->cur;
-#define SC_ARGS h->cs[w].p, h->pts[w].p, h->cam_off.p, h->c_pt.p, h->c_w.p, yvec, h->K4[0], h->K4[1], h->Nc, h->fixed, \
-                h->comm.p, h->partA.p, h->nblkA, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters
-  if (mode == 0) {
-    if (robust) hipLaunchKernelGGL((k_schur_cam<true, 0>), dim3(h->Nc + 1), dim3(CAM_BLOCK), 0, h->stream, SC_ARGS);
-    else        hipLaunchKernelGGL((k_schur_cam<false, 0>), dim3(h->Nc + 1), dim3(CAM_BLOCK), 0, h->stream, SC_ARGS);
+#define CS_ARGS h->cs[w].p, h->ptab[w].p, h->offk.p, h->c_pt.p, h->c_w.p, h->Hppinv.p, h->K4[0], h->K4[1], h->Nc, h->fixed, \
+                h->part6.p, h->partE.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters
+  const dim3 g(cam_grid(h)), b(64 * WPB);
+  if (diag) {
+    if (robust) hipLaunchKernelGGL((k_cam_schur<true, true, false>), g, b, 0, h->stream, CS_ARGS);
+    else        hipLaunchKernelGGL((k_cam_schur<false, true, false>), g, b, 0, h->stream, CS_ARGS);
+  } else if (pcg) {
+    if (robust) hipLaunchKernelGGL((k_cam_schur<true, false, true>), g, b, 0, h->stream, CS_ARGS);
+    else        hipLaunchKernelGGL((k_cam_schur<false, false, true>), g, b, 0, h->stream, CS_ARGS);
   } else {
-    if (robust) hipLaunchKernelGGL((k_schur_cam<true, 1>), dim3(h->Nc + 1), dim3(CAM_BLOCK), 0, h->stream, SC_ARGS);
-    else        hipLaunchKernelGGL((k_schur_cam<false, 1>), dim3(h->Nc + 1), dim3(CAM_BLOCK), 0, h->stream, SC_ARGS);
+    if (robust) hipLaunchKernelGGL((k_cam_schur<true, false, false>), g, b, 0, h->stream, CS_ARGS);
+    else        hipLaunchKernelGGL((k_cam_schur<false, false, false>), g, b, 0, h->stream, CS_ARGS);
   }
-#undef SC_ARGS
+#undef CS_ARGS
 }
-// point pass with camera vector vtil; MODE 0 = PCG (y, partA), MODE 1 = back substitution
-static void launch_schur_pt(ba_handle* h, bool robust, int mode, int k, double tol2, int min_iters) {
+// point pass with the vtil half of camA; mode 0 = PCG iteration k, mode 1 = back substitution
+static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double tol2, int min_iters) {
   if (h->Np == 0) return;
   Scope sc(h, mode == 0 ? BA_K_SCHUR_PT : BA_K_BACKSUB);
   const int w = h->cur;
-#define SP_ARGS h->cs[w].p, h->pts[w].p, h->pt_off.p, h->p_cam.p, h->p_w.p, h->vtil.p, h->Hppinv.p, h->K4[0], h->K4[1], \
-                h->Np, h->fixed, h->y.p, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0.p,       \
-                h->Hpp.p, h->bp.p, h->pts[1 - w].p, h->partB.p
-  if (mode == 0) {
-    if (robust) hipLaunchKernelGGL((k_schur_pt<true, 0>), dim3(h->nblkA), dim3(PT_BLOCK), 0, h->stream, SP_ARGS);
-    else        hipLaunchKernelGGL((k_schur_pt<false, 0>), dim3(h->nblkA), dim3(PT_BLOCK), 0, h->stream, SP_ARGS);
+#define PS_ARGS h->camA.p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_w.p, h->Hppinv.p, h->K4[0], h->K4[1], h->Np, h->Nc, \
+                h->fixed, h->ppb, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0.p, h->Hpp.p,       \
+                h->bp.p, h->ptab[1 - w].p, h->partB.p
+  const dim3 g(h->nblkP), b(PT_THREADS);
+  const size_t lds = h->lds_tab ? h->lds_bytes : 0;
+#define PS_LAUNCH(R, M, L) hipLaunchKernelGGL((k_pt_schur<R, M, L>), g, b, lds, h->stream, PS_ARGS)
+  if (h->lds_tab) {
+    if (mode == 0) { if (robust) PS_LAUNCH(true, 0, true); else PS_LAUNCH(false, 0, true); }
+    else           { if (robust) PS_LAUNCH(true, 1, true); else PS_LAUNCH(false, 1, true); }
   } else {
-    if (robust) hipLaunchKernelGGL((k_schur_pt<true, 1>), dim3(h->nblkA), dim3(PT_BLOCK), 0, h->stream, SP_ARGS);
-    else        hipLaunchKernelGGL((k_schur_pt<false, 1>), dim3(h->nblkA), dim3(PT_BLOCK), 0, h->stream, SP_ARGS);
+    if (mode == 0) { if (robust) PS_LAUNCH(true, 0, false); else PS_LAUNCH(false, 0, false); }
+    else           { if (robust) PS_LAUNCH(true, 1, false); else PS_LAUNCH(false, 1, false); }
   }
-#undef SP_ARGS
+#undef PS_LAUNCH
+#undef PS_ARGS
+}
+// multi-rank: fold partials -> comm (+ commE) and all-reduce them.  Single rank: nothing.
+static int exchange_schur(ba_handle* h, bool with_diag, bool with_uy) {
+  if (h->world == 1) return BA_OK;
+  {
+    Scope sc(h, BA_K_MISC);
+    hipLaunchKernelGGL(k_fold_partials, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->part6.p,
+                       with_diag ? h->partE.p : (const double*)nullptr, with_uy ? h->partA.p : (const double*)nullptr,
+                       h->nblkP, h->Nc, h->comm.p, with_diag ? h->commE.p : (double*)nullptr);
+  }
+  if (int rc = allreduce(h, h->comm.p, 6 * (size_t)h->Nc + 1)) return rc;
+  if (with_diag) return allreduce(h, h->commE.p, 21 * (size_t)h->Nc);
+  return BA_OK;
+}
+static const double* wy_src(ba_handle* h) { return h->world == 1 ? h->part6.p : h->comm.p; }
+static const double* e_src(ba_handle* h) { return h->world == 1 ? h->partE.p : h->commE.p; }
+static int wy_parts(ba_handle* h) { return h->world == 1 ? NPART : 1; }
+
+static void launch_pcg_setup(ba_handle* h, double lambda, bool schur_diag) {
+  Scope sc(h, BA_K_PCG_UPDATE);
+  hipLaunchKernelGGL(k_pcg_setup, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->HccBc.p, bc_ptr(h), wy_src(h), e_src(h),
+                     wy_parts(h), h->cs[h->cur].p, lambda, schur_diag ? 1 : 0, h->Nc, h->fixed, h->Hccd.p, h->Minv.p,
+                     h->gvec.p, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA.p, h->partV.p, h->st.p);
 }
 
 // --------------------------------------------------------------------- K1 entry point
@@ -481,7 +569,7 @@ extern "C" int ba_residuals(ba_handle* h, int32_t loss, double f_scale, double* 
     rdev = h->rbuf.p;
   }
   launch_residual(h, h->cur, loss == BA_LOSS_HUBER, f_scale, rdev);
-  launch_reduce(h, h->partR.p, h->Nc, 2, h->scal.p);
+  launch_scalars(h, false);
   if (int rc = allreduce(h, h->scal.p, 2)) return rc;
   HIPCHECK(hipMemcpyAsync(h->h_scal, h->scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (rdev) HIPCHECK(hipMemcpyAsync(r, rdev, 2 * (size_t)h->Nobs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -499,11 +587,11 @@ extern "C" int ba_linearize(ba_handle* h, int32_t loss, double f_scale, double* 
   if (!(f_scale > 0)) return fail(BA_ERR_INVALID, "f_scale must be positive");
   if (set_device(h)) return BA_ERR_HIP;
   launch_linearize(h, loss == BA_LOSS_HUBER, f_scale);
-  if (int rc = allreduce(h, h->Hcc.p, 27 * (size_t)h->Nc)) return rc;
+  if (int rc = allreduce(h, h->HccBc.p, 27 * (size_t)h->Nc)) return rc;
   h->linearized = true;
   h->lin_robust = (loss == BA_LOSS_HUBER);
   h->lin_fscale = f_scale;
-  if (Hcc) HIPCHECK(hipMemcpyAsync(Hcc, h->Hcc.p, 21 * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (Hcc) HIPCHECK(hipMemcpyAsync(Hcc, h->HccBc.p, 21 * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (bc) HIPCHECK(hipMemcpyAsync(bc, bc_ptr(h), 6 * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (Hpp && h->Np) HIPCHECK(hipMemcpyAsync(Hpp, h->Hpp.p, 6 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (bp && h->Np) HIPCHECK(hipMemcpyAsync(bp, h->bp.p, 3 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -512,24 +600,19 @@ extern "C" int ba_linearize(ba_handle* h, int32_t loss, double f_scale, double* 
 }
 
 // --------------------------------------------------------------------- K4 test hooks
+static int damped_system(ba_handle* h, double lambda, bool schur_diag) {
+  launch_point_invert(h, lambda);
+  launch_cam_schur(h, h->lin_robust, schur_diag, false, 0, 0.0, 0);
+  if (int rc = exchange_schur(h, schur_diag, false)) return rc;
+  launch_pcg_setup(h, lambda, schur_diag);
+  return BA_OK;
+}
+
 extern "C" int ba_schur_rhs(ba_handle* h, double lambda, double* g) {
   if (!h || !g) return fail(BA_ERR_INVALID, "null argument");
   if (!h->linearized) return fail(BA_ERR_STATE, "ba_linearize first");
   if (set_device(h)) return BA_ERR_HIP;
-  launch_damp(h, lambda);
-  launch_schur_cam(h, h->lin_robust, 1, h->y0.p, 0, 0.0, 0);
-  if (int rc = allreduce(h, h->comm.p, 6 * (size_t)h->Nc + 1)) return rc;
-  {
-    Scope sc(h, BA_K_PRECOND);
-    hipLaunchKernelGGL(k_precond_invert, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->Hccd.p,
-                       (const double*)nullptr, h->Nc, h->Minv.p);
-  }
-  {
-    Scope sc(h, BA_K_MISC);
-    hipLaunchKernelGGL(k_pcg_init, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, bc_ptr(h), h->comm.p, h->Hccd.p,
-                       h->Minv.p, h->cs[h->cur].p, h->Nc, h->fixed, h->gvec.p, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p,
-                       h->vtil.p, h->partV.p, h->st.p);
-  }
+  if (int rc = damped_system(h, lambda, true)) return rc;
   HIPCHECK(hipMemcpyAsync(g, h->gvec.p, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
   return BA_OK;
@@ -539,23 +622,21 @@ extern "C" int ba_schur_apply(ba_handle* h, double lambda, const double* v, doub
   if (!h || !v || !out) return fail(BA_ERR_INVALID, "null argument");
   if (!h->linearized) return fail(BA_ERR_STATE, "ba_linearize first");
   if (set_device(h)) return BA_ERR_HIP;
-  launch_damp(h, lambda);
-  HIPCHECK(hipMemcpyAsync(h->x.p, v, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (int rc = damped_system(h, lambda, false)) return rc;       // Hccd, Hppinv
+  HIPCHECK(hipMemcpyAsync(h->vin.p, v, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
   {
     Scope sc(h, BA_K_MISC);
-    hipLaunchKernelGGL(k_vtil, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->x.p, h->cs[h->cur].p, h->Nc,
-                       h->fixed, h->vtil.p);
-    // a PCG state that is not "done" so MODE 0 of the point pass runs
+    hipLaunchKernelGGL(k_vtil, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->vin.p, h->cs[h->cur].p, h->Nc,
+                       h->fixed, h->camA.p);
     hipLaunchKernelGGL(k_pcg_reset, dim3(1), dim3(64), 0, h->stream, h->st.p, h->partV.p, h->nblkV);
   }
-  // point pass writes y = Hppinv W^T v (tol2 < 0 and a huge min_iters keep pcg_finished false)
-  launch_schur_pt(h, h->lin_robust, 0, 0, -1.0, 1 << 30);
-  launch_schur_cam(h, h->lin_robust, 1, h->y.p, 0, 0.0, 0);
-  if (int rc = allreduce(h, h->comm.p, 6 * (size_t)h->Nc + 1)) return rc;
+  launch_pt_schur(h, h->lin_robust, 0, 0, -1.0, 1 << 30);        // y = Hppinv W^T v into the point table
+  launch_cam_schur(h, h->lin_robust, false, false, 0, 0.0, 0);
+  if (int rc = exchange_schur(h, false, true)) return rc;
   {
     Scope sc(h, BA_K_MISC);
-    hipLaunchKernelGGL(k_schur_combine, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->Hccd.p, h->x.p, h->comm.p,
-                       h->Nc, h->fixed, h->z.p);
+    hipLaunchKernelGGL(k_schur_combine, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->Hccd.p, h->vin.p, wy_src(h),
+                       wy_parts(h), h->cs[h->cur].p, h->Nc, h->fixed, h->z.p);
   }
   HIPCHECK(hipMemcpyAsync(out, h->z.p, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -588,13 +669,9 @@ static double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// scalars block layout (device `scal`, pinned mirror `h_scal`)
-//  [0] sse  [1] rho-sum  [2] pt g.d  [3] pt dDd  [4] pt |d|^2  [5] pt |x|^2      <- all-reduced (sum)
-//  [8] cam g.d  [9] cam dDd  [10] dc.r  [11] cam |d|^2  [12] cam |x|^2          <- replicated
-//  [16] max|bc|  [17] max|bp|
 static int eval_cost(ba_handle* h, int which, bool robust, double fscale, double* sse, double* cost) {
   launch_residual(h, which, robust, fscale, nullptr);
-  launch_reduce(h, h->partR.p, h->Nc, 2, h->scal.p);
+  launch_scalars(h, false);
   if (int rc = allreduce(h, h->scal.p, 2)) return rc;
   HIPCHECK(hipMemcpyAsync(h->h_scal, h->scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -613,6 +690,7 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   if (set_device(h)) return BA_ERR_HIP;
   memset(sum, 0, sizeof *sum);
   const bool robust = opts->loss == BA_LOSS_HUBER;
+  const bool schur_diag = opts->preconditioner == BA_PRECOND_SCHUR_JACOBI;
   const double fs = opts->f_scale;
   const int Nc = h->Nc;
   h->profile = opts->profile != 0;
@@ -634,20 +712,19 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     double t0 = now_s();
     if (need_linearize) {
       launch_linearize(h, robust, fs);
-      if (int rc = allreduce(h, h->Hcc.p, 27 * (size_t)Nc)) return rc;
+      if (int rc = allreduce(h, h->HccBc.p, 27 * (size_t)Nc)) return rc;
       h->linearized = true; h->lin_robust = robust; h->lin_fscale = fs;
       need_linearize = false;
       if (opts->gtol > 0) {
         {
           Scope sc(h, BA_K_MISC);
-          hipLaunchKernelGGL(k_absmax, dim3(1), dim3(256), 0, h->stream, bc_ptr(h), 6 * (size_t)Nc, h->scal.p + 16);
-          hipLaunchKernelGGL(k_absmax, dim3(1), dim3(256), 0, h->stream, h->bp.p, 3 * (size_t)h->Np, h->scal.p + 17);
+          hipLaunchKernelGGL(k_absmax, dim3(1), dim3(256), 0, h->stream, bc_ptr(h), 6 * (size_t)Nc, h->scal.p + S_GMAX_C);
+          hipLaunchKernelGGL(k_absmax, dim3(1), dim3(256), 0, h->stream, h->bp.p, 3 * (size_t)h->Np, h->scal.p + S_GMAX_P);
         }
-        HIPCHECK(hipMemcpyAsync(h->h_scal + 16, h->scal.p + 16, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipMemcpyAsync(h->h_scal + S_GMAX_C, h->scal.p + S_GMAX_C, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(hipStreamSynchronize(h->stream));
-        double gmax = std::max(h->h_scal[16], h->h_scal[17]);
-        if (h->world > 1) {   // max over shards of the point gradient: tiny host-visible all-reduce of a sum is not a max;
-          // every rank sees the same bc (all-reduced); bp is shard-local, so fold it through RCCL max
+        double gmax = std::max(h->h_scal[S_GMAX_C], h->h_scal[S_GMAX_P]);
+        if (h->world > 1) {   // bc is all-reduced (identical on every rank); bp is shard-local -> max over ranks
           HIPCHECK(hipMemcpyAsync(h->scal.p + 18, &gmax, sizeof(double), hipMemcpyHostToDevice, h->stream));
           ncclResult_t r = g_rccl.AllReduce(h->scal.p + 18, h->scal.p + 18, 1, ncclDouble, ncclMax, h->nccl, h->stream);
           if (r != ncclSuccess) return fail(BA_ERR_COMM, "ncclAllReduce(max) failed");
@@ -658,31 +735,8 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
         if (gmax <= opts->gtol) { status = 3; break; }
       }
     }
-    // ---- damped system, right-hand side, preconditioner
-    launch_damp(h, lambda);
-    launch_schur_cam(h, robust, 1, h->y0.p, 0, 0.0, 0);
-    if (int rc = allreduce(h, h->comm.p, 6 * (size_t)Nc + 1)) return rc;
-    if (opts->preconditioner == BA_PRECOND_SCHUR_JACOBI) {
-      {
-        Scope sc(h, BA_K_PRECOND);
-        auto kern = robust ? k_schur_diag<true> : k_schur_diag<false>;
-        hipLaunchKernelGGL(kern, dim3(Nc), dim3(CAM_BLOCK), 0, h->stream, h->cs[h->cur].p, h->pts[h->cur].p,
-                           h->cam_off.p, h->c_pt.p, h->c_w.p, h->Hppinv.p, h->K4[0], h->K4[1], h->fixed, h->E.p);
-      }
-      if (int rc = allreduce(h, h->E.p, 21 * (size_t)Nc)) return rc;
-    }
-    {
-      Scope sc(h, BA_K_PRECOND);
-      hipLaunchKernelGGL(k_precond_invert, dim3((Nc + 63) / 64), dim3(64), 0, h->stream, h->Hccd.p,
-                         opts->preconditioner == BA_PRECOND_SCHUR_JACOBI ? (const double*)h->E.p : (const double*)nullptr,
-                         Nc, h->Minv.p);
-    }
-    {
-      Scope sc(h, BA_K_PCG_UPDATE);
-      hipLaunchKernelGGL(k_pcg_init, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, bc_ptr(h), h->comm.p, h->Hccd.p,
-                         h->Minv.p, h->cs[h->cur].p, Nc, h->fixed, h->gvec.p, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p,
-                         h->vtil.p, h->partV.p, h->st.p);
-    }
+    // ---- damped system, right-hand side, preconditioner, first PCG vectors
+    if (int rc = damped_system(h, lambda, schur_diag)) return rc;
     double t1 = now_s();
     sum->seconds_linearize += t1 - t0;
     // ---- PCG
@@ -690,13 +744,15 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     while (k < opts->pcg_max_iters) {
       const int kend = std::min(opts->pcg_max_iters, k + check_every);
       for (; k < kend; ++k) {
-        launch_schur_pt(h, robust, 0, k, tol2, opts->pcg_min_iters);
-        launch_schur_cam(h, robust, 0, h->y.p, k, tol2, opts->pcg_min_iters);
-        if (int rc = allreduce(h, h->comm.p, 6 * (size_t)Nc + 1)) return rc;
+        launch_pt_schur(h, robust, 0, k, tol2, opts->pcg_min_iters);
+        launch_cam_schur(h, robust, false, true, k, tol2, opts->pcg_min_iters);
+        if (int rc = exchange_schur(h, false, true)) return rc;
         Scope sc(h, BA_K_PCG_UPDATE);
-        hipLaunchKernelGGL(k_pcg_step, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, k, h->comm.p, h->Hccd.p,
-                           h->Minv.p, h->cs[h->cur].p, Nc, h->fixed, tol2, opts->pcg_min_iters, h->x.p, h->r.p, h->p.p,
-                           h->s.p, h->z.p, h->vtil.p, h->partV.p, h->nblkV, h->st.p);
+        hipLaunchKernelGGL(k_pcg_step, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, k, wy_src(h), wy_parts(h),
+                           h->world == 1 ? (const double*)h->partA.p : (const double*)(h->comm.p + 6 * (size_t)Nc),
+                           h->world == 1 ? (h->Np > 0 ? h->nblkP : 0) : 1, h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc,
+                           h->fixed, tol2, opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA.p,
+                           h->partV.p, h->nblkV, h->st.p);
       }
       HIPCHECK(hipMemcpyAsync(h->h_st, h->st.p, 2 * sizeof(PcgState), hipMemcpyDeviceToHost, h->stream));
       HIPCHECK(hipStreamSynchronize(h->stream));
@@ -711,21 +767,19 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     {
       Scope sc(h, BA_K_MISC);
       hipLaunchKernelGGL(k_cam_update, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->cams[h->cur].p, h->x.p, h->r.p,
-                         h->Hcc.p, bc_ptr(h), h->cs[h->cur].p, Nc, h->fixed, h->cams[1 - h->cur].p, h->vtil.p, h->partC.p);
+                         h->HccBc.p, bc_ptr(h), h->cs[h->cur].p, Nc, h->fixed, h->cams[1 - h->cur].p, h->cs[1 - h->cur].p,
+                         h->camA.p, h->partC.p);
     }
-    launch_schur_pt(h, robust, 1, 0, 0.0, 0);
-    launch_cam_prepare(h, 1 - h->cur);
+    launch_pt_schur(h, robust, 1, 0, 0.0, 0);
     launch_residual(h, 1 - h->cur, robust, fs, nullptr);
-    launch_reduce(h, h->partR.p, Nc, 2, h->scal.p);
-    if (h->Np > 0) launch_reduce(h, h->partB.p, h->nblkA, 4, h->scal.p + 2);
-    launch_reduce(h, h->partC.p, h->nblkV, 5, h->scal.p + 8);
+    launch_scalars(h, true);
     if (int rc = allreduce(h, h->scal.p, 6)) return rc;
     HIPCHECK(hipMemcpyAsync(h->h_scal, h->scal.p, 16 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
     const double* S = h->h_scal;
-    const double sse_new = S[0], cost_new = 0.5 * S[1];
-    const double gTd = S[2] + S[8], dDd = S[3] + S[9], dcr = S[10];
-    const double step2 = S[4] + S[11], x2 = S[5] + S[12];
+    const double sse_new = S[S_SSE], cost_new = 0.5 * S[S_RHO];
+    const double gTd = S[S_PT_GD] + S[S_CAM_GD], dDd = S[S_PT_DDD] + S[S_CAM_DDD], dcr = S[S_DC_R];
+    const double step2 = S[S_PT_DD] + S[S_CAM_DD], x2 = S[S_PT_XX] + S[S_CAM_XX];
     const double model = 0.5 * (lambda * dDd - gTd + dcr);
     const double rho = (model > 0 && std::isfinite(cost_new)) ? (cost - cost_new) / model : -1.0;
     ++it;
@@ -769,26 +823,27 @@ extern "C" int ba_time_kernel(ba_handle* h, int slot, int reps, double* mean_us)
   if (!h || !mean_us || reps < 1) return fail(BA_ERR_INVALID, "bad argument");
   if (!h->have_params) return fail(BA_ERR_STATE, "no parameters set");
   if (set_device(h)) return BA_ERR_HIP;
-  const bool robust = h->lin_robust;
-  if ((slot == BA_K_SCHUR_PT || slot == BA_K_SCHUR_CAM || slot == BA_K_BACKSUB) && !h->linearized) {
-    launch_linearize(h, robust, h->lin_fscale);
-    launch_damp(h, 1e-4);
-    h->linearized = true;
-  }
   const bool saved = h->profile;
   h->profile = false;
+  const bool robust = h->lin_robust;
+  if (!h->linearized) {
+    launch_linearize(h, robust, h->lin_fscale);
+    h->linearized = true;
+  }
+  if (int rc = damped_system(h, 1e-4, true)) return rc;
+  hipLaunchKernelGGL(k_pcg_reset, dim3(1), dim3(64), 0, h->stream, h->st.p, h->partV.p, h->nblkV);
   hipEvent_t e0, e1;
   HIPCHECK(hipEventCreate(&e0));
   HIPCHECK(hipEventCreate(&e1));
-  hipLaunchKernelGGL(k_pcg_reset, dim3(1), dim3(64), 0, h->stream, h->st.p, h->partV.p, h->nblkV);
   auto once = [&]() {
     switch (slot) {
       case BA_K_RESIDUAL: launch_residual(h, h->cur, robust, h->lin_fscale, nullptr); break;
       case BA_K_LINEARIZE_CAM:
       case BA_K_LINEARIZE_PT: launch_linearize(h, robust, h->lin_fscale); break;
-      case BA_K_SCHUR_PT: launch_schur_pt(h, robust, 0, 0, -1.0, 1 << 30); break;
-      case BA_K_SCHUR_CAM: launch_schur_cam(h, robust, 1, h->y.p, 0, 0.0, 0); break;
-      case BA_K_POINT_INVERT: launch_damp(h, 1e-4); break;
+      case BA_K_SCHUR_PT: launch_pt_schur(h, robust, 0, 0, -1.0, 1 << 30); break;
+      case BA_K_SCHUR_CAM: launch_cam_schur(h, robust, false, false, 0, 0.0, 0); break;
+      case BA_K_PRECOND: launch_cam_schur(h, robust, true, false, 0, 0.0, 0); break;
+      case BA_K_POINT_INVERT: launch_point_invert(h, 1e-4); break;
       default: break;
     }
   };

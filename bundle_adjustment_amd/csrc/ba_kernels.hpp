@@ -1,18 +1,38 @@
-// HIP kernels of the bundle-adjustment solve step (gfx950).  Two orderings of the
-// observation list exist on the device (built once in ba_set_problem):
-//   camera order: observations of camera c are [cam_off[c], cam_off[c+1])  -> c_pt, c_uv
-//   point order:  observations of point  p are [pt_off[p],  pt_off[p+1])   -> p_cam, p_uv
-// "cam" kernels run one workgroup per camera (pose state uniform -> scalar registers,
-// block reduction of the per-camera sums), "pt" kernels one thread per point (point
-// state in registers, serial sum over its few observations).  All sums have a fixed
-// order, so results are bitwise reproducible run to run.
+// HIP kernels of the bundle-adjustment solve step (gfx950).
+//
+// Data in HBM (built once per problem in ba_set_problem, see DESIGN.md "Layout"):
+//   ptab[2][Np][8]   point records {X0 X1 X2 - y0 y1 y2 -}: one 64-byte sector per point, so a
+//                    camera-ordered pass fetches everything it needs about a point with one
+//                    sector; [cur] = accepted points, [1-cur] = trial points; y = PCG scratch
+//   camera order:    observations of camera c are [cam_off[c], cam_off[c+1]), sorted by point;
+//                    offk[c][k] splits them at the NPART point-partition boundaries
+//                    -> c_pt (int32), c_uv, c_w (double2), c_orig (caller's row)
+//   point order:     observations of point p are [pt_off[p], pt_off[p+1]) -> p_cam, p_uv, p_w
+//   cs[2][Nc][24]    per-camera state R t M (camera_state), camA[Nc][18] = R t vtil for the
+//                    point passes (staged in LDS)
+//
+// Camera passes (k_cam_*): one WAVE per (camera, point partition); the workgroup index is
+// laid out so that blockIdx % NPART is the partition.  Workgroups are dealt round-robin
+// over the 8 XCDs, so each XCD only ever touches 1/8 of the point table and keeps it in
+// its own 4 MB L2 (speed only: results do not depend on the placement).  Per-(partition,
+// camera) partial sums are combined, in fixed order, by the consuming kernel.
+//
+// Point passes (k_pt_*): LPP lanes per point walk its observations (software-prefetched
+// index stream), the per-camera table sits in LDS, lanes are combined with DPP row shifts.
+//
+// Every sum has a fixed order: results are bitwise reproducible run to run.
 #pragma once
 #include "ba_device.hpp"
+#include "ba_dpp.hpp"
 
 namespace ba {
 
-constexpr int CAM_BLOCK = 256;   // threads per camera workgroup
-constexpr int PT_BLOCK = 128;    // threads (= points) per point workgroup
+constexpr int NPART = 8;         // point partitions (= XCDs)
+constexpr int WPB = 4;           // waves (= cameras) per workgroup in camera passes
+constexpr int PT = 8;            // doubles per point record
+constexpr int TA = 18;           // doubles per camera in camA: R[9] t[3] vtil[6]
+constexpr int PT_THREADS = 1024; // threads per workgroup in point passes
+constexpr int LPP = 2;           // lanes per point in point passes
 constexpr int VEC_BLOCK = 64;    // threads (= cameras) per workgroup in camera-vector kernels
 
 // PCG device state, two copies indexed by iteration parity (see k_pcg_step)
@@ -21,31 +41,75 @@ struct PcgState {
   int done, iters, flag, pad1;     // done: 1 converged, 2 breakdown
 };
 
+// scalar slots written by k_scalars (device `scal`)
+enum { S_SSE = 0, S_RHO = 1, S_PT_GD = 2, S_PT_DDD = 3, S_PT_DD = 4, S_PT_XX = 5,
+       S_CAM_GD = 8, S_CAM_DDD = 9, S_DC_R = 10, S_CAM_DD = 11, S_CAM_XX = 12, S_GMAX_C = 16, S_GMAX_P = 17 };
+
+__device__ inline double rcp_guarded(double z) { return (z != 0.0) ? 1.0 / z : 1.0; }
+
+// -------------------------------------------------------------------------------------
+// small per-camera / per-point kernels
 // -------------------------------------------------------------------------------------
 __global__ void k_cam_prepare(const double* __restrict__ cams, double* __restrict__ cs, int n_cams) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < n_cams) camera_state(cams + 6 * c, cs + CS * c);
 }
 
-// K1: residuals / cost at (cs, pts).  One workgroup per camera.
-//   r_out (nullable): residual pairs scattered to the caller's observation order.
-//   part[c][0] = sum r^2, part[c][1] = sum rho-term over camera c's observations.
+// pts (Np,3) -> X slots of the point table; table (Np,8) -> pts
+__global__ void k_pack_points(const double* __restrict__ pts, int n_pts, double* __restrict__ ptab) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pts) return;
+  double* o = ptab + PT * (size_t)p;
+  o[0] = pts[3 * (size_t)p]; o[1] = pts[3 * (size_t)p + 1]; o[2] = pts[3 * (size_t)p + 2];
+  o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = 0;
+}
+__global__ void k_unpack_points(const double* __restrict__ ptab, int n_pts, double* __restrict__ pts) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pts) return;
+  const double* s = ptab + PT * (size_t)p;
+  pts[3 * (size_t)p] = s[0]; pts[3 * (size_t)p + 1] = s[1]; pts[3 * (size_t)p + 2] = s[2];
+}
+
+// -------------------------------------------------------------------------------------
+// camera passes: wave = (camera c, partition k)
+// -------------------------------------------------------------------------------------
+struct Seg { int c, k, beg, end, lane; };
+__device__ inline bool cam_segment(const int* __restrict__ offk, int n_cams, Seg& s) {
+  s.k = blockIdx.x % NPART;
+  s.c = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / NPART) * WPB + (int)(threadIdx.x >> 6));
+  s.lane = threadIdx.x & 63;
+  if (s.c >= n_cams) return false;
+  s.beg = offk[s.c * (NPART + 1) + s.k];
+  s.end = offk[s.c * (NPART + 1) + s.k + 1];
+  return true;
+}
+template <int N>
+__device__ inline void wave_store_sums(double (&acc)[N], int lane, double* __restrict__ dst) {
+#pragma unroll
+  for (int q = 0; q < N; ++q) acc[q] = wave_scan_sum_dpp(acc[q]);
+  if (lane == 63) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) dst[q] = acc[q];
+  }
+}
+
+// K1: residuals / cost.  partR[(k*Nc + c)*2 + {0,1}] = sum r^2, sum rho-term.
 template <bool ROBUST>
-__global__ void __launch_bounds__(CAM_BLOCK)
-k_residual_cam(const double* __restrict__ cs, const double* __restrict__ pts, const int* __restrict__ cam_off,
+__global__ void __launch_bounds__(64 * WPB)
+k_cam_residual(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
                const int* __restrict__ c_pt, const double2* __restrict__ c_uv, const int* __restrict__ c_orig,
-               double fx, double fy, double cx, double cy, double hub_c,
-               double* __restrict__ r_out, double* __restrict__ part) {
-  __shared__ double sm[2 * (CAM_BLOCK / 64)];
-  const int c = blockIdx.x;
-  const double* cam = cs + CS * c;
-  const int beg = cam_off[c], end = cam_off[c + 1];
+               double fx, double fy, double cx, double cy, double hub_c, int n_cams,
+               double* __restrict__ r_out, double* __restrict__ partR) {
+  Seg s;
+  if (!cam_segment(offk, n_cams, s)) return;
+  const double* cam = cs + CS * s.c;
   double acc[2] = {0.0, 0.0};
-  for (int i = beg + threadIdx.x; i < end; i += CAM_BLOCK) {
+  for (int i = s.beg + s.lane; i < s.end; i += 64) {
     const int p = c_pt[i];
     const double2 uv = c_uv[i];
+    const double4 X = *(const double4*)(ptab + PT * (size_t)p);
     double xh, yh;
-    obs_project(cam, pts[3 * p], pts[3 * p + 1], pts[3 * p + 2], xh, yh);
+    obs_project(cam, X.x, X.y, X.z, xh, yh);
     const double ru = uv.x - (xh * fx + cx);
     const double rv = uv.y - (yh * fy + cy);
     acc[0] += ru * ru + rv * rv;
@@ -61,37 +125,39 @@ k_residual_cam(const double* __restrict__ cs, const double* __restrict__ pts, co
       r_out[2 * (size_t)o + 1] = rv;
     }
   }
-  block_sum<2>(acc, sm);
-  if (threadIdx.x == 0) {
-    part[2 * c] = acc[0];
-    part[2 * c + 1] = ROBUST ? acc[1] : acc[0];
-  }
+  if (!ROBUST) acc[1] = acc[0];
+  wave_store_sums<2>(acc, s.lane, partR + ((size_t)s.k * n_cams + s.c) * 2);
 }
 
-// K2a: camera half of the normal equations.  One workgroup per camera:
-//   Hcc[c] (21, packed upper) = sum Jc^T w Jc,  bc[c] (6) = sum Jc^T w r
-// with Jc = [P [X]x M | -dpi].  The sums are taken over A = P [X]x (pre-M) and the
-// M^T (.) M congruence is applied once per camera after the block reduction.
-// Also stores the IRLS weights of camera-ordered observations (c_w) when ROBUST.
+// rows of the pre-M camera Jacobian: J0 = [P0 x X | -d00 0 -d02], J1 = [P1 x X | 0 -d11 -d12]
+__device__ inline void cam_jac_rows(const Geom& g, double X0, double X1, double X2, double (&J0)[6], double (&J1)[6]) {
+  J0[0] = g.P[1] * X2 - g.P[2] * X1; J0[1] = g.P[2] * X0 - g.P[0] * X2; J0[2] = g.P[0] * X1 - g.P[1] * X0;
+  J1[0] = g.P[4] * X2 - g.P[5] * X1; J1[1] = g.P[5] * X0 - g.P[3] * X2; J1[2] = g.P[3] * X1 - g.P[4] * X0;
+  J0[3] = -g.d00; J0[4] = 0.0;    J0[5] = -g.d02;
+  J1[3] = 0.0;    J1[4] = -g.d11; J1[5] = -g.d12;
+}
+
+// K2a: camera half of the normal equations, pre-M sums (the M^T . M congruence is applied
+// once per camera in k_lin_finalize):  partL[(k*Nc + c)*27 + ..] = 21 (A upper) + 6 (g).
+// Stores the IRLS weights of camera-ordered observations (c_w) when ROBUST.
 template <bool ROBUST>
-__global__ void __launch_bounds__(CAM_BLOCK)
-k_linearize_cam(const double* __restrict__ cs, const double* __restrict__ pts, const int* __restrict__ cam_off,
+__global__ void __launch_bounds__(64 * WPB)
+k_cam_linearize(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
                 const int* __restrict__ c_pt, const double2* __restrict__ c_uv,
-                double fx, double fy, double cx, double cy, double hub_c, int fixed_cam,
-                double* __restrict__ Hcc, double* __restrict__ bc, double2* __restrict__ c_w) {
-  __shared__ double sm[27 * (CAM_BLOCK / 64)];
-  const int c = blockIdx.x;
-  const double* cam = cs + CS * c;
-  const int beg = cam_off[c], end = cam_off[c + 1];
+                double fx, double fy, double cx, double cy, double hub_c, int n_cams,
+                double2* __restrict__ c_w, double* __restrict__ partL) {
+  Seg s;
+  if (!cam_segment(offk, n_cams, s)) return;
+  const double* cam = cs + CS * s.c;
   double acc[27];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-  for (int i = beg + threadIdx.x; i < end; i += CAM_BLOCK) {
+  for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+  for (int i = s.beg + s.lane; i < s.end; i += 64) {
     const int p = c_pt[i];
     const double2 uv = c_uv[i];
-    const double X0 = pts[3 * p], X1 = pts[3 * p + 1], X2 = pts[3 * p + 2];
+    const double4 X = *(const double4*)(ptab + PT * (size_t)p);
     Geom g;
-    obs_geom(cam, X0, X1, X2, fx, fy, g);
+    obs_geom(cam, X.x, X.y, X.z, fx, fy, g);
     const double ru = uv.x - (g.xh * fx + cx);
     const double rv = uv.y - (g.yh * fy + cy);
     double w0 = 1.0, w1 = 1.0;
@@ -101,12 +167,8 @@ k_linearize_cam(const double* __restrict__ cs, const double* __restrict__ pts, c
       huber(rv, hub_c, t, w1);
       c_w[i] = make_double2(w0, w1);
     }
-    // rows of the pre-M camera Jacobian: J0 = [P0 x X | -d00 0 -d02], J1 = [P1 x X | 0 -d11 -d12]
     double J0[6], J1[6];
-    J0[0] = g.P[1] * X2 - g.P[2] * X1; J0[1] = g.P[2] * X0 - g.P[0] * X2; J0[2] = g.P[0] * X1 - g.P[1] * X0;
-    J1[0] = g.P[4] * X2 - g.P[5] * X1; J1[1] = g.P[5] * X0 - g.P[3] * X2; J1[2] = g.P[3] * X1 - g.P[4] * X0;
-    J0[3] = -g.d00; J0[4] = 0.0;    J0[5] = -g.d02;
-    J1[3] = 0.0;    J1[4] = -g.d11; J1[5] = -g.d12;
+    cam_jac_rows(g, X.x, X.y, X.z, J0, J1);
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
       const double wa0 = w0 * J0[a], wa1 = w1 * J1[a];
@@ -115,87 +177,294 @@ k_linearize_cam(const double* __restrict__ cs, const double* __restrict__ pts, c
       acc[21 + a] += wa0 * ru + wa1 * rv;
     }
   }
-  block_sum<27>(acc, sm);
+  wave_store_sums<27>(acc, s.lane, partL + ((size_t)s.k * n_cams + s.c) * 27);
+}
+
+// symmetric congruence H = T^T A T, T = diag(M, I6-3), A given as full 6x6
+__device__ inline void m_congruence(const double* __restrict__ M, double (&A)[6][6]) {
+  double B[6][6];
+  for (int i = 0; i < 6; ++i) {
+    for (int j = 0; j < 3; ++j) B[i][j] = A[i][0] * M[j] + A[i][1] * M[3 + j] + A[i][2] * M[6 + j];
+    for (int j = 3; j < 6; ++j) B[i][j] = A[i][j];
+  }
+  for (int j = 0; j < 6; ++j) {
+    const double h0 = M[0] * B[0][j] + M[3] * B[1][j] + M[6] * B[2][j];
+    const double h1 = M[1] * B[0][j] + M[4] * B[1][j] + M[7] * B[2][j];
+    const double h2 = M[2] * B[0][j] + M[5] * B[1][j] + M[8] * B[2][j];
+    A[0][j] = h0; A[1][j] = h1; A[2][j] = h2;
+    A[3][j] = B[3][j]; A[4][j] = B[4][j]; A[5][j] = B[5][j];
+  }
+}
+
+// Combine the NPART partial sums of k_cam_linearize (fixed order), apply M:
+//   Hcc[c] (21) = Jc^T w Jc,  bc[c] (6) = Jc^T w r  (zero for the fixed camera);
+// also refresh the R|t half of camA for the point passes.
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_lin_finalize(const double* __restrict__ partL, const double* __restrict__ cs, int n_cams, int fixed_cam,
+               double* __restrict__ Hcc, double* __restrict__ bc, double* __restrict__ camA) {
+  const int c = blockIdx.x * VEC_BLOCK + threadIdx.x;
+  if (c >= n_cams) return;
+  const double* cam = cs + CS * c;
+  for (int q = 0; q < 12; ++q) camA[TA * c + q] = cam[q];
+  double a[27];
+  for (int q = 0; q < 27; ++q) a[q] = 0.0;
+  for (int k = 0; k < NPART; ++k) {
+    const double* src = partL + ((size_t)k * n_cams + c) * 27;
+    for (int q = 0; q < 27; ++q) a[q] += src[q];
+  }
+  double* H = Hcc + 21 * c;
+  double* b = bc + 6 * c;
+  if (c == fixed_cam) {
+    for (int q = 0; q < 21; ++q) H[q] = 0.0;
+    for (int q = 0; q < 6; ++q) b[q] = 0.0;
+    return;
+  }
+  const double* M = cam + 12;
+  double A[6][6];
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) A[i][j] = a[S6(i, j)];
+  m_congruence(M, A);
+  for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) H[U6(i, j)] = A[i][j];
+  b[0] = M[0] * a[21] + M[3] * a[22] + M[6] * a[23];
+  b[1] = M[1] * a[21] + M[4] * a[22] + M[7] * a[23];
+  b[2] = M[2] * a[21] + M[5] * a[22] + M[8] * a[23];
+  b[3] = a[24]; b[4] = a[25]; b[5] = a[26];
+}
+
+// K4b: camera pass of the Schur product, pre-M:  part6[(k*Nc + c)*6 + ..] = sum Jc^T w (Jp y_p)
+// with y read from the point table.  DIAG additionally accumulates the pre-M Schur-Jacobi
+// block sum_o W_o Hppinv_p W_o^T (21 values) into partE -- used once per damping change,
+// together with the right-hand side pass (y = y0).  PCG = true: early exit once converged.
+__device__ inline bool pcg_finished(int k, const PcgState* __restrict__ st, const double* __restrict__ partV,
+                                    int nblkV, double tol2, int min_iters, double& gamma, double& zeta) {
+  const PcgState& s = st[k & 1];
+  const double* pv = partV + (size_t)(k & 1) * 2 * nblkV;
+  double g = 0, z = 0;
+  for (int b = 0; b < nblkV; ++b) { g += pv[2 * b]; z += pv[2 * b + 1]; }
+  gamma = g; zeta = z;
+  if (s.done) return true;
+  const double g0 = (k == 0) ? g : s.gamma0;
+  if (!(g > 0.0)) return true;
+  return (k >= min_iters && g <= tol2 * g0);
+}
+
+template <bool ROBUST, bool DIAG, bool PCG>
+__global__ void __launch_bounds__(64 * WPB)
+k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
+            const int* __restrict__ c_pt, const double2* __restrict__ c_w, const double* __restrict__ Hppinv,
+            double fx, double fy, int n_cams, int fixed_cam, double* __restrict__ part6, double* __restrict__ partE,
+            int kit, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2,
+            int min_iters) {
+  if (PCG) {
+    double g, z;
+    if (pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z)) return;
+  }
+  Seg s;
+  if (!cam_segment(offk, n_cams, s)) return;
+  const double* cam = cs + CS * s.c;
+  double acc[DIAG ? 27 : 6];
+#pragma unroll
+  for (int q = 0; q < (DIAG ? 27 : 6); ++q) acc[q] = 0.0;
+  if (s.c != fixed_cam) {
+    int i = s.beg + s.lane;
+    int p = (i < s.end) ? c_pt[i] : 0;
+    double2 w = make_double2(1.0, 1.0);
+    if (ROBUST && i < s.end) w = c_w[i];
+    while (i < s.end) {
+      const int in = i + 64;
+      const int pn = (in < s.end) ? c_pt[in] : 0;          // prefetch the next index / weight
+      double2 wn = make_double2(1.0, 1.0);
+      if (ROBUST && in < s.end) wn = c_w[in];
+      const double4 X = *(const double4*)(ptab + PT * (size_t)p);
+      const double4 Y = *(const double4*)(ptab + PT * (size_t)p + 4);
+      Geom g;
+      obs_geom(cam, X.x, X.y, X.z, fx, fy, g);
+      const double s0 = -(g.P[0] * Y.x + g.P[1] * Y.y + g.P[2] * Y.z) * w.x;
+      const double s1 = -(g.P[3] * Y.x + g.P[4] * Y.y + g.P[5] * Y.z) * w.y;
+      const double e0 = g.P[0] * s0 + g.P[3] * s1, e1 = g.P[1] * s0 + g.P[4] * s1, e2 = g.P[2] * s0 + g.P[5] * s1;
+      acc[0] += e1 * X.z - e2 * X.y;
+      acc[1] += e2 * X.x - e0 * X.z;
+      acc[2] += e0 * X.y - e1 * X.x;
+      acc[3] -= g.d00 * s0;
+      acc[4] -= g.d11 * s1;
+      acc[5] -= g.d02 * s0 + g.d12 * s1;
+      if (DIAG) {
+        double hi[6];
+        const double2* hp = (const double2*)(Hppinv + 6 * (size_t)p);
+        const double2 h01 = hp[0], h23 = hp[1], h45 = hp[2];
+        hi[0] = h01.x; hi[1] = h01.y; hi[2] = h23.x; hi[3] = h23.y; hi[4] = h45.x; hi[5] = h45.y;
+        double t0[3], t1[3];
+        sym3_mul(hi, g.P, t0);
+        sym3_mul(hi, g.P + 3, t1);
+        const double G00 = w.x * w.x * (g.P[0] * t0[0] + g.P[1] * t0[1] + g.P[2] * t0[2]);
+        const double G01 = w.x * w.y * (g.P[0] * t1[0] + g.P[1] * t1[1] + g.P[2] * t1[2]);
+        const double G11 = w.y * w.y * (g.P[3] * t1[0] + g.P[4] * t1[1] + g.P[5] * t1[2]);
+        double J0[6], J1[6];
+        cam_jac_rows(g, X.x, X.y, X.z, J0, J1);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          const double l0 = J0[a] * G00 + J1[a] * G01, l1 = J0[a] * G01 + J1[a] * G11;
+#pragma unroll
+          for (int b = a; b < 6; ++b) acc[6 + U6(a, b)] += l0 * J0[b] + l1 * J1[b];
+        }
+      }
+      i = in; p = pn; w = wn;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < (DIAG ? 27 : 6); ++q) acc[q] = wave_scan_sum_dpp(acc[q]);
+  if (s.lane == 63) {
+    double* o6 = part6 + ((size_t)s.k * n_cams + s.c) * 6;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) o6[q] = acc[q];
+    if (DIAG) {
+      double* oe = partE + ((size_t)s.k * n_cams + s.c) * 21;
+#pragma unroll
+      for (int q = 0; q < 21; ++q) oe[q] = acc[6 + q];
+    }
+  }
+}
+
+// Wy[c] = [M^T a ; b] from the NPART partial sums (fixed order)
+__device__ inline void combine_wy(const double* __restrict__ part6, int nparts, int n_cams, int c,
+                                  const double* __restrict__ M, double (&wy)[6]) {
+  double a[6] = {0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < nparts; ++k) {
+    const double* src = part6 + ((size_t)k * n_cams + c) * 6;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) a[q] += src[q];
+  }
+  wy[0] = M[0] * a[0] + M[3] * a[1] + M[6] * a[2];
+  wy[1] = M[1] * a[0] + M[4] * a[1] + M[7] * a[2];
+  wy[2] = M[2] * a[0] + M[5] * a[1] + M[8] * a[2];
+  wy[3] = a[3]; wy[4] = a[4]; wy[5] = a[5];
+}
+
+// Multi-rank only: fold the partial sums into one buffer that is then all-reduced:
+//   comm[6c..] = sum_k part6 (pre-M), comm[6 Nc] = sum partA, and (DIAG) commE[21c..] = sum_k partE
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_fold_partials(const double* __restrict__ part6, const double* __restrict__ partE, const double* __restrict__ partA,
+                int nblkA, int n_cams, double* __restrict__ comm, double* __restrict__ commE) {
+  const int c = blockIdx.x * VEC_BLOCK + threadIdx.x;
+  if (c < n_cams) {
+    for (int q = 0; q < 6; ++q) {
+      double a = 0;
+      for (int k = 0; k < NPART; ++k) a += part6[((size_t)k * n_cams + c) * 6 + q];
+      comm[6 * c + q] = a;
+    }
+    if (commE) for (int q = 0; q < 21; ++q) {
+      double a = 0;
+      for (int k = 0; k < NPART; ++k) a += partE[((size_t)k * n_cams + c) * 21 + q];
+      commE[21 * c + q] = a;
+    }
+  }
+  if (c == 0) {
+    double a = 0;
+    if (partA) for (int b = 0; b < nblkA; ++b) a += partA[b];
+    comm[6 * n_cams] = a;
+  }
+}
+
+// -------------------------------------------------------------------------------------
+// point passes: LPP lanes per point, camera table (camA) in LDS when it fits
+// -------------------------------------------------------------------------------------
+template <bool LDS_TAB, int ROWLEN>
+__device__ inline void load_cam_row(const double* __restrict__ tab, const double* __restrict__ camA, int c,
+                                    double (&row)[ROWLEN]) {
+  const double2* src = LDS_TAB ? (const double2*)(tab + TA * c) : (const double2*)(camA + TA * (size_t)c);
+#pragma unroll
+  for (int q = 0; q < ROWLEN / 2; ++q) { const double2 t = src[q]; row[2 * q] = t.x; row[2 * q + 1] = t.y; }
+}
+template <int BLOCK>
+__device__ inline void fill_cam_table(double* __restrict__ tab, const double* __restrict__ camA, int n_cams) {
+  for (int i = threadIdx.x; i < n_cams * TA / 2; i += BLOCK) ((double2*)tab)[i] = ((const double2*)camA)[i];
+  __syncthreads();
+}
+// deterministic workgroup sum of N values held by every wave's lane 0 -> thread 0
+template <int N, int BLOCK>
+__device__ inline void block_combine(double (&v)[N], double* __restrict__ sm) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) sm[wv * N + q] = v[q];
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    double* H = Hcc + 21 * c;
-    double* b = bc + 6 * c;
-    if (c == fixed_cam) {
-      for (int k = 0; k < 21; ++k) H[k] = 0.0;
-      for (int k = 0; k < 6; ++k) b[k] = 0.0;
-      return;
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      double a = 0;
+      for (int w = 0; w < BLOCK / 64; ++w) a += sm[w * N + q];
+      v[q] = a;
     }
-    const double* M = cam + 12;
-    // full symmetric A (pre-M) then H = T^T A T with T = diag(M, I)
-    double A[6][6], B[6][6];
-    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) A[i][j] = acc[S6(i, j)];
-    // B = A T : columns 0..2 mixed by M, 3..5 unchanged
-    for (int i = 0; i < 6; ++i) {
-      for (int j = 0; j < 3; ++j) B[i][j] = A[i][0] * M[j] + A[i][1] * M[3 + j] + A[i][2] * M[6 + j];
-      for (int j = 3; j < 6; ++j) B[i][j] = A[i][j];
-    }
-    // H = T^T B : rows 0..2 mixed by M^T
-    for (int j = 0; j < 6; ++j) {
-      double h0 = M[0] * B[0][j] + M[3] * B[1][j] + M[6] * B[2][j];
-      double h1 = M[1] * B[0][j] + M[4] * B[1][j] + M[7] * B[2][j];
-      double h2 = M[2] * B[0][j] + M[5] * B[1][j] + M[8] * B[2][j];
-      A[0][j] = h0; A[1][j] = h1; A[2][j] = h2;
-      A[3][j] = B[3][j]; A[4][j] = B[4][j]; A[5][j] = B[5][j];
-    }
-    for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) H[U6(i, j)] = A[i][j];
-    const double g0 = acc[21], g1 = acc[22], g2 = acc[23];
-    b[0] = M[0] * g0 + M[3] * g1 + M[6] * g2;
-    b[1] = M[1] * g0 + M[4] * g1 + M[7] * g2;
-    b[2] = M[2] * g0 + M[5] * g1 + M[8] * g2;
-    b[3] = acc[24]; b[4] = acc[25]; b[5] = acc[26];
   }
 }
 
-// K2b: point half.  One thread per point: Hpp[p] (6) = sum P^T w P, bp[p] (3) = -sum P^T w r,
-// and the IRLS weights of point-ordered observations (p_w) when ROBUST.
-template <bool ROBUST>
-__global__ void __launch_bounds__(PT_BLOCK)
-k_linearize_pt(const double* __restrict__ cs, const double* __restrict__ pts, const int* __restrict__ pt_off,
+// K2b: point half of the normal equations.  Hpp[p] (6) = sum P^T w P, bp[p] (3) = -sum P^T w r,
+// IRLS weights of point-ordered observations (p_w) when ROBUST.
+template <bool ROBUST, bool LDS_TAB>
+__global__ void __launch_bounds__(PT_THREADS)
+k_pt_linearize(const double* __restrict__ camA, const double* __restrict__ ptab, const int* __restrict__ pt_off,
                const int* __restrict__ p_cam, const double2* __restrict__ p_uv,
-               double fx, double fy, double cx, double cy, double hub_c, int n_pts,
+               double fx, double fy, double cx, double cy, double hub_c, int n_pts, int n_cams, int pts_per_block,
                double* __restrict__ Hpp, double* __restrict__ bp, double2* __restrict__ p_w) {
-  const int p = blockIdx.x * PT_BLOCK + threadIdx.x;
-  if (p >= n_pts) return;
-  const double X0 = pts[3 * p], X1 = pts[3 * p + 1], X2 = pts[3 * p + 2];
-  double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-  const int beg = pt_off[p], end = pt_off[p + 1];
-  for (int j = beg; j < end; ++j) {
-    const int c = p_cam[j];
-    const double2 uv = p_uv[j];
-    Geom g;
-    obs_geom(cs + CS * c, X0, X1, X2, fx, fy, g);
-    const double ru = uv.x - (g.xh * fx + cx);
-    const double rv = uv.y - (g.yh * fy + cy);
-    double w0 = 1.0, w1 = 1.0;
-    if (ROBUST) {
-      double t;
-      huber(ru, hub_c, t, w0);
-      huber(rv, hub_c, t, w1);
-      p_w[j] = make_double2(w0, w1);
+  extern __shared__ double tab[];
+  if (LDS_TAB) fill_cam_table<PT_THREADS>(tab, camA, n_cams);
+  const int sub = threadIdx.x % LPP;
+  const int pend = min(n_pts, (int)(blockIdx.x + 1) * pts_per_block);
+  for (int p0 = blockIdx.x * pts_per_block; p0 < pend; p0 += PT_THREADS / LPP) {
+    const int p = p0 + threadIdx.x / LPP;
+    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (p < pend) {
+      const double4 X = *(const double4*)(ptab + PT * (size_t)p);
+      const int beg = pt_off[p], end = pt_off[p + 1];
+      int j = beg + sub;
+      int c = (j < end) ? p_cam[j] : 0;
+      double2 uv = (j < end) ? p_uv[j] : make_double2(0, 0);
+      while (j < end) {
+        const int jn = j + LPP;
+        const int cn = (jn < end) ? p_cam[jn] : 0;
+        const double2 uvn = (jn < end) ? p_uv[jn] : make_double2(0, 0);
+        double row[12];
+        load_cam_row<LDS_TAB, 12>(tab, camA, c, row);
+        Geom g;
+        obs_geom(row, X.x, X.y, X.z, fx, fy, g);
+        const double ru = uv.x - (g.xh * fx + cx);
+        const double rv = uv.y - (g.yh * fy + cy);
+        double w0 = 1.0, w1 = 1.0;
+        if (ROBUST) {
+          double t;
+          huber(ru, hub_c, t, w0);
+          huber(rv, hub_c, t, w1);
+          p_w[j] = make_double2(w0, w1);
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const double wa0 = w0 * g.P[q], wa1 = w1 * g.P[3 + q];
+#pragma unroll
+          for (int r = q; r < 3; ++r) a[U3(q, r)] += wa0 * g.P[r] + wa1 * g.P[3 + r];
+          a[6 + q] -= wa0 * ru + wa1 * rv;       // Jp = -P
+        }
+        j = jn; c = cn; uv = uvn;
+      }
     }
+    if (LPP >= 2) {
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const double wa0 = w0 * g.P[a], wa1 = w1 * g.P[3 + a];
+      for (int q = 0; q < 9; ++q) a[q] += dpp_f64<DPP_ROW_SHR1, 0xf>(a[q]);
+    }
+    if (p < pend && sub == LPP - 1) {
 #pragma unroll
-      for (int bb = a; bb < 3; ++bb) h[U3(a, bb)] += wa0 * g.P[bb] + wa1 * g.P[3 + bb];
-      b[a] -= wa0 * ru + wa1 * rv;       // Jp = -P
+      for (int q = 0; q < 6; ++q) Hpp[6 * (size_t)p + q] = a[q];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) bp[3 * (size_t)p + q] = a[6 + q];
     }
   }
-#pragma unroll
-  for (int k = 0; k < 6; ++k) Hpp[6 * (size_t)p + k] = h[k];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) bp[3 * (size_t)p + k] = b[k];
 }
 
-// K3: damped 3x3 inverse per point and y0 = (Hpp + lam Dp)^-1 bp.
-__global__ void __launch_bounds__(PT_BLOCK)
+// K3: damped 3x3 inverse per point and y0 = (Hpp + lam Dp)^-1 bp (also placed in the y
+// slot of the point table, where the right-hand-side camera pass reads it).
+__global__ void __launch_bounds__(256)
 k_point_invert(const double* __restrict__ Hpp, const double* __restrict__ bp, double lambda, int n_pts,
-               double* __restrict__ Hppinv, double* __restrict__ y0) {
-  const int p = blockIdx.x * PT_BLOCK + threadIdx.x;
+               double* __restrict__ Hppinv, double* __restrict__ y0, double* __restrict__ ptab) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= n_pts) return;
   double h[6], inv[6];
 #pragma unroll
@@ -210,275 +479,168 @@ k_point_invert(const double* __restrict__ Hpp, const double* __restrict__ bp, do
   double y[3];
   sym3_mul(inv, b, y);
   y0[3 * (size_t)p] = y[0]; y0[3 * (size_t)p + 1] = y[1]; y0[3 * (size_t)p + 2] = y[2];
+  double* o = ptab + PT * (size_t)p + 4;
+  o[0] = y[0]; o[1] = y[1]; o[2] = y[2];
 }
 
-// Damped camera blocks Hccd = Hcc + lam * max(diag, floor); fixed camera -> identity.
-__global__ void k_damp_cameras(const double* __restrict__ Hcc, double lambda, int n_cams, int fixed_cam,
-                               double* __restrict__ Hccd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n_cams) return;
-  double h[21];
-  for (int k = 0; k < 21; ++k) h[k] = Hcc[21 * c + k];
-  if (c == fixed_cam) {
-    for (int k = 0; k < 21; ++k) h[k] = 0.0;
-    for (int i = 0; i < 6; ++i) h[U6(i, i)] = 1.0;
-  } else {
-    for (int i = 0; i < 6; ++i) h[U6(i, i)] += lambda * fmax(h[U6(i, i)], DIAG_FLOOR);
-  }
-  for (int k = 0; k < 21; ++k) Hccd[21 * c + k] = h[k];
-}
-
-// PCG convergence test shared by the three kernels of an iteration: every workgroup
-// evaluates it from the same device words, so all of them take the same branch.
-__device__ inline bool pcg_finished(int k, const PcgState* __restrict__ st, const double* __restrict__ partV,
-                                    int nblkV, double tol2, int min_iters, double& gamma, double& zeta) {
-  const PcgState& s = st[k & 1];
-  const double* pv = partV + (size_t)(k & 1) * 2 * nblkV;
-  double g = 0, z = 0;
-  for (int b = 0; b < nblkV; ++b) { g += pv[2 * b]; z += pv[2 * b + 1]; }
-  gamma = g; zeta = z;
-  if (s.done) return true;
-  const double g0 = (k == 0) ? g : s.gamma0;
-  if (!(g > 0.0)) return true;
-  return (k >= min_iters && g <= tol2 * g0);
-}
-
-// K4a / K6: point pass.  One thread per point:
-//   u = sum_o Jp^T w (Jc v_c),  Jc v = P (X x vt_r) - dpi vt_t,  vt = (M v_r, v_t)
-// MODE 0 (PCG):  y[p] = Hppinv u, partA[block] = sum u.y          (early exit when PCG is done)
-// MODE 1 (back substitution): dp = -(y0 + Hppinv u), pts_trial = pts + dp and the
-//         point-side scalars of the gain ratio / stopping tests -> partB[block][4]
-template <bool ROBUST, int MODE>
-__global__ void __launch_bounds__(PT_BLOCK)
-k_schur_pt(const double* __restrict__ cs, const double* __restrict__ pts, const int* __restrict__ pt_off,
-           const int* __restrict__ p_cam, const double2* __restrict__ p_w, const double* __restrict__ vtil,
-           const double* __restrict__ Hppinv, double fx, double fy, int n_pts, int fixed_cam,
-           double* __restrict__ y, double* __restrict__ partA,
-           // MODE 0
-           int k, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2,
+// K4a / K6: point pass of the Schur product.  u = sum_o Jp^T w (Jc v_c) with
+//   Jc v = P (X x vt_r) - dpi vt_t,  vt = (M v_r, v_t) = camA[c][12..17].
+// MODE 0 (PCG): y[p] = Hppinv u into the point table, partA[block] = sum u.y; early exit when done.
+// MODE 1 (back substitution): dp = -(y0 + Hppinv u), trial point = X + dp, partB[block][4] =
+//         bp.dp, sum Dp dp^2, |dp|^2, |X|^2.
+template <bool ROBUST, int MODE, bool LDS_TAB>
+__global__ void __launch_bounds__(PT_THREADS)
+k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,
+           const int* __restrict__ p_cam, const double2* __restrict__ p_w, const double* __restrict__ Hppinv,
+           double fx, double fy, int n_pts, int n_cams, int fixed_cam, int pts_per_block, double* __restrict__ partA,
+           int kit, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2,
            int min_iters,
-           // MODE 1
            const double* __restrict__ y0, const double* __restrict__ Hpp, const double* __restrict__ bp,
-           double* __restrict__ pts_trial, double* __restrict__ partB) {
-  __shared__ double sm[4 * (PT_BLOCK / 64)];
+           double* __restrict__ ptab_trial, double* __restrict__ partB) {
+  extern __shared__ double tab[];
+  __shared__ double sm[4 * (PT_THREADS / 64)];
   if (MODE == 0) {
     double g, z;
-    if (pcg_finished(k, st, partV, nblkV, tol2, min_iters, g, z)) return;
+    if (pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z)) return;
   }
-  const int p = blockIdx.x * PT_BLOCK + threadIdx.x;
+  if (LDS_TAB) fill_cam_table<PT_THREADS>(tab, camA, n_cams);
+  const int sub = threadIdx.x % LPP;
   double acc[4] = {0, 0, 0, 0};
-  if (p < n_pts) {
-    const double X0 = pts[3 * (size_t)p], X1 = pts[3 * (size_t)p + 1], X2 = pts[3 * (size_t)p + 2];
+  const int pend = min(n_pts, (int)(blockIdx.x + 1) * pts_per_block);
+  for (int p0 = blockIdx.x * pts_per_block; p0 < pend; p0 += PT_THREADS / LPP) {
+    const int p = p0 + threadIdx.x / LPP;
     double u[3] = {0, 0, 0};
-    const int beg = pt_off[p], end = pt_off[p + 1];
-    for (int j = beg; j < end; ++j) {
-      const int c = p_cam[j];
-      if (c == fixed_cam) continue;
-      const double* v = vtil + 6 * c;
-      Geom g;
-      obs_geom(cs + CS * c, X0, X1, X2, fx, fy, g);
-      const double q0 = X1 * v[2] - X2 * v[1], q1 = X2 * v[0] - X0 * v[2], q2 = X0 * v[1] - X1 * v[0];
-      double s0 = g.P[0] * q0 + g.P[1] * q1 + g.P[2] * q2 - (g.d00 * v[3] + g.d02 * v[5]);
-      double s1 = g.P[3] * q0 + g.P[4] * q1 + g.P[5] * q2 - (g.d11 * v[4] + g.d12 * v[5]);
-      if (ROBUST) { const double2 w = p_w[j]; s0 *= w.x; s1 *= w.y; }
-      u[0] -= g.P[0] * s0 + g.P[3] * s1;
-      u[1] -= g.P[1] * s0 + g.P[4] * s1;
-      u[2] -= g.P[2] * s0 + g.P[5] * s1;
+    double4 X = make_double4(0, 0, 0, 0);
+    if (p < pend) {
+      X = *(const double4*)(ptab + PT * (size_t)p);
+      const int beg = pt_off[p], end = pt_off[p + 1];
+      int j = beg + sub;
+      int c = (j < end) ? p_cam[j] : 0;
+      double2 w = make_double2(1.0, 1.0);
+      if (ROBUST && j < end) w = p_w[j];
+      while (j < end) {
+        const int jn = j + LPP;
+        const int cn = (jn < end) ? p_cam[jn] : 0;
+        double2 wn = make_double2(1.0, 1.0);
+        if (ROBUST && jn < end) wn = p_w[jn];
+        if (c != fixed_cam) {
+          double row[TA];
+          load_cam_row<LDS_TAB, TA>(tab, camA, c, row);
+          const double* v = row + 12;
+          Geom g;
+          obs_geom(row, X.x, X.y, X.z, fx, fy, g);
+          const double q0 = X.y * v[2] - X.z * v[1], q1 = X.z * v[0] - X.x * v[2], q2 = X.x * v[1] - X.y * v[0];
+          const double s0 = (g.P[0] * q0 + g.P[1] * q1 + g.P[2] * q2 - (g.d00 * v[3] + g.d02 * v[5])) * w.x;
+          const double s1 = (g.P[3] * q0 + g.P[4] * q1 + g.P[5] * q2 - (g.d11 * v[4] + g.d12 * v[5])) * w.y;
+          u[0] -= g.P[0] * s0 + g.P[3] * s1;
+          u[1] -= g.P[1] * s0 + g.P[4] * s1;
+          u[2] -= g.P[2] * s0 + g.P[5] * s1;
+        }
+        j = jn; c = cn; w = wn;
+      }
     }
-    double hi[6], yy[3];
+    if (LPP >= 2) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) hi[q] = Hppinv[6 * (size_t)p + q];
-    sym3_mul(hi, u, yy);
-    if (MODE == 0) {
-      y[3 * (size_t)p] = yy[0]; y[3 * (size_t)p + 1] = yy[1]; y[3 * (size_t)p + 2] = yy[2];
-      acc[0] = u[0] * yy[0] + u[1] * yy[1] + u[2] * yy[2];
-    } else {
-      const double d0 = -(y0[3 * (size_t)p] + yy[0]);
-      const double d1 = -(y0[3 * (size_t)p + 1] + yy[1]);
-      const double d2 = -(y0[3 * (size_t)p + 2] + yy[2]);
-      pts_trial[3 * (size_t)p] = X0 + d0;
-      pts_trial[3 * (size_t)p + 1] = X1 + d1;
-      pts_trial[3 * (size_t)p + 2] = X2 + d2;
-      const double D0 = fmax(Hpp[6 * (size_t)p], DIAG_FLOOR), D1 = fmax(Hpp[6 * (size_t)p + 3], DIAG_FLOOR),
-                   D2 = fmax(Hpp[6 * (size_t)p + 5], DIAG_FLOOR);
-      acc[0] = bp[3 * (size_t)p] * d0 + bp[3 * (size_t)p + 1] * d1 + bp[3 * (size_t)p + 2] * d2;   // g^T d
-      acc[1] = D0 * d0 * d0 + D1 * d1 * d1 + D2 * d2 * d2;                                           // d^T D d
-      acc[2] = d0 * d0 + d1 * d1 + d2 * d2;                                                          // |d|^2
-      acc[3] = X0 * X0 + X1 * X1 + X2 * X2;                                                          // |x|^2
+      for (int q = 0; q < 3; ++q) u[q] += dpp_f64<DPP_ROW_SHR1, 0xf>(u[q]);
+    }
+    if (p < pend && sub == LPP - 1) {
+      double hi[6], yy[3];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) hi[q] = Hppinv[6 * (size_t)p + q];
+      sym3_mul(hi, u, yy);
+      if (MODE == 0) {
+        double* o = ptab + PT * (size_t)p + 4;
+        o[0] = yy[0]; o[1] = yy[1]; o[2] = yy[2];
+        acc[0] += u[0] * yy[0] + u[1] * yy[1] + u[2] * yy[2];
+      } else {
+        const double d0 = -(y0[3 * (size_t)p] + yy[0]);
+        const double d1 = -(y0[3 * (size_t)p + 1] + yy[1]);
+        const double d2 = -(y0[3 * (size_t)p + 2] + yy[2]);
+        double* o = ptab_trial + PT * (size_t)p;
+        o[0] = X.x + d0; o[1] = X.y + d1; o[2] = X.z + d2;
+        const double D0 = fmax(Hpp[6 * (size_t)p], DIAG_FLOOR), D1 = fmax(Hpp[6 * (size_t)p + 3], DIAG_FLOOR),
+                     D2 = fmax(Hpp[6 * (size_t)p + 5], DIAG_FLOOR);
+        acc[0] += bp[3 * (size_t)p] * d0 + bp[3 * (size_t)p + 1] * d1 + bp[3 * (size_t)p + 2] * d2;
+        acc[1] += D0 * d0 * d0 + D1 * d1 * d1 + D2 * d2 * d2;
+        acc[2] += d0 * d0 + d1 * d1 + d2 * d2;
+        acc[3] += X.x * X.x + X.y * X.y + X.z * X.z;
+      }
     }
   }
-  block_sum<4>(acc, sm);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = wave_total_dpp(acc[q]);
+  block_combine<4, PT_THREADS>(acc, sm);
   if (threadIdx.x == 0) {
     if (MODE == 0) partA[blockIdx.x] = acc[0];
     else { for (int q = 0; q < 4; ++q) partB[4 * blockIdx.x + q] = acc[q]; }
   }
 }
 
-// K4b: camera pass.  One workgroup per camera:  Wy[c] = sum_o Jc^T w (Jp y_p),  Jp y = -P y,
-//   Jc^T s = [ M^T ((P^T s) x X) ; -dpi^T s ].
-// The extra workgroup blockIdx.x == n_cams folds partA into comm[6 n_cams] (the u.y sum)
-// so that one all-reduce of `comm` carries everything PCG needs from the shards.
-// MODE 0 = PCG iteration (early exit when done), MODE 1 = right-hand side (y = y0).
-template <bool ROBUST, int MODE>
-__global__ void __launch_bounds__(CAM_BLOCK)
-k_schur_cam(const double* __restrict__ cs, const double* __restrict__ pts, const int* __restrict__ cam_off,
-            const int* __restrict__ c_pt, const double2* __restrict__ c_w, const double* __restrict__ y,
-            double fx, double fy, int n_cams, int fixed_cam, double* __restrict__ comm,
-            const double* __restrict__ partA, int nblkA,
-            int k, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2,
-            int min_iters) {
-  __shared__ double sm[6 * (CAM_BLOCK / 64)];
-  if (MODE == 0) {
-    double g, z;
-    if (pcg_finished(k, st, partV, nblkV, tol2, min_iters, g, z)) return;
-  }
-  const int c = blockIdx.x;
-  if (c == n_cams) {                       // fold the point-pass partial sums
-    double a[1] = {0.0};
-    if (MODE == 0) for (int b = threadIdx.x; b < nblkA; b += CAM_BLOCK) a[0] += partA[b];
-    block_sum<1>(a, sm);
-    if (threadIdx.x == 0) comm[6 * n_cams] = a[0];
-    return;
-  }
-  const double* cam = cs + CS * c;
-  const int beg = cam_off[c], end = cam_off[c + 1];
-  double acc[6] = {0, 0, 0, 0, 0, 0};
-  if (c != fixed_cam) {
-    for (int i = beg + threadIdx.x; i < end; i += CAM_BLOCK) {
-      const int p = c_pt[i];
-      const double X0 = pts[3 * (size_t)p], X1 = pts[3 * (size_t)p + 1], X2 = pts[3 * (size_t)p + 2];
-      const double y0 = y[3 * (size_t)p], y1 = y[3 * (size_t)p + 1], y2 = y[3 * (size_t)p + 2];
-      Geom g;
-      obs_geom(cam, X0, X1, X2, fx, fy, g);
-      double s0 = -(g.P[0] * y0 + g.P[1] * y1 + g.P[2] * y2);
-      double s1 = -(g.P[3] * y0 + g.P[4] * y1 + g.P[5] * y2);
-      if (ROBUST) { const double2 w = c_w[i]; s0 *= w.x; s1 *= w.y; }
-      const double e0 = g.P[0] * s0 + g.P[3] * s1, e1 = g.P[1] * s0 + g.P[4] * s1, e2 = g.P[2] * s0 + g.P[5] * s1;
-      acc[0] += e1 * X2 - e2 * X1;
-      acc[1] += e2 * X0 - e0 * X2;
-      acc[2] += e0 * X1 - e1 * X0;
-      acc[3] -= g.d00 * s0;
-      acc[4] -= g.d11 * s1;
-      acc[5] -= g.d02 * s0 + g.d12 * s1;
-    }
-  }
-  block_sum<6>(acc, sm);
-  if (threadIdx.x == 0) {
-    const double* M = cam + 12;
-    double* o = comm + 6 * c;
-    o[0] = M[0] * acc[0] + M[3] * acc[1] + M[6] * acc[2];
-    o[1] = M[1] * acc[0] + M[4] * acc[1] + M[7] * acc[2];
-    o[2] = M[2] * acc[0] + M[5] * acc[1] + M[8] * acc[2];
-    o[3] = acc[3]; o[4] = acc[4]; o[5] = acc[5];
-  }
+// -------------------------------------------------------------------------------------
+// reduced-camera-system vector kernels (one thread per camera)
+// -------------------------------------------------------------------------------------
+__device__ inline void write_vtil(const double* __restrict__ M, const double (&v)[6], double* __restrict__ dst) {
+  dst[0] = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+  dst[1] = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+  dst[2] = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+  dst[3] = v[3]; dst[4] = v[4]; dst[5] = v[5];
 }
 
-// Schur-Jacobi preconditioner blocks: E[c] (21) = sum_o W_o Hppinv_p W_o^T, W_o = Jc^T w Jp.
-// One workgroup per camera; written to `out` (all-reduced across shards by the host
-// side, then subtracted from Hccd and inverted in k_precond_invert).
-template <bool ROBUST>
-__global__ void __launch_bounds__(CAM_BLOCK)
-k_schur_diag(const double* __restrict__ cs, const double* __restrict__ pts, const int* __restrict__ cam_off,
-             const int* __restrict__ c_pt, const double2* __restrict__ c_w, const double* __restrict__ Hppinv,
-             double fx, double fy, int fixed_cam, double* __restrict__ out) {
-  __shared__ double sm[21 * (CAM_BLOCK / 64)];
-  const int c = blockIdx.x;
-  const double* cam = cs + CS * c;
-  const int beg = cam_off[c], end = cam_off[c + 1];
-  double acc[21];
-#pragma unroll
-  for (int q = 0; q < 21; ++q) acc[q] = 0.0;
-  if (c != fixed_cam) {
-    for (int i = beg + threadIdx.x; i < end; i += CAM_BLOCK) {
-      const int p = c_pt[i];
-      const double X0 = pts[3 * (size_t)p], X1 = pts[3 * (size_t)p + 1], X2 = pts[3 * (size_t)p + 2];
-      Geom g;
-      obs_geom(cam, X0, X1, X2, fx, fy, g);
-      double w0 = 1.0, w1 = 1.0;
-      if (ROBUST) { const double2 w = c_w[i]; w0 = w.x; w1 = w.y; }
-      double hi[6];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) hi[q] = Hppinv[6 * (size_t)p + q];
-      // G (2x2) = w Jp Hppinv Jp^T w = (w P) Hppinv (w P)^T
-      double t0[3], t1[3];
-      sym3_mul(hi, g.P, t0);
-      sym3_mul(hi, g.P + 3, t1);
-      const double G00 = w0 * w0 * (g.P[0] * t0[0] + g.P[1] * t0[1] + g.P[2] * t0[2]);
-      const double G01 = w0 * w1 * (g.P[0] * t1[0] + g.P[1] * t1[1] + g.P[2] * t1[2]);
-      const double G11 = w1 * w1 * (g.P[3] * t1[0] + g.P[4] * t1[1] + g.P[5] * t1[2]);
-      double J0[6], J1[6];   // pre-M camera Jacobian rows
-      J0[0] = g.P[1] * X2 - g.P[2] * X1; J0[1] = g.P[2] * X0 - g.P[0] * X2; J0[2] = g.P[0] * X1 - g.P[1] * X0;
-      J1[0] = g.P[4] * X2 - g.P[5] * X1; J1[1] = g.P[5] * X0 - g.P[3] * X2; J1[2] = g.P[3] * X1 - g.P[4] * X0;
-      J0[3] = -g.d00; J0[4] = 0.0;    J0[5] = -g.d02;
-      J1[3] = 0.0;    J1[4] = -g.d11; J1[5] = -g.d12;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        const double l0 = J0[a] * G00 + J1[a] * G01, l1 = J0[a] * G01 + J1[a] * G11;
-#pragma unroll
-        for (int b = a; b < 6; ++b) acc[U6(a, b)] += l0 * J0[b] + l1 * J1[b];
-      }
-    }
-  }
-  block_sum<21>(acc, sm);
-  if (threadIdx.x == 0) {
-    const double* M = cam + 12;
-    double A[6][6], B[6][6];
-    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) A[i][j] = acc[S6(i, j)];
-    for (int i = 0; i < 6; ++i) {
-      for (int j = 0; j < 3; ++j) B[i][j] = A[i][0] * M[j] + A[i][1] * M[3 + j] + A[i][2] * M[6 + j];
-      for (int j = 3; j < 6; ++j) B[i][j] = A[i][j];
-    }
-    for (int j = 0; j < 6; ++j) {
-      double h0 = M[0] * B[0][j] + M[3] * B[1][j] + M[6] * B[2][j];
-      double h1 = M[1] * B[0][j] + M[4] * B[1][j] + M[7] * B[2][j];
-      double h2 = M[2] * B[0][j] + M[5] * B[1][j] + M[8] * B[2][j];
-      A[0][j] = h0; A[1][j] = h1; A[2][j] = h2;
-      A[3][j] = B[3][j]; A[4][j] = B[4][j]; A[5][j] = B[5][j];
-    }
-    for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) out[21 * c + U6(i, j)] = A[i][j];
-  }
-}
-
-// Minv[c] = (Hccd[c] - E[c])^-1 (E may be null: plain block-Jacobi).
-__global__ void k_precond_invert(const double* __restrict__ Hccd, const double* __restrict__ E, int n_cams,
-                                 double* __restrict__ Minv) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n_cams) return;
-  double h[21], inv[21];
-  for (int q = 0; q < 21; ++q) h[q] = Hccd[21 * c + q] - (E ? E[21 * c + q] : 0.0);
-  spd6_inverse(h, inv);
-  for (int q = 0; q < 21; ++q) Minv[21 * c + q] = inv[q];
-}
-
-// PCG start: g = -(bc - Wy0) (fixed camera: 0), x = 0, r = g, z = Minv r, p = s = 0,
-// vtil = (M z_r, z_t), first partial sums gamma = r.z, zeta = z.Hccd z, state reset.
+// PCG setup at damping lambda: Hccd = Hcc + lam Dc (fixed camera: identity), Schur-Jacobi
+// or Jacobi preconditioner Minv = (Hccd - E)^-1, right-hand side g = -(bc - W y0), and the
+// first PCG vectors: x = 0, r = g, z = Minv r, p = s = 0, vtil, gamma/zeta partials.
+// E / Wy0 come either as NPART partial sums (nparts = NPART) or already folded and
+// all-reduced (nparts = 1).
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_pcg_init(const double* __restrict__ bc, const double* __restrict__ comm, const double* __restrict__ Hccd,
-           const double* __restrict__ Minv, const double* __restrict__ cs, int n_cams, int fixed_cam,
-           double* __restrict__ gvec, double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
-           double* __restrict__ s, double* __restrict__ z, double* __restrict__ vtil,
-           double* __restrict__ partV, PcgState* __restrict__ st) {
+k_pcg_setup(const double* __restrict__ Hcc, const double* __restrict__ bc, const double* __restrict__ part6,
+            const double* __restrict__ partE, int nparts, const double* __restrict__ cs, double lambda,
+            int use_schur_diag, int n_cams, int fixed_cam, double* __restrict__ Hccd, double* __restrict__ Minv,
+            double* __restrict__ gvec, double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
+            double* __restrict__ s, double* __restrict__ z, double* __restrict__ camA,
+            double* __restrict__ partV, PcgState* __restrict__ st) {
   __shared__ double sm[2];
   const int c = blockIdx.x * VEC_BLOCK + threadIdx.x;
   double acc[2] = {0, 0};
   if (c < n_cams) {
-    double g[6], zz[6], hz[6];
-    for (int q = 0; q < 6; ++q) g[q] = (c == fixed_cam) ? 0.0 : -(bc[6 * c + q] - comm[6 * c + q]);
-    sym6_mul(Minv + 21 * c, g, zz);
-    sym6_mul(Hccd + 21 * c, zz, hz);
     const double* M = cs + CS * c + 12;
+    double h[21], m[21], inv[21];
+    for (int q = 0; q < 21; ++q) h[q] = Hcc[21 * c + q];
+    if (c == fixed_cam) {
+      for (int q = 0; q < 21; ++q) h[q] = 0.0;
+      for (int i = 0; i < 6; ++i) h[U6(i, i)] = 1.0;
+    } else {
+      for (int i = 0; i < 6; ++i) h[U6(i, i)] += lambda * fmax(h[U6(i, i)], DIAG_FLOOR);
+    }
+    for (int q = 0; q < 21; ++q) { Hccd[21 * c + q] = h[q]; m[q] = h[q]; }
+    if (use_schur_diag && c != fixed_cam) {
+      double e[21];
+      for (int q = 0; q < 21; ++q) e[q] = 0.0;
+      for (int k = 0; k < nparts; ++k) {
+        const double* src = partE + ((size_t)k * n_cams + c) * 21;
+        for (int q = 0; q < 21; ++q) e[q] += src[q];
+      }
+      double A[6][6];
+      for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) A[i][j] = e[S6(i, j)];
+      m_congruence(M, A);
+      for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) m[U6(i, j)] -= A[i][j];
+    }
+    spd6_inverse(m, inv);
+    for (int q = 0; q < 21; ++q) Minv[21 * c + q] = inv[q];
+    double wy[6], g[6], zz[6], hz[6];
+    combine_wy(part6, nparts, n_cams, c, M, wy);
+    for (int q = 0; q < 6; ++q) g[q] = (c == fixed_cam) ? 0.0 : -(bc[6 * c + q] - wy[q]);
+    sym6_mul(inv, g, zz);
+    sym6_mul(h, zz, hz);
     for (int q = 0; q < 6; ++q) {
       gvec[6 * c + q] = g[q]; r[6 * c + q] = g[q]; x[6 * c + q] = 0.0; p[6 * c + q] = 0.0; s[6 * c + q] = 0.0;
       z[6 * c + q] = zz[q];
       acc[0] += g[q] * zz[q];
       acc[1] += zz[q] * hz[q];
     }
-    vtil[6 * c + 0] = M[0] * zz[0] + M[1] * zz[1] + M[2] * zz[2];
-    vtil[6 * c + 1] = M[3] * zz[0] + M[4] * zz[1] + M[5] * zz[2];
-    vtil[6 * c + 2] = M[6] * zz[0] + M[7] * zz[1] + M[8] * zz[2];
-    vtil[6 * c + 3] = zz[3]; vtil[6 * c + 4] = zz[4]; vtil[6 * c + 5] = zz[5];
+    write_vtil(M, zz, camA + TA * c + 12);
   }
-  block_sum<2>(acc, sm);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) acc[q] = wave_total_dpp(acc[q]);
   if (threadIdx.x == 0) {
     partV[2 * blockIdx.x] = acc[0];
     partV[2 * blockIdx.x + 1] = acc[1];
@@ -488,22 +650,24 @@ k_pcg_init(const double* __restrict__ bc, const double* __restrict__ comm, const
       st[1] = s0;
     }
   }
+  (void)sm;
 }
 
-// K5: one PCG iteration's vector work (Chronopoulos-Gear single-reduction CG), one
-// thread per camera.  With z the preconditioned residual and w = S z:
-//   gamma = r.z (partials from the previous step), delta = z.Hccd z - u.y,
+// K5: one PCG iteration's vector work (Chronopoulos-Gear single-reduction CG).  With z the
+// preconditioned residual and w = S z:
+//   gamma = r.z (partials of the previous step), delta = z.Hccd z - u.y,
 //   beta = gamma/gamma_prev, alpha = gamma / (delta - beta gamma / alpha_prev),
 //   p = z + beta p, s = w + beta s, x += alpha p, r -= alpha s, z = Minv r.
-// Every workgroup recomputes the scalars from the same words; workgroup 0 publishes
-// the next state into the other parity slot.
+// Every workgroup recomputes the scalars from the same words; workgroup 0 publishes the
+// next state into the other parity slot.  uy_src: partA (npartA block partials) or, multi
+// rank, one all-reduced word.
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_pcg_step(int k, const double* __restrict__ comm, const double* __restrict__ Hccd, const double* __restrict__ Minv,
-           const double* __restrict__ cs, int n_cams, int fixed_cam, double tol2, int min_iters,
+k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __restrict__ uy_src, int npartA,
+           const double* __restrict__ Hccd, const double* __restrict__ Minv, const double* __restrict__ cs,
+           int n_cams, int fixed_cam, double tol2, int min_iters,
            double* __restrict__ x, double* __restrict__ r, double* __restrict__ p, double* __restrict__ s,
-           double* __restrict__ z, double* __restrict__ vtil, double* __restrict__ partV, int nblkV,
+           double* __restrict__ z, double* __restrict__ camA, double* __restrict__ partV, int nblkV,
            PcgState* __restrict__ st) {
-  __shared__ double sm[2];
   double gamma, zeta;
   const bool fin = pcg_finished(k, st, partV, nblkV, tol2, min_iters, gamma, zeta);
   const PcgState sin = st[k & 1];
@@ -516,7 +680,8 @@ k_pcg_step(int k, const double* __restrict__ comm, const double* __restrict__ Hc
     }
     return;
   }
-  const double uy = comm[6 * n_cams];
+  double uy = 0.0;
+  for (int b = 0; b < npartA; ++b) uy += uy_src[b];
   const double delta = zeta - uy;
   const double beta = (k == 0) ? 0.0 : gamma / sin.gamma_prev;
   const double denom = (k == 0) ? delta : delta - beta * gamma / sin.alpha_prev;
@@ -532,11 +697,14 @@ k_pcg_step(int k, const double* __restrict__ comm, const double* __restrict__ Hc
   const int c = blockIdx.x * VEC_BLOCK + threadIdx.x;
   double acc[2] = {0, 0};
   if (c < n_cams && c != fixed_cam) {
-    double zz[6], w[6], pp[6], ss[6], rr[6], hz[6];
+    const double* M = cs + CS * c + 12;
+    double zz[6], w[6], wy[6], pp[6], ss[6], rr[6], hz[6], h[21];
+    for (int q = 0; q < 21; ++q) h[q] = Hccd[21 * c + q];
     for (int q = 0; q < 6; ++q) zz[q] = z[6 * c + q];
-    sym6_mul(Hccd + 21 * c, zz, w);
+    sym6_mul(h, zz, w);
+    combine_wy(part6, nparts, n_cams, c, M, wy);
     for (int q = 0; q < 6; ++q) {
-      w[q] -= comm[6 * c + q];
+      w[q] -= wy[q];
       pp[q] = zz[q] + beta * p[6 * c + q];
       ss[q] = w[q] + beta * s[6 * c + q];
       x[6 * c + q] += alpha * pp[q];
@@ -544,19 +712,16 @@ k_pcg_step(int k, const double* __restrict__ comm, const double* __restrict__ Hc
       p[6 * c + q] = pp[q]; s[6 * c + q] = ss[q]; r[6 * c + q] = rr[q];
     }
     sym6_mul(Minv + 21 * c, rr, zz);
-    sym6_mul(Hccd + 21 * c, zz, hz);
-    const double* M = cs + CS * c + 12;
+    sym6_mul(h, zz, hz);
     for (int q = 0; q < 6; ++q) {
       z[6 * c + q] = zz[q];
       acc[0] += rr[q] * zz[q];
       acc[1] += zz[q] * hz[q];
     }
-    vtil[6 * c + 0] = M[0] * zz[0] + M[1] * zz[1] + M[2] * zz[2];
-    vtil[6 * c + 1] = M[3] * zz[0] + M[4] * zz[1] + M[5] * zz[2];
-    vtil[6 * c + 2] = M[6] * zz[0] + M[7] * zz[1] + M[8] * zz[2];
-    vtil[6 * c + 3] = zz[3]; vtil[6 * c + 4] = zz[4]; vtil[6 * c + 5] = zz[5];
+    write_vtil(M, zz, camA + TA * c + 12);
   }
-  block_sum<2>(acc, sm);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) acc[q] = wave_total_dpp(acc[q]);
   if (threadIdx.x == 0) {
     double* pv = partV + (size_t)((k + 1) & 1) * 2 * nblkV;
     pv[2 * blockIdx.x] = acc[0];
@@ -571,15 +736,14 @@ k_pcg_step(int k, const double* __restrict__ comm, const double* __restrict__ Hc
   }
 }
 
-// K7a: camera update.  cams_trial = cams + dc, vtil = (M dc_r, dc_t) for the back
-// substitution, and the camera-side scalars -> partC[block][5]:
-//   bc.dc, sum Dc dc^2, dc.r_pcg, |dc|^2, |cams|^2
+// K7a: camera update.  cams_trial = cams + dc, camera state of the trial cameras, vtil =
+// (M dc_r, dc_t) into camA for the back substitution, camera-side scalars ->
+// partC[block][5]: bc.dc, sum Dc dc^2, dc.r_pcg, |dc|^2, |cams|^2
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_cam_update(const double* __restrict__ cams, const double* __restrict__ dc, const double* __restrict__ rpcg,
              const double* __restrict__ Hcc, const double* __restrict__ bc, const double* __restrict__ cs,
-             int n_cams, int fixed_cam, double* __restrict__ cams_trial, double* __restrict__ vtil,
-             double* __restrict__ partC) {
-  __shared__ double sm[5];
+             int n_cams, int fixed_cam, double* __restrict__ cams_trial, double* __restrict__ cs_trial,
+             double* __restrict__ camA, double* __restrict__ partC) {
   const int c = blockIdx.x * VEC_BLOCK + threadIdx.x;
   double acc[5] = {0, 0, 0, 0, 0};
   if (c < n_cams) {
@@ -594,26 +758,33 @@ k_cam_update(const double* __restrict__ cams, const double* __restrict__ dc, con
       acc[3] += d[q] * d[q];
       acc[4] += xq * xq;
     }
-    const double* M = cs + CS * c + 12;
-    vtil[6 * c + 0] = M[0] * d[0] + M[1] * d[1] + M[2] * d[2];
-    vtil[6 * c + 1] = M[3] * d[0] + M[4] * d[1] + M[5] * d[2];
-    vtil[6 * c + 2] = M[6] * d[0] + M[7] * d[1] + M[8] * d[2];
-    vtil[6 * c + 3] = d[3]; vtil[6 * c + 4] = d[4]; vtil[6 * c + 5] = d[5];
+    write_vtil(cs + CS * c + 12, d, camA + TA * c + 12);
+    camera_state(cams_trial + 6 * c, cs_trial + CS * c);
   }
-  block_sum<5>(acc, sm);
+#pragma unroll
+  for (int q = 0; q < 5; ++q) acc[q] = wave_total_dpp(acc[q]);
   if (threadIdx.x == 0) for (int q = 0; q < 5; ++q) partC[5 * blockIdx.x + q] = acc[q];
 }
 
-// out[j] = sum_i part[i * ncols + j]   (single workgroup, fixed order)
+// One workgroup folds every partial-sum array of an LM step into the scalar block `scal`
+// (fixed order): residual partials (nR rows x 2), point partials (nB x 4, may be 0 rows),
+// camera partials (nC x 5, may be 0 rows).
+__device__ inline double block_fold(const double* __restrict__ part, int nrows, int ncols, int col, double* sm) {
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nrows; i += 256) a += part[(size_t)i * ncols + col];
+  a = wave_total_dpp(a);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
 __global__ void __launch_bounds__(256)
-k_reduce_cols(const double* __restrict__ part, int nrows, int ncols, double* __restrict__ out) {
+k_scalars(const double* __restrict__ partR, int nR, const double* __restrict__ partB, int nB,
+          const double* __restrict__ partC, int nC, double* __restrict__ scal) {
   __shared__ double sm[4];
-  for (int j = 0; j < ncols; ++j) {
-    double a[1] = {0.0};
-    for (int i = threadIdx.x; i < nrows; i += 256) a[0] += part[(size_t)i * ncols + j];
-    block_sum<1>(a, sm);
-    if (threadIdx.x == 0) out[j] = a[0];
-  }
+  for (int q = 0; q < 2; ++q) { const double v = block_fold(partR, nR, 2, q, sm); if (threadIdx.x == 0) scal[S_SSE + q] = v; }
+  for (int q = 0; q < 4; ++q) { const double v = nB ? block_fold(partB, nB, 4, q, sm) : 0.0; if (threadIdx.x == 0) scal[S_PT_GD + q] = v; }
+  for (int q = 0; q < 5; ++q) { const double v = nC ? block_fold(partC, nC, 5, q, sm) : 0.0; if (threadIdx.x == 0) scal[S_CAM_GD + q] = v; }
 }
 
 // out[0] = max |v[i]|  (single workgroup)
@@ -637,29 +808,27 @@ __global__ void k_pcg_reset(PcgState* __restrict__ st, double* __restrict__ part
   }
 }
 
-// out = (Hcc + lam Dc) v - Wy   (test hook behind ba_schur_apply; fixed row = identity)
+// out = Hccd v - Wy   (test hook behind ba_schur_apply; fixed row = identity)
 __global__ void k_schur_combine(const double* __restrict__ Hccd, const double* __restrict__ v,
-                                const double* __restrict__ comm, int n_cams, int fixed_cam, double* __restrict__ out) {
+                                const double* __restrict__ part6, int nparts, const double* __restrict__ cs,
+                                int n_cams, int fixed_cam, double* __restrict__ out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cams) return;
-  double vv[6], w[6];
+  double vv[6], w[6], wy[6];
   for (int q = 0; q < 6; ++q) vv[q] = v[6 * c + q];
   sym6_mul(Hccd + 21 * c, vv, w);
-  for (int q = 0; q < 6; ++q) out[6 * c + q] = (c == fixed_cam) ? vv[q] : w[q] - comm[6 * c + q];
+  combine_wy(part6, nparts, n_cams, c, cs + CS * c + 12, wy);
+  for (int q = 0; q < 6; ++q) out[6 * c + q] = (c == fixed_cam) ? vv[q] : w[q] - wy[q];
 }
 
-// vtil = (M v_r, v_t) for an arbitrary camera vector (test hook / back substitution)
+// vtil half of camA for an arbitrary camera vector (test hook)
 __global__ void k_vtil(const double* __restrict__ v, const double* __restrict__ cs, int n_cams, int fixed_cam,
-                       double* __restrict__ vtil) {
+                       double* __restrict__ camA) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cams) return;
-  const double* M = cs + CS * c + 12;
   double d[6];
   for (int q = 0; q < 6; ++q) d[q] = (c == fixed_cam) ? 0.0 : v[6 * c + q];
-  vtil[6 * c + 0] = M[0] * d[0] + M[1] * d[1] + M[2] * d[2];
-  vtil[6 * c + 1] = M[3] * d[0] + M[4] * d[1] + M[5] * d[2];
-  vtil[6 * c + 2] = M[6] * d[0] + M[7] * d[1] + M[8] * d[2];
-  vtil[6 * c + 3] = d[3]; vtil[6 * c + 4] = d[4]; vtil[6 * c + 5] = d[5];
+  write_vtil(cs + CS * c + 12, d, camA + TA * c + 12);
 }
 
 }  // namespace ba
