@@ -123,6 +123,7 @@ struct ba_handle {
   DBuf<double> gvec, x, r, p, s, z, vin, comm, commE, scal, rbuf;
   DBuf<PcgState> st;
   int nblkP = 1, ppb = 1, nblkV = 1;
+  int pcg_pred = 6;            // PCG iterations to launch before the first look at the device state
   bool lds_tab = true;
   size_t lds_bytes = 0;
   // pinned host mirror for scalars
@@ -454,7 +455,7 @@ static void launch_residual(ba_handle* h, int which, bool robust, double fscale,
 // fold the partial arrays of a step into `scal` (residual always; point / camera parts optional)
 static void launch_scalars(ba_handle* h, bool with_step) {
   Scope sc(h, BA_K_MISC);
-  hipLaunchKernelGGL(k_scalars, dim3(1), dim3(256), 0, h->stream, h->partR.p, NPART * h->Nc, h->partB.p,
+  hipLaunchKernelGGL(k_scalars, dim3(1), dim3(1024), 0, h->stream, h->partR.p, NPART * h->Nc, h->partB.p,
                      (with_step && h->Np > 0) ? h->nblkP : 0, h->partC.p, with_step ? h->nblkV : 0, h->scal.p);
 }
 static void launch_linearize(ba_handle* h, bool robust, double fscale) {
@@ -497,8 +498,9 @@ static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int
   Scope sc(h, diag ? BA_K_PRECOND : BA_K_SCHUR_CAM);
   const int w = h->cur;
 #define CS_ARGS h->cs[w].p, h->ptab[w].p, h->offk.p, h->c_pt.p, h->c_w.p, h->Hppinv.p, h->K4[0], h->K4[1], h->Nc, h->fixed, \
-                h->part6.p, h->partE.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters
-  const dim3 g(cam_grid(h)), b(64 * WPB);
+                h->part6.p, h->partE.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->partA.p,              \
+                (h->Np > 0 ? h->nblkP : 0), h->comm.p + 6 * (size_t)h->Nc
+  const dim3 g(cam_grid(h) + (pcg ? 1 : 0)), b(64 * WPB);
   if (diag) {
     if (robust) hipLaunchKernelGGL((k_cam_schur<true, true, false>), g, b, 0, h->stream, CS_ARGS);
     else        hipLaunchKernelGGL((k_cam_schur<false, true, false>), g, b, 0, h->stream, CS_ARGS);
@@ -659,7 +661,7 @@ extern "C" int ba_default_options(ba_options* o) {
   o->pcg_min_iters = 1;
   o->preconditioner = BA_PRECOND_SCHUR_JACOBI;
   o->jacobian_precision = 0;
-  o->pcg_check_every = 4;
+  o->pcg_check_every = 2;
   o->profile = 0;
   o->verbose = 0;
   return BA_OK;
@@ -739,43 +741,56 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     if (int rc = damped_system(h, lambda, schur_diag)) return rc;
     double t1 = now_s();
     sum->seconds_linearize += t1 - t0;
-    // ---- PCG
+    // ---- PCG: launch the predicted number of iterations, then speculatively the step /
+    // trial-point kernels, and look at the device state once (one host sync per LM
+    // iteration in the common case); if PCG had not converged, resume it and redo the tail.
     int k = 0, pcg_done_iters = -1;
-    while (k < opts->pcg_max_iters) {
-      const int kend = std::min(opts->pcg_max_iters, k + check_every);
+    auto launch_pcg = [&](int n) -> int {
+      const int kend = std::min(opts->pcg_max_iters, k + n);
       for (; k < kend; ++k) {
         launch_pt_schur(h, robust, 0, k, tol2, opts->pcg_min_iters);
         launch_cam_schur(h, robust, false, true, k, tol2, opts->pcg_min_iters);
         if (int rc = exchange_schur(h, false, true)) return rc;
         Scope sc(h, BA_K_PCG_UPDATE);
         hipLaunchKernelGGL(k_pcg_step, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, k, wy_src(h), wy_parts(h),
-                           h->world == 1 ? (const double*)h->partA.p : (const double*)(h->comm.p + 6 * (size_t)Nc),
-                           h->world == 1 ? (h->Np > 0 ? h->nblkP : 0) : 1, h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc,
+                           (const double*)(h->comm.p + 6 * (size_t)Nc), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc,
                            h->fixed, tol2, opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA.p,
                            h->partV.p, h->nblkV, h->st.p);
       }
+      return BA_OK;
+    };
+    if (int rc = launch_pcg(std::max(1, std::min(h->pcg_pred, opts->pcg_max_iters)))) return rc;
+    double t2 = t1;
+    while (true) {
+      // ---- step, trial point, gain-ratio scalars
+      {
+        Scope sc(h, BA_K_MISC);
+        hipLaunchKernelGGL(k_cam_update, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->cams[h->cur].p, h->x.p, h->r.p,
+                           h->HccBc.p, bc_ptr(h), h->cs[h->cur].p, Nc, h->fixed, h->cams[1 - h->cur].p, h->cs[1 - h->cur].p,
+                           h->camA.p, h->partC.p);
+      }
+      launch_pt_schur(h, robust, 1, 0, 0.0, 0);
+      launch_residual(h, 1 - h->cur, robust, fs, nullptr);
+      launch_scalars(h, true);
+      if (int rc = allreduce(h, h->scal.p, 6)) return rc;
+      HIPCHECK(hipMemcpyAsync(h->h_scal, h->scal.p, 16 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIPCHECK(hipMemcpyAsync(h->h_st, h->st.p, 2 * sizeof(PcgState), hipMemcpyDeviceToHost, h->stream));
       HIPCHECK(hipStreamSynchronize(h->stream));
-      const PcgState& s = h->h_st[k & 1];
-      if (s.done) { pcg_done_iters = s.iters; break; }
+      const PcgState& ps = h->h_st[k & 1];
+      if (ps.done) { pcg_done_iters = ps.iters; break; }
+      if (k >= opts->pcg_max_iters) { pcg_done_iters = k; break; }
+      // not converged yet: camA's vtil half was overwritten by the step -> restore it from z, resume
+      {
+        Scope sc(h, BA_K_MISC);
+        hipLaunchKernelGGL(k_vtil, dim3((Nc + 63) / 64), dim3(64), 0, h->stream, h->z.p, h->cs[h->cur].p, Nc, h->fixed,
+                           h->camA.p);
+      }
+      if (int rc = launch_pcg(check_every)) return rc;
     }
-    if (pcg_done_iters < 0) pcg_done_iters = k;
+    h->pcg_pred = pcg_done_iters + 1;
     sum->pcg_iterations += pcg_done_iters;
-    double t2 = now_s();
+    t2 = now_s();
     sum->seconds_pcg += t2 - t1;
-    // ---- step, trial point, gain ratio
-    {
-      Scope sc(h, BA_K_MISC);
-      hipLaunchKernelGGL(k_cam_update, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->cams[h->cur].p, h->x.p, h->r.p,
-                         h->HccBc.p, bc_ptr(h), h->cs[h->cur].p, Nc, h->fixed, h->cams[1 - h->cur].p, h->cs[1 - h->cur].p,
-                         h->camA.p, h->partC.p);
-    }
-    launch_pt_schur(h, robust, 1, 0, 0.0, 0);
-    launch_residual(h, 1 - h->cur, robust, fs, nullptr);
-    launch_scalars(h, true);
-    if (int rc = allreduce(h, h->scal.p, 6)) return rc;
-    HIPCHECK(hipMemcpyAsync(h->h_scal, h->scal.p, 16 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(hipStreamSynchronize(h->stream));
     const double* S = h->h_scal;
     const double sse_new = S[S_SSE], cost_new = 0.5 * S[S_RHO];
     const double gTd = S[S_PT_GD] + S[S_CAM_GD], dDd = S[S_PT_DDD] + S[S_CAM_DDD], dcr = S[S_DC_R];

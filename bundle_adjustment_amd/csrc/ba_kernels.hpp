@@ -253,10 +253,20 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
             const int* __restrict__ c_pt, const double2* __restrict__ c_w, const double* __restrict__ Hppinv,
             double fx, double fy, int n_cams, int fixed_cam, double* __restrict__ part6, double* __restrict__ partE,
             int kit, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2,
-            int min_iters) {
+            int min_iters, const double* __restrict__ partA, int nblkA, double* __restrict__ uy) {
   if (PCG) {
     double g, z;
     if (pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z)) return;
+    if (blockIdx.x == gridDim.x - 1) {      // extra workgroup: u.y = sum of the point pass's block partials
+      __shared__ double smu[WPB];
+      double a = 0.0;
+      for (int b = threadIdx.x; b < nblkA; b += 64 * WPB) a += partA[b];
+      a = wave_total_dpp(a);
+      if ((threadIdx.x & 63) == 0) smu[threadIdx.x >> 6] = a;
+      __syncthreads();
+      if (threadIdx.x == 0) { double t = 0; for (int w = 0; w < WPB; ++w) t += smu[w]; uy[0] = t; }
+      return;
+    }
   }
   Seg s;
   if (!cam_segment(offk, n_cams, s)) return;
@@ -659,10 +669,10 @@ k_pcg_setup(const double* __restrict__ Hcc, const double* __restrict__ bc, const
 //   beta = gamma/gamma_prev, alpha = gamma / (delta - beta gamma / alpha_prev),
 //   p = z + beta p, s = w + beta s, x += alpha p, r -= alpha s, z = Minv r.
 // Every workgroup recomputes the scalars from the same words; workgroup 0 publishes the
-// next state into the other parity slot.  uy_src: partA (npartA block partials) or, multi
-// rank, one all-reduced word.
+// next state into the other parity slot.  uy_src: the u.y word (folded by k_cam_schur's
+// extra workgroup, or all-reduced in a multi-rank job).
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __restrict__ uy_src, int npartA,
+k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __restrict__ uy_src,
            const double* __restrict__ Hccd, const double* __restrict__ Minv, const double* __restrict__ cs,
            int n_cams, int fixed_cam, double tol2, int min_iters,
            double* __restrict__ x, double* __restrict__ r, double* __restrict__ p, double* __restrict__ s,
@@ -680,8 +690,7 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
     }
     return;
   }
-  double uy = 0.0;
-  for (int b = 0; b < npartA; ++b) uy += uy_src[b];
+  const double uy = uy_src[0];
   const double delta = zeta - uy;
   const double beta = (k == 0) ? 0.0 : gamma / sin.gamma_prev;
   const double denom = (k == 0) ? delta : delta - beta * gamma / sin.alpha_prev;
@@ -769,22 +778,34 @@ k_cam_update(const double* __restrict__ cams, const double* __restrict__ dc, con
 // One workgroup folds every partial-sum array of an LM step into the scalar block `scal`
 // (fixed order): residual partials (nR rows x 2), point partials (nB x 4, may be 0 rows),
 // camera partials (nC x 5, may be 0 rows).
-__device__ inline double block_fold(const double* __restrict__ part, int nrows, int ncols, int col, double* sm) {
-  double a = 0.0;
-  for (int i = threadIdx.x; i < nrows; i += 256) a += part[(size_t)i * ncols + col];
-  a = wave_total_dpp(a);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
-  __syncthreads();
-  return sm[0] + sm[1] + sm[2] + sm[3];
-}
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_scalars(const double* __restrict__ partR, int nR, const double* __restrict__ partB, int nB,
           const double* __restrict__ partC, int nC, double* __restrict__ scal) {
-  __shared__ double sm[4];
-  for (int q = 0; q < 2; ++q) { const double v = block_fold(partR, nR, 2, q, sm); if (threadIdx.x == 0) scal[S_SSE + q] = v; }
-  for (int q = 0; q < 4; ++q) { const double v = nB ? block_fold(partB, nB, 4, q, sm) : 0.0; if (threadIdx.x == 0) scal[S_PT_GD + q] = v; }
-  for (int q = 0; q < 5; ++q) { const double v = nC ? block_fold(partC, nC, 5, q, sm) : 0.0; if (threadIdx.x == 0) scal[S_CAM_GD + q] = v; }
+  __shared__ double sm[11 * 16];
+  double a[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < nR; i += 1024) { const double2 t = ((const double2*)partR)[i]; a[0] += t.x; a[1] += t.y; }
+  for (int i = threadIdx.x; i < nB; i += 1024) {
+    const double2 t0 = ((const double2*)partB)[2 * i], t1 = ((const double2*)partB)[2 * i + 1];
+    a[2] += t0.x; a[3] += t0.y; a[4] += t1.x; a[5] += t1.y;
+  }
+  for (int i = threadIdx.x; i < nC; i += 1024) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) a[6 + q] += partC[5 * i + q];
+  }
+#pragma unroll
+  for (int q = 0; q < 11; ++q) a[q] = wave_total_dpp(a[q]);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 11; ++q) sm[wv * 11 + q] = a[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < 11) {
+    double t = 0;
+    for (int w = 0; w < 16; ++w) t += sm[w * 11 + threadIdx.x];
+    const int slot = threadIdx.x < 2 ? S_SSE + threadIdx.x : (threadIdx.x < 6 ? S_PT_GD + (threadIdx.x - 2) : S_CAM_GD + (threadIdx.x - 6));
+    scal[slot] = t;
+  }
 }
 
 // out[0] = max |v[i]|  (single workgroup)
