@@ -1,0 +1,191 @@
+"""Drop-in for the reference's ``BundleAdjuster`` (``src/bundle_adjuster.py:16-240``).
+
+Same constructor, public attributes (``camera_matrix``, ``window_size`` -- callers mutate
+``window_size`` for the final global BA, ``src/main.py:83-86``), same ``run(gmap)`` control
+flow, skip / divergence behaviour, map write-back shapes and log lines (parsed by
+``src/analyze_log.py:42-45``), same private helper names and signatures.  The solve itself
+(``scipy.optimize.least_squares`` at ``:170-174`` and everything it calls back) is replaced
+by the HIP Levenberg-Marquardt / Schur / PCG solver behind ``libba_hip.so``; there is no CPU
+path in this class.
+
+Differences, by design:
+* the Jacobian is analytic on the device, so ``_prepare_sparsity_matrix`` is kept only for
+  API compatibility (it is not needed by ``run``) and the spy-plot step (``:168``) is an
+  optional hook (``sparsity_plot_hook``), off by default;
+* the intermediate ``.pcd`` snapshot (``:187-193``) is written as a plain ASCII PCD, only
+  when the ``DEBUG_DIRS['lba_steps']`` directory exists (no open3d dependency);
+* extra keyword arguments select solver options; their defaults are the reference's
+  literals (``loss='huber'``, ``xtol = ftol = 1e-5``, at most 50 evaluations).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import hip_backend
+from .map_structures import Map
+from .parameters import DEBUG_DIRS
+from .problem import BAProblem, flatten_window, gather_window
+from .rotations import matrices_to_rvecs
+
+
+class BundleAdjuster:
+    def __init__(self, camera_matrix, window_size=5, *, device_id=0, loss='huber', f_scale=1.0, ftol=1e-5,
+                 xtol=1e-5, gtol=1e-8, max_iters=50, pcg_tol=0.1, pcg_max_iters=200, preconditioner='schur_jacobi',
+                 sparsity_plot_hook=None, verbose=0):
+        self.camera_matrix = camera_matrix
+        self.window_size = window_size
+        self.device_id = device_id
+        self.solver_options = dict(loss=loss, f_scale=f_scale, ftol=ftol, xtol=xtol, gtol=gtol, max_iters=max_iters,
+                                   pcg_tol=pcg_tol, pcg_max_iters=pcg_max_iters, preconditioner=preconditioner,
+                                   verbose=verbose)
+        self.sparsity_plot_hook = sparsity_plot_hook
+        self.last_summary = None
+        self._solver = None
+
+    # -- device -------------------------------------------------------------------------
+    def _get_solver(self):
+        if self._solver is None:
+            self._solver = hip_backend.Solver(self.device_id)
+        return self._solver
+
+    def close(self):
+        if self._solver is not None:
+            self._solver.close()
+            self._solver = None
+
+    # -- reference-compatible helpers -----------------------------------------------------
+    def _cost_function(self, params, fixed_kf_pose, fixed_kf_id, adjustable_kf_ids, map_point_ids, observations,
+                       keypoints_2d):
+        """Reprojection residuals (observed - projected, x then y per observation, rows in
+        ``observations`` order) -- ``src/bundle_adjuster.py:24-72`` evaluated on the GPU."""
+        na, npnt = len(adjustable_kf_ids), len(map_point_ids)
+        params = np.asarray(params, dtype=np.float64)
+        kf_index = {fixed_kf_id: 0}
+        kf_index.update({k: i + 1 for i, k in enumerate(adjustable_kf_ids)})
+        mp_index = {m: i for i, m in enumerate(map_point_ids)}
+        # rows the reference skips (unknown map point / keyframe, :54,:63) are dropped here too
+        kept = [(kf_index[k], mp_index[m], keypoints_2d[(k, m)]) for k, m in observations
+                if m in mp_index and k in kf_index]
+        fixed_R, fixed_t = fixed_kf_pose
+        cams = np.empty((na + 1, 6))
+        cams[0, :3] = matrices_to_rvecs(np.asarray(fixed_R, dtype=np.float64)[None])[0]
+        cams[0, 3:] = np.asarray(fixed_t, dtype=np.float64).ravel()
+        cams[1:, :3] = params[:3 * na].reshape(na, 3)
+        cams[1:, 3:] = params[3 * na:6 * na].reshape(na, 3)
+        pts = params[6 * na:].reshape(npnt, 3)
+        K = np.asarray(self.camera_matrix, dtype=np.float64)
+        prob = BAProblem(cams, pts, np.array([a for a, _, _ in kept], dtype=np.int32),
+                         np.array([b for _, b, _ in kept], dtype=np.int32),
+                         np.array([c for _, _, c in kept], dtype=np.float64).reshape(len(kept), 2),
+                         np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]]), 0)
+        s = self._get_solver()
+        s.set_problem(prob)
+        r, _, _ = s.residuals('linear')
+        return r.ravel()
+
+    def _prepare_sparsity_matrix(self, num_adj_kfs, num_mps, adj_kf_ids, mp_ids, observations):
+        """0/1 structure of the Jacobian the reference hands to scipy
+        (``src/bundle_adjuster.py:74-120``): rows 2i, 2i+1 <-> observation i; columns
+        [rvec(3 Na) | tvec(3 Na) | points(3 Np)].  Not used by ``run`` (analytic Jacobian)."""
+        from scipy.sparse import lil_matrix
+        A = lil_matrix((len(observations) * 2, num_adj_kfs * 6 + num_mps * 3), dtype=int)
+        adj = {kf: i for i, kf in enumerate(adj_kf_ids)}
+        mpi = {mp: i for i, mp in enumerate(mp_ids)}
+        for i, (kf, mp) in enumerate(observations):
+            m = mpi.get(mp)
+            if m is None:
+                continue
+            rows = slice(2 * i, 2 * i + 2)
+            A[rows, num_adj_kfs * 6 + 3 * m:num_adj_kfs * 6 + 3 * m + 3] = 1
+            k = adj.get(kf)
+            if k is not None:
+                A[rows, 3 * k:3 * k + 3] = 1
+                A[rows, 3 * num_adj_kfs + 3 * k:3 * num_adj_kfs + 3 * k + 3] = 1
+        return A
+
+    def _gather_local_data(self, gmap: Map, local_kf_ids: list):
+        """``src/bundle_adjuster.py:195-218``."""
+        return gather_window(gmap, local_kf_ids)
+
+    def _update_map(self, gmap: Map, optimized_params: np.ndarray, adjustable_kf_ids: list,
+                    local_map_point_ids: list, rotations=None):
+        """Write optimised poses / points back in place (``src/bundle_adjuster.py:220-240``):
+        ``R`` (3,3), ``t`` (3,1), ``position`` (3,1).  ``rotations`` (Na,3,3), when given,
+        are the device's Rodrigues matrices of the optimised rotation vectors."""
+        na = len(adjustable_kf_ids)
+        x = np.asarray(optimized_params, dtype=np.float64)
+        rvecs = x[:3 * na].reshape(na, 3)
+        tvecs = x[3 * na:6 * na].reshape(na, 3)
+        pts = x[6 * na:].reshape(len(local_map_point_ids), 3)
+        if rotations is None:
+            from .rotations import rvecs_to_matrices
+            rotations = rvecs_to_matrices(rvecs)
+        for i, kf_id in enumerate(adjustable_kf_ids):
+            gmap.keyframes[kf_id].R = np.array(rotations[i], dtype=np.float64).reshape(3, 3)
+            gmap.keyframes[kf_id].t = tvecs[i].reshape(3, 1).copy()
+        for i, mp_id in enumerate(local_map_point_ids):
+            gmap.map_points[mp_id].position = pts[i].reshape(3, 1).copy()
+
+    # -- the solve step -------------------------------------------------------------------
+    def run(self, gmap: Map):
+        """Sliding-window / global bundle adjustment, ``src/bundle_adjuster.py:122-193``."""
+        print("    --- Running Local Bundle Adjustment ---")
+        all_kf_ids = sorted(gmap.keyframes.keys())
+        if len(all_kf_ids) < self.window_size:
+            print("    -> LBA Skipped: Not enough keyframes.")
+            return
+        local_kf_ids = all_kf_ids[-(self.window_size + 1):-1]      # newest keyframe excluded (:139)
+        fixed_kf_id = local_kf_ids[0]
+        adjustable_kf_ids = local_kf_ids[1:]
+        if not adjustable_kf_ids:
+            print("    -> LBA Skipped: No adjustable keyframes.")
+            return
+        local_map_point_ids, observations, keypoints_2d = self._gather_local_data(gmap, local_kf_ids)
+        if not local_map_point_ids:
+            print("    -> LBA Skipped: No points in the local window.")
+            return
+
+        prob = flatten_window(gmap, local_kf_ids, local_map_point_ids, observations, keypoints_2d, self.camera_matrix)
+        if self.sparsity_plot_hook is not None:
+            self.sparsity_plot_hook(self._prepare_sparsity_matrix(len(adjustable_kf_ids), len(local_map_point_ids),
+                                                                  adjustable_kf_ids, local_map_point_ids, observations),
+                                    fixed_kf_id, local_kf_ids[-1])
+        solver = self._get_solver()
+        solver.set_problem(prob)
+        summary = solver.solve(**self.solver_options)
+        self.last_summary = summary
+        initial_cost, final_cost = summary["initial_sse"], summary["final_sse"]     # plain SSE (:165, :176)
+        if final_cost >= initial_cost:
+            print(f"    -> LBA Diverged! Cost increased from {initial_cost:.2f} to {final_cost:.2f}. Discarding results.")
+            return
+
+        cams, pts = solver.get_params()
+        R = solver.get_rotations()
+        x = np.concatenate([cams[1:, :3].ravel(), cams[1:, 3:].ravel(), pts.ravel()])
+        self._update_map(gmap, x, adjustable_kf_ids, local_map_point_ids, rotations=R[1:])
+
+        improvement = 100.0 * (initial_cost - final_cost) / (initial_cost + 1e-8)
+        print(f"    -> LBA Complete. Initial Cost: {initial_cost:.2f}, Final Cost: {final_cost:.2f}, "
+              f"Improvement: {improvement:.2f}%")
+
+        lba_steps_dir = DEBUG_DIRS['lba_steps']
+        if os.path.isdir(lba_steps_dir):
+            pcd = gmap.get_pcd()
+            if pcd.has_points():
+                pcd_filename = os.path.join(lba_steps_dir, f"map_after_lba_kf_{fixed_kf_id}.pcd")
+                _write_ascii_pcd(pcd_filename, pcd.points, pcd.colors)
+                print(f"    -> Saved intermediate map to {pcd_filename}")
+
+
+def _write_ascii_pcd(path, points, colors):
+    pts = np.asarray(points, dtype=np.float64).reshape(-1, 3)
+    cols = np.clip(np.asarray(colors, dtype=np.float64).reshape(-1, 3), 0.0, 1.0)
+    rgb = (np.round(cols * 255).astype(np.uint32) @ np.array([65536, 256, 1], dtype=np.uint32)).astype(np.uint32)
+    with open(path, "w") as f:
+        f.write("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgb\nSIZE 4 4 4 4\n"
+                "TYPE F F F U\nCOUNT 1 1 1 1\n")
+        f.write(f"WIDTH {pts.shape[0]}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {pts.shape[0]}\nDATA ascii\n")
+        for p, c in zip(pts, rgb):
+            f.write(f"{p[0]:.9g} {p[1]:.9g} {p[2]:.9g} {int(c)}\n")

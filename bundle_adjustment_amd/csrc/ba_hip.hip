@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -131,6 +132,7 @@ struct ba_handle {
   PcgState* h_st = nullptr;
   // comm
   int rank = 0, world = 1;
+  bool force_fold = false;     // BA_DEBUG_FOLD=1: run the multi-rank kernel sequence (fold, folded consumers) on one rank
   ncclComm_t nccl = nullptr;
   // profiling
   bool profile = false;
@@ -168,6 +170,7 @@ extern "C" int ba_create(int device_id, ba_handle** out) {
   HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHECK(hipHostMalloc((void**)&h->h_scal, 64 * sizeof(double)));
   HIPCHECK(hipHostMalloc((void**)&h->h_st, 2 * sizeof(PcgState)));
+  { const char* e = getenv("BA_DEBUG_FOLD"); h->force_fold = e && e[0] == '1'; }
   HIPCHECK(allow_big_lds(k_pt_linearize<true, true>));
   HIPCHECK(allow_big_lds(k_pt_linearize<false, true>));
   HIPCHECK(allow_big_lds(k_pt_schur<true, 0, true>));
@@ -535,8 +538,9 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
 #undef PS_ARGS
 }
 // multi-rank: fold partials -> comm (+ commE) and all-reduce them.  Single rank: nothing.
+static bool folded(ba_handle* h) { return h->world > 1 || h->force_fold; }
 static int exchange_schur(ba_handle* h, bool with_diag, bool with_uy) {
-  if (h->world == 1) return BA_OK;
+  if (!folded(h)) return BA_OK;
   {
     Scope sc(h, BA_K_MISC);
     hipLaunchKernelGGL(k_fold_partials, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->part6.p,
@@ -547,9 +551,9 @@ static int exchange_schur(ba_handle* h, bool with_diag, bool with_uy) {
   if (with_diag) return allreduce(h, h->commE.p, 21 * (size_t)h->Nc);
   return BA_OK;
 }
-static const double* wy_src(ba_handle* h) { return h->world == 1 ? h->part6.p : h->comm.p; }
-static const double* e_src(ba_handle* h) { return h->world == 1 ? h->partE.p : h->commE.p; }
-static int wy_parts(ba_handle* h) { return h->world == 1 ? NPART : 1; }
+static const double* wy_src(ba_handle* h) { return folded(h) ? h->comm.p : h->part6.p; }
+static const double* e_src(ba_handle* h) { return folded(h) ? h->commE.p : h->partE.p; }
+static int wy_parts(ba_handle* h) { return folded(h) ? 1 : NPART; }
 
 static void launch_pcg_setup(ba_handle* h, double lambda, bool schur_diag) {
   Scope sc(h, BA_K_PCG_UPDATE);

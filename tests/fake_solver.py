@@ -1,0 +1,44 @@
+"""Test double for hip_backend.Solver backed by the CPU oracle.  Lets the host-side logic
+of BundleAdjuster (window selection, packing, skip / divergence paths, write-back, log
+lines) be tested where there is no GPU.  Test infrastructure only."""
+import numpy as np
+
+from oracle import ba_oracle as o
+
+
+class OracleSolver:
+    force_diverge = False
+
+    def __init__(self, device_id=0):
+        self.prob = None
+
+    def close(self):
+        pass
+
+    def set_problem(self, prob, with_params=True):
+        prob.validate()
+        self.prob = prob
+        self.cams, self.pts = prob.cams.copy(), prob.pts.copy()
+        self.n_cams, self.n_pts, self.n_obs = prob.n_cams, prob.n_pts, prob.n_obs
+
+    def residuals(self, loss="linear", f_scale=1.0, want_vector=True):
+        p = self.prob
+        r = o.residuals(self.cams, self.pts, p.cam_idx, p.pt_idx, p.uv, p.K4)
+        return r, float((r * r).sum()), o.robust_cost(r, loss)
+
+    def solve(self, **kw):
+        p = self.prob
+        out = o.lm_solve(self.cams, self.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, p.fixed_cam, kw.get("loss", "huber"),
+                         max_iters=kw.get("max_iters", 50), ftol=kw.get("ftol", 1e-5), xtol=kw.get("xtol", 1e-5),
+                         gtol=kw.get("gtol", 1e-8), pcg_tol=kw.get("pcg_tol", 0.1))
+        if self.force_diverge:
+            return dict(initial_sse=out["sse0"], final_sse=out["sse0"] * 1.5, iterations=1, accepted=0)
+        self.cams, self.pts = out["cams"], out["pts"]
+        return dict(initial_sse=out["sse0"], final_sse=out["sse"], initial_cost=out["cost0"], final_cost=out["cost"],
+                    iterations=out["iterations"], accepted=out["accepted"], pcg_iterations=out["pcg_iters"])
+
+    def get_params(self):
+        return self.cams.copy(), self.pts.copy()
+
+    def get_rotations(self):
+        return o.rodrigues_batch(self.cams[:, :3])

@@ -1,0 +1,73 @@
+"""GPU: the drop-in BundleAdjuster end to end on maps rebuilt from the reference's goldens."""
+import io
+import re
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from bundle_adjustment_amd import BundleAdjuster
+from bundle_adjustment_amd.synthetic import make_config, problem_to_map
+from oracle import ba_oracle as o
+from tests.helpers import golden_cost_case, load_golden, rebuild_map
+
+pytestmark = pytest.mark.gpu
+LOG_RE = re.compile(r"^    -> LBA Complete\. Initial Cost: (\d+\.\d\d), Final Cost: (\d+\.\d\d), Improvement: (-?\d+\.\d\d)%$")
+
+
+def _run(ba, gmap):
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        ba.run(gmap)
+    return buf.getvalue()
+
+
+@pytest.mark.parametrize("name", ["cost_seed0", "cost_edge"])
+def test_cost_function_entry_point(name):
+    """BundleAdjuster._cost_function (same signature as the reference's) on the GPU ==
+    the imported reference's output vector."""
+    g = load_golden(name)
+    ba = BundleAdjuster(g["K"], window_size=int(g["window_size"]))
+    kw = golden_cost_case(g)
+    for xk, fk in (("x0", "f0"), ("x1", "f1")):
+        f = ba._cost_function(g[xk], **kw)
+        assert f.shape == g[fk].shape
+        assert np.abs(f - g[fk]).max() <= 1e-9 * max(1.0, np.abs(g[fk]).max())
+    ba.close()
+
+
+@pytest.mark.parametrize("name", ["run_seed0", "run_seed1", "run_global"])
+def test_run_on_reference_maps(name):
+    g = load_golden(name)
+    gmap = rebuild_map(g)
+    ba = BundleAdjuster(g["K"], window_size=int(g["window_size"]))
+    lines = _run(ba, gmap).splitlines()
+    ref = str(g["log"]).splitlines()
+    assert lines[0] == ref[0]
+    m, mref = LOG_RE.match(lines[1]), LOG_RE.match(ref[1])
+    assert m and mref
+    assert m.group(1) == mref.group(1)
+    assert float(m.group(2)) <= float(mref.group(2)) * (1 + 1e-9)
+    # the written-back map reproduces the reported final cost through the oracle residual
+    w = int(g["window_size"])
+    local = sorted(gmap.keyframes)[-(w + 1):-1]
+    mp_ids, observations, kp2d = ba._gather_local_data(gmap, local)
+    adj = local[1:]
+    x = np.concatenate([np.array([o.rodrigues_to_vec(gmap.keyframes[i].R) for i in adj]).ravel(),
+                        np.array([gmap.keyframes[i].t.ravel() for i in adj]).ravel(),
+                        np.array([gmap.map_points[i].position.ravel() for i in mp_ids]).ravel()])
+    f = o.reference_cost_function(x, (gmap.keyframes[local[0]].R, gmap.keyframes[local[0]].t), local[0], adj, mp_ids,
+                                  observations, kp2d, g["K"])
+    assert abs(float((f ** 2).sum()) - ba.last_summary["final_sse"]) <= 1e-6 * ba.last_summary["final_sse"]
+    ba.close()
+
+
+def test_run_on_synthetic_c2_map():
+    p = make_config("C2", seed=2)
+    gmap = problem_to_map(p)
+    K = np.array([[p.K4[0], 0, p.K4[2]], [0, p.K4[1], p.K4[3]], [0, 0, 1.0]])
+    ba = BundleAdjuster(K, window_size=p.n_cams)
+    log = _run(ba, gmap)
+    m = LOG_RE.match(log.splitlines()[1])
+    assert m and float(m.group(3)) > 90.0
+    ba.close()

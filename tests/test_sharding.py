@@ -1,0 +1,150 @@
+"""Landmark sharding.  CPU: the shard bookkeeping, and -- with two gloo ranks
+-- that all-reducing per-shard reduced camera systems reproduces the full system (oracle as
+the checker).  GPU: shards computed through the C ABI sum to the whole."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from bundle_adjustment_amd.problem import extract_shard, shard_by_landmark
+from bundle_adjustment_amd.synthetic import make_problem
+from oracle import ba_oracle as o
+
+
+def test_shards_partition_points_and_observations():
+    p = make_problem(9, 500, 4, seed=1)
+    for g in (1, 2, 3, 8):
+        ranges = shard_by_landmark(p, g)
+        assert ranges[0][0] == 0 and ranges[-1][1] == p.n_pts
+        seen = np.zeros(p.n_obs, dtype=int)
+        counts = []
+        for (b, e), nxt in zip(ranges, ranges[1:] + [(p.n_pts, p.n_pts)]):
+            assert e == nxt[0] and b <= e
+            sub, sel = extract_shard(p, b, e)
+            seen[sel] += 1
+            counts.append(sub.n_obs)
+            assert sub.n_cams == p.n_cams and sub.n_pts == e - b
+            np.testing.assert_array_equal(sub.pts, p.pts[b:e])
+            np.testing.assert_array_equal(sub.pt_idx + b, p.pt_idx[sel])
+            np.testing.assert_array_equal(sub.uv, p.uv[sel])
+        assert np.all(seen == 1)
+        assert max(counts) - min(counts) <= 2 * 4 + 4          # balanced by observation count
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rank_main(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    p = make_problem(7, 300, 4, seed=5)
+    b, e = shard_by_landmark(p, world)[rank]
+    sub, _ = extract_shard(p, b, e)
+    lam = 1e-3
+    ne = o.normal_equations(sub.cams, sub.pts, sub.cam_idx, sub.pt_idx, sub.uv, sub.K4, 0, "huber")
+    # what every rank all-reduces once per linearisation: Hcc | bc
+    hb = torch.from_numpy(np.concatenate([ne["Hcc"].ravel(), ne["bc"].ravel()]))
+    dist.all_reduce(hb)
+    nc = p.n_cams
+    ne["Hcc"] = hb[:36 * nc].numpy().reshape(nc, 6, 6).copy()
+    ne["bc"] = hb[36 * nc:].numpy().reshape(nc, 6).copy()
+    # per PCG iteration: the shard's W Hpp^-1 W^T v (and the u.y word) -- all-reduced; S v assembled from it
+    op = o.SchurOperator(ne, sub.cam_idx, sub.pt_idx, lam, 0)
+    v = np.random.default_rng(0).normal(size=(nc, 6))
+    v[0] = 0
+    wy = torch.from_numpy(op.w_times(op.wt_times(v)))
+    dist.all_reduce(wy)
+    sv = np.einsum("cij,cj->ci", op.Hccd, v) - wy.numpy()
+    sv[0] = v[0]
+    # right-hand side
+    y0 = np.einsum("pij,pj->pi", op.Hppinv, ne["bp"])
+    wy0 = torch.from_numpy(op.w_times(y0))
+    dist.all_reduce(wy0)
+    g = -(ne["bc"] - wy0.numpy())
+    g[0] = 0
+    if rank == 0:
+        full = o.normal_equations(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, 0, "huber")
+        fop = o.SchurOperator(full, p.cam_idx, p.pt_idx, lam, 0)
+        q.put((float(np.abs(sv - fop.apply(v)).max() / np.abs(fop.apply(v)).max()),
+               float(np.abs(g - fop.rhs()).max() / np.abs(fop.rhs()).max()),
+               float(np.abs(ne["Hcc"] - full["Hcc"]).max() / np.abs(full["Hcc"]).max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_allreduce_of_reduced_camera_system():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    errs = q.get(timeout=120)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert max(errs) <= 1e-12, errs
+
+
+@pytest.mark.gpu
+def test_gpu_shards_sum_to_the_whole():
+    """Through the C ABI: Hcc/bc of the shards add up to the full problem's, and at lambda = 0
+    so do the Schur products (each shard contributes its own W Hpp^-1 W^T)."""
+    from bundle_adjustment_amd import hip_backend
+    p = make_problem(10, 600, 4, seed=8)
+    with hip_backend.Solver(0) as s:
+        s.set_problem(p)
+        Hcc, bc, _, _ = s.linearize("huber")
+        v = np.random.default_rng(1).normal(size=(p.n_cams, 6))
+        v[0] = 0
+        sv = s.schur_apply(0.0, v)
+        acc_H, acc_b, acc_sv = np.zeros_like(Hcc), np.zeros_like(bc), np.zeros_like(sv)
+        for b, e in shard_by_landmark(p, 3):
+            sub, _ = extract_shard(p, b, e)
+            s.set_problem(sub)
+            h, bb, _, _ = s.linearize("huber")
+            acc_H += h
+            acc_b += bb
+            acc_sv += s.schur_apply(0.0, v)
+        assert np.abs(acc_H - Hcc).max() <= 1e-10 * np.abs(Hcc).max()
+        assert np.abs(acc_b - bc).max() <= 1e-10 * np.abs(bc).max()
+        acc_sv[0] = sv[0]
+        assert np.abs(acc_sv - sv).max() <= 1e-9 * np.abs(sv).max()
+
+
+@pytest.mark.gpu
+def test_gpu_folded_multi_rank_kernel_sequence(monkeypatch):
+    """BA_DEBUG_FOLD=1 makes a single rank run the exact kernel sequence of a multi-rank job
+    (fold partials -> comm buffers -> folded consumers), minus the RCCL call itself: same
+    answers as the direct path."""
+    from bundle_adjustment_amd import hip_backend
+    p = make_problem(12, 800, 5, seed=4, outlier_frac=0.02)
+    kw = dict(loss="huber", max_iters=25, ftol=1e-13, xtol=1e-13, gtol=0.0, pcg_tol=1e-3)
+    with hip_backend.Solver(0) as s:
+        s.set_problem(p)
+        ref = s.solve(**kw)
+        ref_params = s.get_params()
+    monkeypatch.setenv("BA_DEBUG_FOLD", "1")
+    with hip_backend.Solver(0) as s:
+        s.set_problem(p)
+        s.linearize("huber")
+        g1 = s.schur_rhs(1e-3)
+        out = s.solve(**kw)
+        cams, pts = s.get_params()
+    monkeypatch.delenv("BA_DEBUG_FOLD")
+    with hip_backend.Solver(0) as s:
+        s.set_problem(p)
+        s.linearize("huber")
+        g0 = s.schur_rhs(1e-3)
+    assert np.abs(g1 - g0).max() <= 1e-12 * np.abs(g0).max()
+    assert abs(out["final_cost"] - ref["final_cost"]) <= 1e-10 * ref["final_cost"]
+    assert np.abs(cams - ref_params[0]).max() <= 1e-7 and np.abs(pts - ref_params[1]).max() <= 1e-6
