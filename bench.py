@@ -118,7 +118,8 @@ def main():
         b, e = shard_by_landmark(prob, world)[rank]
         shard, _ = extract_shard(prob, b, e)
 
-    solver = hip_backend.Solver(local_rank if world > 1 else 0)
+    ndev = hip_backend.device_count()
+    solver = hip_backend.Solver((local_rank % ndev) if world > 1 else 0)
     if world > 1:
         uid = [hip_backend.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
