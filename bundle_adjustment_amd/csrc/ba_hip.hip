@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -112,24 +113,32 @@ struct ba_handle {
   double K4[4] = {1, 1, 0, 0};
   // observation lists (camera order, point order)
   DBuf<int> offk, c_pt, c_orig, pt_off, p_cam;
-  DBuf<double2> c_uv, p_uv, c_w, p_w;
+  DBuf<double2> c_uv, p_uv, c_w[2], p_w;   // c_w / partL are double-buffered: the camera half of the next
+                                           // linearisation is computed speculatively at the trial point
   // parameters (current / trial): cameras, camera state, point table
   DBuf<double> cams[2], cs[2], ptab[2], stage;
   int cur = 0;
   // camera table of the point passes, normal equations
-  DBuf<double> camA, HccBc, Hpp, bp, Hppinv, y0, Hccd, Minv;
+  DBuf<double> camA[2], HccBc, Hpp, bp, Hppinv, y0, Hccd, Minv;
   // partial sums
-  DBuf<double> partR, partL, part6, partE, partA, partB, partC, partV;
+  DBuf<double> partR, partL[2], part6, partE, partA, partB, partC, partV;
+  int lb = 0;                  // which c_w / partL buffer holds the current linearisation
+  hipEvent_t ev_decide = nullptr;
   // PCG vectors, comm buffers (multi-rank), scalars
   DBuf<double> gvec, x, r, p, s, z, vin, comm, commE, scal, rbuf;
   DBuf<PcgState> st;
   int nblkP = 1, ppb = 1, nblkV = 1;
-  int pcg_pred = 6;            // PCG iterations to launch before the first look at the device state
   bool lds_tab = true;
   size_t lds_bytes = 0;
   // pinned host mirror for scalars
   double* h_scal = nullptr;
+  double* d_scal_host = nullptr;   // device-side address of h_scal (host-mapped, coherent)
   PcgState* h_st = nullptr;
+  double* h_partV = nullptr;
+  double* h_gmax = nullptr;
+  long long* h_flags = nullptr;    // host-mapped progress words: [0..1] PCG verdicts, [2..3] step scalars
+  long long* d_flags = nullptr;
+  long long flag_base = 1, step_seq = 1;
   // comm
   int rank = 0, world = 1;
   bool force_fold = false;     // BA_DEBUG_FOLD=1: run the multi-rank kernel sequence (fold, folded consumers) on one rank
@@ -168,8 +177,15 @@ extern "C" int ba_create(int device_id, ba_handle** out) {
   h->device = device_id;
   HIPCHECK(hipSetDevice(device_id));
   HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  HIPCHECK(hipHostMalloc((void**)&h->h_scal, 64 * sizeof(double)));
+  HIPCHECK(hipEventCreateWithFlags(&h->ev_decide, hipEventDisableTiming));
+  HIPCHECK(hipHostMalloc((void**)&h->h_scal, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+  HIPCHECK(hipHostGetDevicePointer((void**)&h->d_scal_host, h->h_scal, 0));
   HIPCHECK(hipHostMalloc((void**)&h->h_st, 2 * sizeof(PcgState)));
+  HIPCHECK(hipHostMalloc((void**)&h->h_partV, 4 * 4096 * sizeof(double)));
+  HIPCHECK(hipHostMalloc((void**)&h->h_gmax, 8 * sizeof(double)));
+  HIPCHECK(hipHostMalloc((void**)&h->h_flags, 8 * sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent));
+  memset(h->h_flags, 0, 8 * sizeof(long long));
+  HIPCHECK(hipHostGetDevicePointer((void**)&h->d_flags, h->h_flags, 0));
   { const char* e = getenv("BA_DEBUG_FOLD"); h->force_fold = e && e[0] == '1'; }
   HIPCHECK(allow_big_lds(k_pt_linearize<true, true>));
   HIPCHECK(allow_big_lds(k_pt_linearize<false, true>));
@@ -189,18 +205,22 @@ extern "C" int ba_destroy(ba_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   if (h->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(h->nccl);
   for (auto e : h->ev) (void)hipEventDestroy(e);
+  if (h->ev_decide) (void)hipEventDestroy(h->ev_decide);
   DBuf<int>* ib[] = {&h->offk, &h->c_pt, &h->c_orig, &h->pt_off, &h->p_cam};
   for (auto b : ib) b->release();
-  DBuf<double2>* d2[] = {&h->c_uv, &h->p_uv, &h->c_w, &h->p_w};
+  DBuf<double2>* d2[] = {&h->c_uv, &h->p_uv, &h->c_w[0], &h->c_w[1], &h->p_w};
   for (auto b : d2) b->release();
   DBuf<double>* db[] = {&h->cams[0], &h->cams[1], &h->cs[0], &h->cs[1], &h->ptab[0], &h->ptab[1], &h->stage,
-                        &h->camA, &h->HccBc, &h->Hpp, &h->bp, &h->Hppinv, &h->y0, &h->Hccd, &h->Minv,
-                        &h->partR, &h->partL, &h->part6, &h->partE, &h->partA, &h->partB, &h->partC, &h->partV,
+                        &h->camA[0], &h->camA[1], &h->HccBc, &h->Hpp, &h->bp, &h->Hppinv, &h->y0, &h->Hccd, &h->Minv,
+                        &h->partR, &h->partL[0], &h->partL[1], &h->part6, &h->partE, &h->partA, &h->partB, &h->partC, &h->partV,
                         &h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin, &h->comm, &h->commE, &h->scal, &h->rbuf};
   for (auto b : db) b->release();
   h->st.release();
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->h_st) (void)hipHostFree(h->h_st);
+  if (h->h_partV) (void)hipHostFree(h->h_partV);
+  if (h->h_gmax) (void)hipHostFree(h->h_gmax);
+  if (h->h_flags) (void)hipHostFree(h->h_flags);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return BA_OK;
@@ -356,6 +376,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   h->Nc = Nc; h->Np = Np; h->Nobs = No; h->fixed = fixed_cam;
   memcpy(h->K4, K4, sizeof h->K4);
   h->nblkV = (Nc + VEC_BLOCK - 1) / VEC_BLOCK;
+  if (h->nblkV > 4096) return fail(BA_ERR_INVALID, "more than %d cameras are not supported", 4096 * VEC_BLOCK);
   h->lds_bytes = (size_t)Nc * TA * sizeof(double);
   h->lds_tab = h->lds_bytes <= 150 * 1024;
   const int pts_per_pass = PT_THREADS / LPP;
@@ -366,19 +387,20 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(h->offk.alloc((size_t)Nc * (NPART + 1))); HIPCHECK(h->pt_off.alloc(Np + 1));
   HIPCHECK(h->c_pt.alloc(nobs1)); HIPCHECK(h->c_orig.alloc(nobs1)); HIPCHECK(h->p_cam.alloc(nobs1));
   HIPCHECK(h->c_uv.alloc(nobs1)); HIPCHECK(h->p_uv.alloc(nobs1));
-  HIPCHECK(h->c_w.alloc(nobs1)); HIPCHECK(h->p_w.alloc(nobs1));
+  HIPCHECK(h->c_w[0].alloc(nobs1)); HIPCHECK(h->c_w[1].alloc(nobs1)); HIPCHECK(h->p_w.alloc(nobs1));
   for (int k = 0; k < 2; ++k) {
     HIPCHECK(h->cams[k].alloc(6 * (size_t)Nc)); HIPCHECK(h->cs[k].alloc(CS * (size_t)Nc));
     HIPCHECK(h->ptab[k].alloc(PT * np1));
     HIPCHECK(hipMemsetAsync(h->ptab[k].p, 0, PT * np1 * sizeof(double), h->stream));
   }
   HIPCHECK(h->stage.alloc(3 * np1));
-  HIPCHECK(h->camA.alloc(TA * (size_t)Nc));
+  HIPCHECK(h->camA[0].alloc(TA * (size_t)Nc)); HIPCHECK(h->camA[1].alloc(TA * (size_t)Nc));
   HIPCHECK(h->HccBc.alloc(27 * (size_t)Nc + 8));   // Hcc (21 Nc) | bc (6 Nc): one all-reduce
   HIPCHECK(h->Hpp.alloc(6 * np1)); HIPCHECK(h->bp.alloc(3 * np1)); HIPCHECK(h->Hppinv.alloc(6 * np1));
   HIPCHECK(h->y0.alloc(3 * np1));
   HIPCHECK(h->Hccd.alloc(21 * (size_t)Nc)); HIPCHECK(h->Minv.alloc(21 * (size_t)Nc));
-  HIPCHECK(h->partR.alloc(2 * (size_t)NPART * Nc)); HIPCHECK(h->partL.alloc(27 * (size_t)NPART * Nc));
+  HIPCHECK(h->partR.alloc(2 * (size_t)NPART * Nc));
+  HIPCHECK(h->partL[0].alloc(27 * (size_t)NPART * Nc)); HIPCHECK(h->partL[1].alloc(27 * (size_t)NPART * Nc));
   HIPCHECK(h->part6.alloc(6 * (size_t)NPART * Nc)); HIPCHECK(h->partE.alloc(21 * (size_t)NPART * Nc));
   HIPCHECK(h->partA.alloc(h->nblkP)); HIPCHECK(h->partB.alloc(4 * (size_t)h->nblkP));
   HIPCHECK(h->partC.alloc(5 * (size_t)h->nblkV)); HIPCHECK(h->partV.alloc(4 * (size_t)h->nblkV));
@@ -387,7 +409,9 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(h->comm.alloc(6 * (size_t)Nc + 8)); HIPCHECK(h->commE.alloc(21 * (size_t)Nc));
   HIPCHECK(h->scal.alloc(64));
   HIPCHECK(h->st.alloc(2));
-  HIPCHECK(hipMemsetAsync(h->camA.p, 0, TA * (size_t)Nc * sizeof(double), h->stream));
+  HIPCHECK(hipMemsetAsync(h->camA[0].p, 0, TA * (size_t)Nc * sizeof(double), h->stream));
+  HIPCHECK(hipMemsetAsync(h->camA[1].p, 0, TA * (size_t)Nc * sizeof(double), h->stream));
+  h->lb = 0;
   HIPCHECK(hipMemcpyAsync(h->offk.p, offk.data(), offk.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(hipMemcpyAsync(h->pt_off.p, pt_off.data(), (Np + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream));
   if (No > 0) {
@@ -417,7 +441,7 @@ extern "C" int ba_set_params(ba_handle* h, const double* cams, const double* pts
     HIPCHECK(hipMemcpyAsync(h->stage.p, pts, 3 * (size_t)h->Np * sizeof(double), hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_pack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->stage.p, h->Np, h->ptab[0].p);
   }
-  hipLaunchKernelGGL(k_cam_prepare, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->cams[0].p, h->cs[0].p, h->Nc);
+  hipLaunchKernelGGL(k_cam_prepare, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->cams[0].p, h->cs[0].p, h->camA[0].p, h->Nc);
   HIPCHECK(hipStreamSynchronize(h->stream));
   h->have_params = true;
   h->linearized = false;
@@ -456,38 +480,59 @@ static void launch_residual(ba_handle* h, int which, bool robust, double fscale,
                      h->partR.p);
 }
 // fold the partial arrays of a step into `scal` (residual always; point / camera parts optional)
-static void launch_scalars(ba_handle* h, bool with_step) {
+// with_step: also the step partials and the PCG verdict for iteration k; on a single rank the
+// results go straight to the host-mapped mirror (no copy kernel)
+static void launch_scalars(ba_handle* h, bool with_step, int k = 0, double tol2 = 0.0, int min_iters = 0, long long seq = 0) {
   Scope sc(h, BA_K_MISC);
+  const bool direct = with_step && h->world == 1;     // results straight into host-mapped memory + sequence word
   hipLaunchKernelGGL(k_scalars, dim3(1), dim3(1024), 0, h->stream, h->partR.p, NPART * h->Nc, h->partB.p,
-                     (with_step && h->Np > 0) ? h->nblkP : 0, h->partC.p, with_step ? h->nblkV : 0, h->scal.p);
+                     (with_step && h->Np > 0) ? h->nblkP : 0, h->partC.p, with_step ? h->nblkV : 0, k,
+                     with_step ? (const PcgState*)h->st.p : (const PcgState*)nullptr, h->partV.p, h->nblkV, tol2, min_iters,
+                     h->scal.p, direct ? h->d_scal_host : (double*)nullptr, direct ? h->d_flags + 2 : (long long*)nullptr, seq);
 }
-static void launch_linearize(ba_handle* h, bool robust, double fscale) {
+// spin on a host-mapped sequence word until it reaches `target` (the device publishes with a
+// system-scope release); a wall-clock limit turns a wedged GPU into an error instead of a hang
+static int wait_flag(ba_handle* h, int idx, long long target) {
+  volatile long long* f = h->h_flags + idx;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (*f < target) {
+    if ((++spins & 0xfff) == 0 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0)
+      return fail(BA_ERR_HIP, "timed out waiting for the device (flag %d: %lld < %lld)", idx, (long long)*f, target);
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return BA_OK;
+}
+// camera half of the linearisation at parameter set `which`, into buffer set `buf`
+static void launch_lin_cam(ba_handle* h, int which, int buf, bool robust, double fscale) {
+  Scope sc(h, BA_K_LINEARIZE_CAM);
+  auto kern = robust ? k_cam_linearize<true> : k_cam_linearize<false>;
+  hipLaunchKernelGGL(kern, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[which].p, h->ptab[which].p, h->offk.p,
+                     h->c_pt.p, h->c_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, h->c_w[buf].p,
+                     h->partL[buf].p);
+}
+static void launch_lin_finalize(ba_handle* h) {
+  Scope sc(h, BA_K_MISC);
+  hipLaunchKernelGGL(k_lin_finalize, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->partL[h->lb].p, h->cs[h->cur].p,
+                     h->Nc, h->fixed, h->HccBc.p, bc_ptr(h));
+}
+// point half at the current parameters, with the damped inverse / y0 at `lambda` fused in
+static void launch_lin_pt(ba_handle* h, bool robust, double fscale, double lambda) {
+  if (h->Np == 0) return;
+  Scope sc(h, BA_K_LINEARIZE_PT);
   const int w = h->cur;
-  {
-    Scope sc(h, BA_K_LINEARIZE_CAM);
-    auto kern = robust ? k_cam_linearize<true> : k_cam_linearize<false>;
-    hipLaunchKernelGGL(kern, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[w].p, h->ptab[w].p, h->offk.p,
-                       h->c_pt.p, h->c_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, h->c_w.p, h->partL.p);
+#define LP_ARGS h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, \
+                h->Np, h->Nc, h->ppb, lambda, h->Hpp.p, h->bp.p, h->p_w.p, h->Hppinv.p, h->y0.p
+  const size_t lds = h->lds_tab ? h->lds_bytes : 0;
+  if (h->lds_tab) {
+    if (robust) hipLaunchKernelGGL((k_pt_linearize<true, true>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, LP_ARGS);
+    else        hipLaunchKernelGGL((k_pt_linearize<false, true>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, LP_ARGS);
+  } else {
+    if (robust) hipLaunchKernelGGL((k_pt_linearize<true, false>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, LP_ARGS);
+    else        hipLaunchKernelGGL((k_pt_linearize<false, false>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, LP_ARGS);
   }
-  {
-    Scope sc(h, BA_K_MISC);
-    hipLaunchKernelGGL(k_lin_finalize, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->partL.p, h->cs[w].p, h->Nc,
-                       h->fixed, h->HccBc.p, bc_ptr(h), h->camA.p);
-  }
-  if (h->Np > 0) {
-    Scope sc(h, BA_K_LINEARIZE_PT);
-#define LP_ARGS h->camA.p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, \
-                h->Np, h->Nc, h->ppb, h->Hpp.p, h->bp.p, h->p_w.p
-    const size_t lds = h->lds_tab ? h->lds_bytes : 0;
-    if (h->lds_tab) {
-      if (robust) hipLaunchKernelGGL((k_pt_linearize<true, true>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, LP_ARGS);
-      else        hipLaunchKernelGGL((k_pt_linearize<false, true>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, LP_ARGS);
-    } else {
-      if (robust) hipLaunchKernelGGL((k_pt_linearize<true, false>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, LP_ARGS);
-      else        hipLaunchKernelGGL((k_pt_linearize<false, false>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, LP_ARGS);
-    }
 #undef LP_ARGS
-  }
 }
 static void launch_point_invert(ba_handle* h, double lambda) {
   if (h->Np == 0) return;
@@ -500,7 +545,7 @@ static void launch_point_invert(ba_handle* h, double lambda) {
 static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int k, double tol2, int min_iters) {
   Scope sc(h, diag ? BA_K_PRECOND : BA_K_SCHUR_CAM);
   const int w = h->cur;
-#define CS_ARGS h->cs[w].p, h->ptab[w].p, h->offk.p, h->c_pt.p, h->c_w.p, h->Hppinv.p, h->K4[0], h->K4[1], h->Nc, h->fixed, \
+#define CS_ARGS h->cs[w].p, h->ptab[w].p, h->offk.p, h->c_pt.p, h->c_w[h->lb].p, h->Hppinv.p, h->K4[0], h->K4[1], h->Nc, h->fixed, \
                 h->part6.p, h->partE.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->partA.p,              \
                 (h->Np > 0 ? h->nblkP : 0), h->comm.p + 6 * (size_t)h->Nc
   const dim3 g(cam_grid(h) + (pcg ? 1 : 0)), b(64 * WPB);
@@ -516,12 +561,12 @@ static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int
   }
 #undef CS_ARGS
 }
-// point pass with the vtil half of camA; mode 0 = PCG iteration k, mode 1 = back substitution
+// point pass with the camera vector in vtil; mode 0 = PCG iteration k, mode 1 = back substitution
 static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double tol2, int min_iters) {
   if (h->Np == 0) return;
   Scope sc(h, mode == 0 ? BA_K_SCHUR_PT : BA_K_BACKSUB);
   const int w = h->cur;
-#define PS_ARGS h->camA.p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_w.p, h->Hppinv.p, h->K4[0], h->K4[1], h->Np, h->Nc, \
+#define PS_ARGS h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_w.p, h->Hppinv.p, h->K4[0], h->K4[1], h->Np, h->Nc, \
                 h->fixed, h->ppb, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0.p, h->Hpp.p,       \
                 h->bp.p, h->ptab[1 - w].p, h->partB.p
   const dim3 g(h->nblkP), b(PT_THREADS);
@@ -555,11 +600,15 @@ static const double* wy_src(ba_handle* h) { return folded(h) ? h->comm.p : h->pa
 static const double* e_src(ba_handle* h) { return folded(h) ? h->commE.p : h->partE.p; }
 static int wy_parts(ba_handle* h) { return folded(h) ? 1 : NPART; }
 
-static void launch_pcg_setup(ba_handle* h, double lambda, bool schur_diag) {
+// finalize = true: fold the fresh camera-half partials into Hcc | bc inside the same kernel
+static void launch_pcg_setup(ba_handle* h, double lambda, bool schur_diag, bool finalize) {
   Scope sc(h, BA_K_PCG_UPDATE);
-  hipLaunchKernelGGL(k_pcg_setup, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->HccBc.p, bc_ptr(h), wy_src(h), e_src(h),
-                     wy_parts(h), h->cs[h->cur].p, lambda, schur_diag ? 1 : 0, h->Nc, h->fixed, h->Hccd.p, h->Minv.p,
-                     h->gvec.p, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA.p, h->partV.p, h->st.p);
+#define SU_ARGS h->partL[h->lb].p, h->HccBc.p, bc_ptr(h), wy_src(h), e_src(h), wy_parts(h), h->cs[h->cur].p, lambda,        \
+                schur_diag ? 1 : 0, h->Nc, h->fixed, h->Hccd.p, h->Minv.p, h->gvec.p, h->x.p, h->r.p, h->p.p, h->s.p,     \
+                h->z.p, h->camA[h->cur].p, h->partV.p, h->st.p
+  if (finalize) hipLaunchKernelGGL((k_pcg_setup<true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);
+  else          hipLaunchKernelGGL((k_pcg_setup<false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);
+#undef SU_ARGS
 }
 
 // --------------------------------------------------------------------- K1 entry point
@@ -592,8 +641,10 @@ extern "C" int ba_linearize(ba_handle* h, int32_t loss, double f_scale, double* 
   if (loss != BA_LOSS_LINEAR && loss != BA_LOSS_HUBER) return fail(BA_ERR_INVALID, "unknown loss %d", loss);
   if (!(f_scale > 0)) return fail(BA_ERR_INVALID, "f_scale must be positive");
   if (set_device(h)) return BA_ERR_HIP;
-  launch_linearize(h, loss == BA_LOSS_HUBER, f_scale);
+  launch_lin_cam(h, h->cur, h->lb, loss == BA_LOSS_HUBER, f_scale);
+  launch_lin_finalize(h);
   if (int rc = allreduce(h, h->HccBc.p, 27 * (size_t)h->Nc)) return rc;
+  launch_lin_pt(h, loss == BA_LOSS_HUBER, f_scale, 1.0);
   h->linearized = true;
   h->lin_robust = (loss == BA_LOSS_HUBER);
   h->lin_fscale = f_scale;
@@ -606,11 +657,13 @@ extern "C" int ba_linearize(ba_handle* h, int32_t loss, double f_scale, double* 
 }
 
 // --------------------------------------------------------------------- K4 test hooks
-static int damped_system(ba_handle* h, double lambda, bool schur_diag) {
-  launch_point_invert(h, lambda);
+// invert: (re)compute the damped point inverses (not needed right after launch_lin_pt at the
+// same lambda); finalize: Hcc | bc still have to be folded from the camera-half partials
+static int damped_system(ba_handle* h, double lambda, bool schur_diag, bool invert = true, bool finalize = false) {
+  if (invert) launch_point_invert(h, lambda);
   launch_cam_schur(h, h->lin_robust, schur_diag, false, 0, 0.0, 0);
   if (int rc = exchange_schur(h, schur_diag, false)) return rc;
-  launch_pcg_setup(h, lambda, schur_diag);
+  launch_pcg_setup(h, lambda, schur_diag, finalize);
   return BA_OK;
 }
 
@@ -633,7 +686,7 @@ extern "C" int ba_schur_apply(ba_handle* h, double lambda, const double* v, doub
   {
     Scope sc(h, BA_K_MISC);
     hipLaunchKernelGGL(k_vtil, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->vin.p, h->cs[h->cur].p, h->Nc,
-                       h->fixed, h->camA.p);
+                       h->fixed, h->camA[h->cur].p);
     hipLaunchKernelGGL(k_pcg_reset, dim3(1), dim3(64), 0, h->stream, h->st.p, h->partV.p, h->nblkV);
   }
   launch_pt_schur(h, h->lin_robust, 0, 0, -1.0, 1 << 30);        // y = Hppinv W^T v into the point table
@@ -700,7 +753,6 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   const double fs = opts->f_scale;
   const int Nc = h->Nc;
   h->profile = opts->profile != 0;
-  const int check_every = std::max(1, opts->pcg_check_every);
   const double tol2 = opts->pcg_tol * opts->pcg_tol;
 
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -712,88 +764,100 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   sum->initial_cost = cost;
   double lambda = opts->initial_lambda, nu = 2.0;
   int it = 0, status = 0;
-  bool need_linearize = true;
+  bool need_linearize = true;      // point half (and, unless speculated, camera half) to be recomputed
+  bool have_cam_half = false;      // buffers [lb] already hold the camera half at the current parameters
+  h->linearized = false;
 
   while (it < opts->max_iters) {
     double t0 = now_s();
+    bool fresh = false;
     if (need_linearize) {
-      launch_linearize(h, robust, fs);
-      if (int rc = allreduce(h, h->HccBc.p, 27 * (size_t)Nc)) return rc;
-      h->linearized = true; h->lin_robust = robust; h->lin_fscale = fs;
+      if (!have_cam_half) launch_lin_cam(h, h->cur, h->lb, robust, fs);
+      launch_lin_pt(h, robust, fs, lambda);          // also Hpp^-1, y0 at this lambda
+      h->lin_robust = robust; h->lin_fscale = fs;
       need_linearize = false;
-      if (opts->gtol > 0) {
-        {
-          Scope sc(h, BA_K_MISC);
-          hipLaunchKernelGGL(k_absmax, dim3(1), dim3(256), 0, h->stream, bc_ptr(h), 6 * (size_t)Nc, h->scal.p + S_GMAX_C);
-          hipLaunchKernelGGL(k_absmax, dim3(1), dim3(256), 0, h->stream, h->bp.p, 3 * (size_t)h->Np, h->scal.p + S_GMAX_P);
-        }
-        HIPCHECK(hipMemcpyAsync(h->h_scal + S_GMAX_C, h->scal.p + S_GMAX_C, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(hipStreamSynchronize(h->stream));
-        double gmax = std::max(h->h_scal[S_GMAX_C], h->h_scal[S_GMAX_P]);
-        if (h->world > 1) {   // bc is all-reduced (identical on every rank); bp is shard-local -> max over ranks
-          HIPCHECK(hipMemcpyAsync(h->scal.p + 18, &gmax, sizeof(double), hipMemcpyHostToDevice, h->stream));
-          ncclResult_t r = g_rccl.AllReduce(h->scal.p + 18, h->scal.p + 18, 1, ncclDouble, ncclMax, h->nccl, h->stream);
-          if (r != ncclSuccess) return fail(BA_ERR_COMM, "ncclAllReduce(max) failed");
-          HIPCHECK(hipMemcpyAsync(h->h_scal + 18, h->scal.p + 18, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-          HIPCHECK(hipStreamSynchronize(h->stream));
-          gmax = h->h_scal[18];
-        }
-        if (gmax <= opts->gtol) { status = 3; break; }
+      have_cam_half = false;
+      fresh = true;
+      if (folded(h)) {                                // Hcc | bc must be all-reduced before the setup kernel
+        launch_lin_finalize(h);
+        if (int rc = allreduce(h, h->HccBc.p, 27 * (size_t)Nc)) return rc;
       }
     }
     // ---- damped system, right-hand side, preconditioner, first PCG vectors
-    if (int rc = damped_system(h, lambda, schur_diag)) return rc;
+    if (int rc = damped_system(h, lambda, schur_diag, !fresh, fresh && !folded(h))) return rc;
+    if (fresh && opts->gtol > 0) {
+      {
+        Scope sc(h, BA_K_MISC);
+        hipLaunchKernelGGL(k_absmax, dim3(1), dim3(256), 0, h->stream, bc_ptr(h), 6 * (size_t)Nc, h->scal.p + S_GMAX_C);
+        hipLaunchKernelGGL(k_absmax, dim3(1), dim3(256), 0, h->stream, h->bp.p, 3 * (size_t)h->Np, h->scal.p + S_GMAX_P);
+      }
+      HIPCHECK(hipMemcpyAsync(h->h_gmax, h->scal.p + S_GMAX_C, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPCHECK(hipStreamSynchronize(h->stream));
+      double gmax = std::max(h->h_gmax[0], h->h_gmax[1]);
+      if (h->world > 1) {   // bc is all-reduced (identical on every rank); bp is shard-local -> max over ranks
+        HIPCHECK(hipMemcpyAsync(h->scal.p + 18, &gmax, sizeof(double), hipMemcpyHostToDevice, h->stream));
+        ncclResult_t r = g_rccl.AllReduce(h->scal.p + 18, h->scal.p + 18, 1, ncclDouble, ncclMax, h->nccl, h->stream);
+        if (r != ncclSuccess) return fail(BA_ERR_COMM, "ncclAllReduce(max) failed");
+        HIPCHECK(hipMemcpyAsync(h->h_gmax, h->scal.p + 18, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        gmax = h->h_gmax[0];
+      }
+      if (gmax <= opts->gtol) { status = 3; break; }
+    }
     double t1 = now_s();
     sum->seconds_linearize += t1 - t0;
-    // ---- PCG: launch the predicted number of iterations, then speculatively the step /
-    // trial-point kernels, and look at the device state once (one host sync per LM
-    // iteration in the common case); if PCG had not converged, resume it and redo the tail.
+    // ---- PCG.  The vector kernel of iteration k publishes its verdict (go on / converged after
+    // n iterations) in host-mapped memory when it STARTS; the host keeps at most two iterations
+    // in flight: iteration j is launched once the verdict of iteration j-2 says "go on".  The
+    // rule only depends on the (deterministic, rank-identical) verdicts, never on timing.
     int k = 0, pcg_done_iters = -1;
-    auto launch_pcg = [&](int n) -> int {
-      const int kend = std::min(opts->pcg_max_iters, k + n);
-      for (; k < kend; ++k) {
-        launch_pt_schur(h, robust, 0, k, tol2, opts->pcg_min_iters);
-        launch_cam_schur(h, robust, false, true, k, tol2, opts->pcg_min_iters);
-        if (int rc = exchange_schur(h, false, true)) return rc;
-        Scope sc(h, BA_K_PCG_UPDATE);
-        hipLaunchKernelGGL(k_pcg_step, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, k, wy_src(h), wy_parts(h),
-                           (const double*)(h->comm.p + 6 * (size_t)Nc), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc,
-                           h->fixed, tol2, opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA.p,
-                           h->partV.p, h->nblkV, h->st.p);
-      }
+    const long long base = h->flag_base;
+    h->flag_base += opts->pcg_max_iters + 8;
+    auto launch_pcg_iteration = [&]() -> int {
+      launch_pt_schur(h, robust, 0, k, tol2, opts->pcg_min_iters);
+      launch_cam_schur(h, robust, false, true, k, tol2, opts->pcg_min_iters);
+      if (int rc = exchange_schur(h, false, true)) return rc;
+      Scope sc(h, BA_K_PCG_UPDATE);
+      hipLaunchKernelGGL(k_pcg_step, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, k, wy_src(h), wy_parts(h),
+                         (const double*)(h->comm.p + 6 * (size_t)Nc), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc,
+                         h->fixed, tol2, opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA[h->cur].p,
+                         h->partV.p, h->nblkV, h->st.p, h->d_flags, base);
+      ++k;
       return BA_OK;
     };
-    if (int rc = launch_pcg(std::max(1, std::min(h->pcg_pred, opts->pcg_max_iters)))) return rc;
-    double t2 = t1;
-    while (true) {
-      // ---- step, trial point, gain-ratio scalars
-      {
-        Scope sc(h, BA_K_MISC);
-        hipLaunchKernelGGL(k_cam_update, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->cams[h->cur].p, h->x.p, h->r.p,
-                           h->HccBc.p, bc_ptr(h), h->cs[h->cur].p, Nc, h->fixed, h->cams[1 - h->cur].p, h->cs[1 - h->cur].p,
-                           h->camA.p, h->partC.p);
+    while (k < opts->pcg_max_iters) {
+      if (k >= 2) {
+        if (int rc = wait_flag(h, 0, base + (k - 2) + 1)) return rc;     // verdict of iteration k-2 (or later)
+        const long long payload = h->h_flags[1];
+        if (payload > 0) { pcg_done_iters = (int)payload - 1; break; }
       }
-      launch_pt_schur(h, robust, 1, 0, 0.0, 0);
-      launch_residual(h, 1 - h->cur, robust, fs, nullptr);
-      launch_scalars(h, true);
-      if (int rc = allreduce(h, h->scal.p, 6)) return rc;
-      HIPCHECK(hipMemcpyAsync(h->h_scal, h->scal.p, 16 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      HIPCHECK(hipMemcpyAsync(h->h_st, h->st.p, 2 * sizeof(PcgState), hipMemcpyDeviceToHost, h->stream));
-      HIPCHECK(hipStreamSynchronize(h->stream));
-      const PcgState& ps = h->h_st[k & 1];
-      if (ps.done) { pcg_done_iters = ps.iters; break; }
-      if (k >= opts->pcg_max_iters) { pcg_done_iters = k; break; }
-      // not converged yet: camA's vtil half was overwritten by the step -> restore it from z, resume
-      {
-        Scope sc(h, BA_K_MISC);
-        hipLaunchKernelGGL(k_vtil, dim3((Nc + 63) / 64), dim3(64), 0, h->stream, h->z.p, h->cs[h->cur].p, Nc, h->fixed,
-                           h->camA.p);
-      }
-      if (int rc = launch_pcg(check_every)) return rc;
+      if (int rc = launch_pcg_iteration()) return rc;
     }
-    h->pcg_pred = pcg_done_iters + 1;
+    // ---- step, trial point, gain-ratio scalars
+    {
+      Scope sc(h, BA_K_MISC);
+      hipLaunchKernelGGL(k_cam_update, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->cams[h->cur].p, h->x.p, h->r.p,
+                         h->HccBc.p, bc_ptr(h), h->cs[h->cur].p, Nc, h->fixed, h->cams[1 - h->cur].p, h->cs[1 - h->cur].p,
+                         h->camA[h->cur].p, h->camA[1 - h->cur].p, h->partC.p);
+    }
+    launch_pt_schur(h, robust, 1, 0, 0.0, 0);
+    launch_residual(h, 1 - h->cur, robust, fs, nullptr);
+    const long long seq = ++h->step_seq;
+    launch_scalars(h, true, k, tol2, opts->pcg_min_iters, seq);
+    if (h->world > 1) {
+      if (int rc = allreduce(h, h->scal.p, 6)) return rc;
+      HIPCHECK(hipMemcpyAsync(h->h_scal, h->scal.p, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPCHECK(hipEventRecord(h->ev_decide, h->stream));
+    }
+    // speculation: while the host decides, the GPU already computes the camera half of the next
+    // linearisation at the trial point, into the other c_w / partL buffers
+    const bool speculated = (it + 1 < opts->max_iters);
+    if (speculated) launch_lin_cam(h, 1 - h->cur, 1 - h->lb, robust, fs);
+    if (h->world > 1) HIPCHECK(hipEventSynchronize(h->ev_decide));
+    else if (int rc = wait_flag(h, 2, seq)) return rc;
+    if (pcg_done_iters < 0) pcg_done_iters = (h->h_scal[S_PCG_FIN] != 0.0) ? (int)h->h_scal[S_PCG_ITERS] : k;
     sum->pcg_iterations += pcg_done_iters;
-    t2 = now_s();
+    double t2 = now_s();
     sum->seconds_pcg += t2 - t1;
     const double* S = h->h_scal;
     const double sse_new = S[S_SSE], cost_new = 0.5 * S[S_RHO];
@@ -809,13 +873,13 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     if (rho > 0 && std::isfinite(cost_new)) {
       const double dcost = cost - cost_new;
       h->cur = 1 - h->cur;
+      if (speculated) { h->lb = 1 - h->lb; have_cam_half = true; }
       cost = cost_new;
       sse = sse_new;
       sum->accepted++;
       lambda = std::max(lambda * std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)), 1e-12);
       nu = 2.0;
       need_linearize = true;
-      h->linearized = false;
       if (dcost <= opts->ftol * cost) { status = 1; stop = true; }
     } else {
       lambda = std::min(lambda * nu, 1e12);
@@ -845,10 +909,10 @@ extern "C" int ba_time_kernel(ba_handle* h, int slot, int reps, double* mean_us)
   const bool saved = h->profile;
   h->profile = false;
   const bool robust = h->lin_robust;
-  if (!h->linearized) {
-    launch_linearize(h, robust, h->lin_fscale);
-    h->linearized = true;
-  }
+  launch_lin_cam(h, h->cur, h->lb, robust, h->lin_fscale);
+  launch_lin_finalize(h);
+  launch_lin_pt(h, robust, h->lin_fscale, 1e-4);
+  h->linearized = true;
   if (int rc = damped_system(h, 1e-4, true)) return rc;
   hipLaunchKernelGGL(k_pcg_reset, dim3(1), dim3(64), 0, h->stream, h->st.p, h->partV.p, h->nblkV);
   hipEvent_t e0, e1;
@@ -857,8 +921,8 @@ extern "C" int ba_time_kernel(ba_handle* h, int slot, int reps, double* mean_us)
   auto once = [&]() {
     switch (slot) {
       case BA_K_RESIDUAL: launch_residual(h, h->cur, robust, h->lin_fscale, nullptr); break;
-      case BA_K_LINEARIZE_CAM:
-      case BA_K_LINEARIZE_PT: launch_linearize(h, robust, h->lin_fscale); break;
+      case BA_K_LINEARIZE_CAM: launch_lin_cam(h, h->cur, h->lb, robust, h->lin_fscale); break;
+      case BA_K_LINEARIZE_PT: launch_lin_pt(h, robust, h->lin_fscale, 1e-4); break;
       case BA_K_SCHUR_PT: launch_pt_schur(h, robust, 0, 0, -1.0, 1 << 30); break;
       case BA_K_SCHUR_CAM: launch_cam_schur(h, robust, false, false, 0, 0.0, 0); break;
       case BA_K_PRECOND: launch_cam_schur(h, robust, true, false, 0, 0.0, 0); break;

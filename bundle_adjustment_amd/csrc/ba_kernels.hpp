@@ -8,8 +8,8 @@
 //                    offk[c][k] splits them at the NPART point-partition boundaries
 //                    -> c_pt (int32), c_uv, c_w (double2), c_orig (caller's row)
 //   point order:     observations of point p are [pt_off[p], pt_off[p+1]) -> p_cam, p_uv, p_w
-//   cs[2][Nc][24]    per-camera state R t M (camera_state), camA[Nc][18] = R t vtil for the
-//                    point passes (staged in LDS)
+//   cs[2][Nc][24]    per-camera state R t M (camera_state), camA[2][Nc][18] = R t | vtil, the
+//                    packed table the point passes stage in LDS (vtil = camera vector of the pass)
 //
 // Camera passes (k_cam_*): one WAVE per (camera, point partition); the workgroup index is
 // laid out so that blockIdx % NPART is the partition.  Workgroups are dealt round-robin
@@ -43,16 +43,20 @@ struct PcgState {
 
 // scalar slots written by k_scalars (device `scal`)
 enum { S_SSE = 0, S_RHO = 1, S_PT_GD = 2, S_PT_DDD = 3, S_PT_DD = 4, S_PT_XX = 5,
-       S_CAM_GD = 8, S_CAM_DDD = 9, S_DC_R = 10, S_CAM_DD = 11, S_CAM_XX = 12, S_GMAX_C = 16, S_GMAX_P = 17 };
+       S_CAM_GD = 8, S_CAM_DDD = 9, S_DC_R = 10, S_CAM_DD = 11, S_CAM_XX = 12, S_GMAX_C = 16, S_GMAX_P = 17,
+       S_PCG_FIN = 20, S_PCG_ITERS = 21, S_COUNT = 24 };
 
 __device__ inline double rcp_guarded(double z) { return (z != 0.0) ? 1.0 / z : 1.0; }
 
 // -------------------------------------------------------------------------------------
 // small per-camera / per-point kernels
 // -------------------------------------------------------------------------------------
-__global__ void k_cam_prepare(const double* __restrict__ cams, double* __restrict__ cs, int n_cams) {
+__global__ void k_cam_prepare(const double* __restrict__ cams, double* __restrict__ cs, double* __restrict__ camA,
+                              int n_cams) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < n_cams) camera_state(cams + 6 * c, cs + CS * c);
+  if (c >= n_cams) return;
+  camera_state(cams + 6 * c, cs + CS * c);
+  for (int q = 0; q < 12; ++q) camA[TA * c + q] = cs[CS * c + q];
 }
 
 // pts (Np,3) -> X slots of the point table; table (Np,8) -> pts
@@ -197,27 +201,19 @@ __device__ inline void m_congruence(const double* __restrict__ M, double (&A)[6]
 }
 
 // Combine the NPART partial sums of k_cam_linearize (fixed order), apply M:
-//   Hcc[c] (21) = Jc^T w Jc,  bc[c] (6) = Jc^T w r  (zero for the fixed camera);
-// also refresh the R|t half of camA for the point passes.
-__global__ void __launch_bounds__(VEC_BLOCK)
-k_lin_finalize(const double* __restrict__ partL, const double* __restrict__ cs, int n_cams, int fixed_cam,
-               double* __restrict__ Hcc, double* __restrict__ bc, double* __restrict__ camA) {
-  const int c = blockIdx.x * VEC_BLOCK + threadIdx.x;
-  if (c >= n_cams) return;
-  const double* cam = cs + CS * c;
-  for (int q = 0; q < 12; ++q) camA[TA * c + q] = cam[q];
+//   Hcc[c] (21) = Jc^T w Jc,  bc[c] (6) = Jc^T w r  (zero for the fixed camera).
+__device__ inline void lin_finalize_camera(const double* __restrict__ partL, const double* __restrict__ cam, int n_cams,
+                                           int c, int fixed_cam, double* __restrict__ H, double* __restrict__ b) {
+  if (c == fixed_cam) {
+    for (int q = 0; q < 21; ++q) H[q] = 0.0;
+    for (int q = 0; q < 6; ++q) b[q] = 0.0;
+    return;
+  }
   double a[27];
   for (int q = 0; q < 27; ++q) a[q] = 0.0;
   for (int k = 0; k < NPART; ++k) {
     const double* src = partL + ((size_t)k * n_cams + c) * 27;
     for (int q = 0; q < 27; ++q) a[q] += src[q];
-  }
-  double* H = Hcc + 21 * c;
-  double* b = bc + 6 * c;
-  if (c == fixed_cam) {
-    for (int q = 0; q < 21; ++q) H[q] = 0.0;
-    for (int q = 0; q < 6; ++q) b[q] = 0.0;
-    return;
   }
   const double* M = cam + 12;
   double A[6][6];
@@ -229,11 +225,27 @@ k_lin_finalize(const double* __restrict__ partL, const double* __restrict__ cs, 
   b[2] = M[2] * a[21] + M[5] * a[22] + M[8] * a[23];
   b[3] = a[24]; b[4] = a[25]; b[5] = a[26];
 }
+// stand-alone form (multi-rank jobs all-reduce Hcc|bc between this and k_pcg_setup; test hook)
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_lin_finalize(const double* __restrict__ partL, const double* __restrict__ cs, int n_cams, int fixed_cam,
+               double* __restrict__ Hcc, double* __restrict__ bc) {
+  const int c = blockIdx.x * VEC_BLOCK + threadIdx.x;
+  if (c >= n_cams) return;
+  lin_finalize_camera(partL, cs + CS * c, n_cams, c, fixed_cam, Hcc + 21 * c, bc + 6 * c);
+}
 
 // K4b: camera pass of the Schur product, pre-M:  part6[(k*Nc + c)*6 + ..] = sum Jc^T w (Jp y_p)
 // with y read from the point table.  DIAG additionally accumulates the pre-M Schur-Jacobi
 // block sum_o W_o Hppinv_p W_o^T (21 values) into partE -- used once per damping change,
 // together with the right-hand side pass (y = y0).  PCG = true: early exit once converged.
+// Host-visible progress word (host-mapped, coherent memory): payload first, then the
+// sequence number with a system-scope release; the host spins on the sequence number.
+__device__ inline void publish_flag(long long* __restrict__ host_flag, long long seq, long long payload) {
+  if (!host_flag) return;
+  __hip_atomic_store(host_flag + 1, payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ inline bool pcg_finished(int k, const PcgState* __restrict__ st, const double* __restrict__ partV,
                                     int nblkV, double tol2, int min_iters, double& gamma, double& zeta) {
   const PcgState& s = st[k & 1];
@@ -377,6 +389,7 @@ k_fold_partials(const double* __restrict__ part6, const double* __restrict__ par
 // -------------------------------------------------------------------------------------
 // point passes: LPP lanes per point, camera table (camA) in LDS when it fits
 // -------------------------------------------------------------------------------------
+// row c of the packed camera table camA = R[9] t[3] | vtil[6]; ROWLEN 12 reads R|t only
 template <bool LDS_TAB, int ROWLEN>
 __device__ inline void load_cam_row(const double* __restrict__ tab, const double* __restrict__ camA, int c,
                                     double (&row)[ROWLEN]) {
@@ -412,10 +425,11 @@ __device__ inline void block_combine(double (&v)[N], double* __restrict__ sm) {
 // IRLS weights of point-ordered observations (p_w) when ROBUST.
 template <bool ROBUST, bool LDS_TAB>
 __global__ void __launch_bounds__(PT_THREADS)
-k_pt_linearize(const double* __restrict__ camA, const double* __restrict__ ptab, const int* __restrict__ pt_off,
+k_pt_linearize(const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,
                const int* __restrict__ p_cam, const double2* __restrict__ p_uv,
                double fx, double fy, double cx, double cy, double hub_c, int n_pts, int n_cams, int pts_per_block,
-               double* __restrict__ Hpp, double* __restrict__ bp, double2* __restrict__ p_w) {
+               double lambda, double* __restrict__ Hpp, double* __restrict__ bp, double2* __restrict__ p_w,
+               double* __restrict__ Hppinv, double* __restrict__ y0) {
   extern __shared__ double tab[];
   if (LDS_TAB) fill_cam_table<PT_THREADS>(tab, camA, n_cams);
   const int sub = threadIdx.x % LPP;
@@ -465,6 +479,18 @@ k_pt_linearize(const double* __restrict__ camA, const double* __restrict__ ptab,
       for (int q = 0; q < 6; ++q) Hpp[6 * (size_t)p + q] = a[q];
 #pragma unroll
       for (int q = 0; q < 3; ++q) bp[3 * (size_t)p + q] = a[6 + q];
+      // K3 fused: damped inverse and y0 at the damping this linearisation starts with
+      double h[6] = {a[0], a[1], a[2], a[3], a[4], a[5]}, inv[6], y[3];
+      h[0] += lambda * fmax(h[0], DIAG_FLOOR);
+      h[3] += lambda * fmax(h[3], DIAG_FLOOR);
+      h[5] += lambda * fmax(h[5], DIAG_FLOOR);
+      sym3_inverse(h, inv);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) Hppinv[6 * (size_t)p + q] = inv[q];
+      sym3_mul(inv, a + 6, y);
+      y0[3 * (size_t)p] = y[0]; y0[3 * (size_t)p + 1] = y[1]; y0[3 * (size_t)p + 2] = y[2];
+      double* o = ptab + PT * (size_t)p + 4;
+      o[0] = y[0]; o[1] = y[1]; o[2] = y[2];
     }
   }
 }
@@ -598,21 +624,24 @@ __device__ inline void write_vtil(const double* __restrict__ M, const double (&v
 
 // PCG setup at damping lambda: Hccd = Hcc + lam Dc (fixed camera: identity), Schur-Jacobi
 // or Jacobi preconditioner Minv = (Hccd - E)^-1, right-hand side g = -(bc - W y0), and the
+// (FINALIZE: first folds the fresh linearisation partials into Hcc | bc, single rank)
 // first PCG vectors: x = 0, r = g, z = Minv r, p = s = 0, vtil, gamma/zeta partials.
 // E / Wy0 come either as NPART partial sums (nparts = NPART) or already folded and
 // all-reduced (nparts = 1).
+template <bool FINALIZE>
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_pcg_setup(const double* __restrict__ Hcc, const double* __restrict__ bc, const double* __restrict__ part6,
+k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* __restrict__ bc, const double* __restrict__ part6,
             const double* __restrict__ partE, int nparts, const double* __restrict__ cs, double lambda,
             int use_schur_diag, int n_cams, int fixed_cam, double* __restrict__ Hccd, double* __restrict__ Minv,
             double* __restrict__ gvec, double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
-            double* __restrict__ s, double* __restrict__ z, double* __restrict__ camA,
+            double* __restrict__ s, double* __restrict__ z, double* __restrict__ vtil,
             double* __restrict__ partV, PcgState* __restrict__ st) {
   __shared__ double sm[2];
   const int c = blockIdx.x * VEC_BLOCK + threadIdx.x;
   double acc[2] = {0, 0};
   if (c < n_cams) {
     const double* M = cs + CS * c + 12;
+    if (FINALIZE) lin_finalize_camera(partL, cs + CS * c, n_cams, c, fixed_cam, Hcc + 21 * c, bc + 6 * c);
     double h[21], m[21], inv[21];
     for (int q = 0; q < 21; ++q) h[q] = Hcc[21 * c + q];
     if (c == fixed_cam) {
@@ -647,7 +676,7 @@ k_pcg_setup(const double* __restrict__ Hcc, const double* __restrict__ bc, const
       acc[0] += g[q] * zz[q];
       acc[1] += zz[q] * hz[q];
     }
-    write_vtil(M, zz, camA + TA * c + 12);
+    write_vtil(M, zz, vtil + TA * c + 12);
   }
 #pragma unroll
   for (int q = 0; q < 2; ++q) acc[q] = wave_total_dpp(acc[q]);
@@ -676,8 +705,8 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
            const double* __restrict__ Hccd, const double* __restrict__ Minv, const double* __restrict__ cs,
            int n_cams, int fixed_cam, double tol2, int min_iters,
            double* __restrict__ x, double* __restrict__ r, double* __restrict__ p, double* __restrict__ s,
-           double* __restrict__ z, double* __restrict__ camA, double* __restrict__ partV, int nblkV,
-           PcgState* __restrict__ st) {
+           double* __restrict__ z, double* __restrict__ vtil, double* __restrict__ partV, int nblkV,
+           PcgState* __restrict__ st, long long* __restrict__ host_flag, long long flag_base) {
   double gamma, zeta;
   const bool fin = pcg_finished(k, st, partV, nblkV, tol2, min_iters, gamma, zeta);
   const PcgState sin = st[k & 1];
@@ -687,6 +716,7 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
       PcgState o = sin;
       if (!o.done) { o.done = 1; o.iters = k; if (k == 0) o.gamma0 = gamma; }
       *sout = o;
+      publish_flag(host_flag, flag_base + k + 1, o.iters + 1);
     }
     return;
   }
@@ -699,9 +729,11 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
       PcgState o = sin;
       o.done = 2; o.iters = k; if (k == 0) o.gamma0 = gamma;
       *sout = o;
+      publish_flag(host_flag, flag_base + k + 1, k + 1);
     }
     return;
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) publish_flag(host_flag, flag_base + k + 1, 0);   // verdict: keep going
   const double alpha = gamma / denom;
   const int c = blockIdx.x * VEC_BLOCK + threadIdx.x;
   double acc[2] = {0, 0};
@@ -727,7 +759,7 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
       acc[0] += rr[q] * zz[q];
       acc[1] += zz[q] * hz[q];
     }
-    write_vtil(M, zz, camA + TA * c + 12);
+    write_vtil(M, zz, vtil + TA * c + 12);
   }
 #pragma unroll
   for (int q = 0; q < 2; ++q) acc[q] = wave_total_dpp(acc[q]);
@@ -752,7 +784,7 @@ __global__ void __launch_bounds__(VEC_BLOCK)
 k_cam_update(const double* __restrict__ cams, const double* __restrict__ dc, const double* __restrict__ rpcg,
              const double* __restrict__ Hcc, const double* __restrict__ bc, const double* __restrict__ cs,
              int n_cams, int fixed_cam, double* __restrict__ cams_trial, double* __restrict__ cs_trial,
-             double* __restrict__ camA, double* __restrict__ partC) {
+             double* __restrict__ vtil, double* __restrict__ camA_trial, double* __restrict__ partC) {
   const int c = blockIdx.x * VEC_BLOCK + threadIdx.x;
   double acc[5] = {0, 0, 0, 0, 0};
   if (c < n_cams) {
@@ -767,8 +799,9 @@ k_cam_update(const double* __restrict__ cams, const double* __restrict__ dc, con
       acc[3] += d[q] * d[q];
       acc[4] += xq * xq;
     }
-    write_vtil(cs + CS * c + 12, d, camA + TA * c + 12);
+    write_vtil(cs + CS * c + 12, d, vtil + TA * c + 12);
     camera_state(cams_trial + 6 * c, cs_trial + CS * c);
+    for (int q = 0; q < 12; ++q) camA_trial[TA * c + q] = cs_trial[CS * c + q];
   }
 #pragma unroll
   for (int q = 0; q < 5; ++q) acc[q] = wave_total_dpp(acc[q]);
@@ -777,10 +810,14 @@ k_cam_update(const double* __restrict__ cams, const double* __restrict__ dc, con
 
 // One workgroup folds every partial-sum array of an LM step into the scalar block `scal`
 // (fixed order): residual partials (nR rows x 2), point partials (nB x 4, may be 0 rows),
-// camera partials (nC x 5, may be 0 rows).
+// camera partials (nC x 5, may be 0 rows); with st != null also the PCG verdict for
+// iteration `kit` (the test pcg_finished makes).  scal_host (nullable) is a host-mapped
+// mirror written in the same kernel, so the host needs no copy, only the stream sync.
 __global__ void __launch_bounds__(1024)
 k_scalars(const double* __restrict__ partR, int nR, const double* __restrict__ partB, int nB,
-          const double* __restrict__ partC, int nC, double* __restrict__ scal) {
+          const double* __restrict__ partC, int nC, int kit, const PcgState* __restrict__ st,
+          const double* __restrict__ partV, int nblkV, double tol2, int min_iters,
+          double* __restrict__ scal, double* __restrict__ scal_host, long long* __restrict__ host_flag, long long seq) {
   __shared__ double sm[11 * 16];
   double a[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = threadIdx.x; i < nR; i += 1024) { const double2 t = ((const double2*)partR)[i]; a[0] += t.x; a[1] += t.y; }
@@ -805,6 +842,20 @@ k_scalars(const double* __restrict__ partR, int nR, const double* __restrict__ p
     for (int w = 0; w < 16; ++w) t += sm[w * 11 + threadIdx.x];
     const int slot = threadIdx.x < 2 ? S_SSE + threadIdx.x : (threadIdx.x < 6 ? S_PT_GD + (threadIdx.x - 2) : S_CAM_GD + (threadIdx.x - 6));
     scal[slot] = t;
+    if (scal_host) scal_host[slot] = t;
+  }
+  if (threadIdx.x == 64 && st) {
+    double g, z;
+    const bool fin = pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z);
+    const PcgState& s = st[kit & 1];
+    const double iters = s.done ? (double)s.iters : (double)kit;
+    scal[S_PCG_FIN] = fin ? 1.0 : 0.0; scal[S_PCG_ITERS] = iters;
+    if (scal_host) { scal_host[S_PCG_FIN] = fin ? 1.0 : 0.0; scal_host[S_PCG_ITERS] = iters; }
+  }
+  if (host_flag) {                 // every scalar is out: publish the step's sequence number
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) publish_flag(host_flag, seq, 0);
   }
 }
 
@@ -844,12 +895,12 @@ __global__ void k_schur_combine(const double* __restrict__ Hccd, const double* _
 
 // vtil half of camA for an arbitrary camera vector (test hook)
 __global__ void k_vtil(const double* __restrict__ v, const double* __restrict__ cs, int n_cams, int fixed_cam,
-                       double* __restrict__ camA) {
+                       double* __restrict__ vtil) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cams) return;
   double d[6];
   for (int q = 0; q < 6; ++q) d[q] = (c == fixed_cam) ? 0.0 : v[6 * c + q];
-  write_vtil(cs + CS * c + 12, d, camA + TA * c + 12);
+  write_vtil(cs + CS * c + 12, d, vtil + TA * c + 12);
 }
 
 }  // namespace ba
