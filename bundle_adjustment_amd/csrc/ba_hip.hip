@@ -12,6 +12,9 @@
 //     K7a camera update, K6 back substitution, K1 cost at the trial point  [all-reduce]
 //     gain ratio -> accept (swap buffers) / reject (raise lambda)
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -143,6 +146,9 @@ struct ba_handle {
   int rank = 0, world = 1;
   bool force_fold = false;     // BA_DEBUG_FOLD=1: run the multi-rank kernel sequence (fold, folded consumers) on one rank
   ncclComm_t nccl = nullptr;
+  // host-staged shared-memory transport (BA_COMM=shm): a test vehicle that lets several ranks
+  // share ONE GPU (RCCL refuses that), so the multi-rank control flow can be exercised end to end
+  struct ShmComm* shm = nullptr;
   // profiling
   bool profile = false;
   std::vector<hipEvent_t> ev;
@@ -198,12 +204,15 @@ extern "C" int ba_create(int device_id, ba_handle** out) {
 }
 
 static void flush_profile(ba_handle* h);
+static void shm_destroy(ba_handle* h);
+static int shm_init(ba_handle* h, int rank, int world, const void* id128);
 
 extern "C" int ba_destroy(ba_handle* h) {
   if (!h) return BA_OK;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   if (h->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(h->nccl);
+  shm_destroy(h);
   for (auto e : h->ev) (void)hipEventDestroy(e);
   if (h->ev_decide) (void)hipEventDestroy(h->ev_decide);
   DBuf<int>* ib[] = {&h->offk, &h->c_pt, &h->c_orig, &h->pt_off, &h->p_cam};
@@ -236,8 +245,15 @@ extern "C" int ba_synchronize(ba_handle* h) {
 // ------------------------------------------------------------------------------ comm
 extern "C" int ba_comm_unique_id(void* id128) {
   if (!id128) return fail(BA_ERR_INVALID, "null id buffer");
-  if (int rc = load_rccl()) return rc;
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  { const char* e = getenv("BA_COMM");
+    if (e && strcmp(e, "shm") == 0) {               // any 128 unique bytes will do
+      unsigned long long seed = (unsigned long long)getpid() * 2654435761ULL ^ (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+      unsigned char* o = (unsigned char*)id128;
+      for (int i = 0; i < 128; ++i) { seed = seed * 6364136223846793005ULL + 1442695040888963407ULL; o[i] = (unsigned char)(seed >> 33); }
+      return BA_OK;
+    } }
+  if (int rc = load_rccl()) return rc;
   ncclUniqueId id;
   ncclResult_t r = g_rccl.GetUniqueId(&id);
   if (r != ncclSuccess) return fail(BA_ERR_COMM, "ncclGetUniqueId: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
@@ -252,8 +268,9 @@ extern "C" int ba_comm_init(ba_handle* h, int rank, int world, const void* id128
   h->world = world;
   if (world == 1) return BA_OK;
   if (!id128) return fail(BA_ERR_INVALID, "null id buffer");
-  if (int rc = load_rccl()) return rc;
   if (set_device(h)) return BA_ERR_HIP;
+  { const char* e = getenv("BA_COMM"); if (e && strcmp(e, "shm") == 0) return shm_init(h, rank, world, id128); }
+  if (int rc = load_rccl()) return rc;
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   ncclResult_t r = g_rccl.CommInitRank(&h->nccl, world, id, rank);
@@ -311,10 +328,90 @@ extern "C" int ba_reset_profile(ba_handle* h) {
   return BA_OK;
 }
 
-static int allreduce(ba_handle* h, double* buf, size_t count) {
+// ------------------------------------------------------------- shared-memory transport
+// Same semantics as the RCCL path (in-place sum / max all-reduce of doubles, identical bits
+// on every rank), implemented with a POSIX shared-memory segment and host staging.  Slow by
+// design; selected with BA_COMM=shm.  Never used unless asked for.
+struct ShmComm {
+  static constexpr size_t SLOT = 8u << 20;         // bytes per rank
+  int rank = 0, world = 1;
+  char name[64] = {0};
+  unsigned char* base = nullptr;
+  size_t bytes = 0;
+  double* stage = nullptr;                          // pinned
+  unsigned gen = 0;
+  std::atomic<unsigned>* counter() { return reinterpret_cast<std::atomic<unsigned>*>(base); }
+  std::atomic<unsigned>* sense() { return reinterpret_cast<std::atomic<unsigned>*>(base + 64); }
+  double* slot(int r) { return reinterpret_cast<double*>(base + 4096 + (size_t)r * SLOT); }
+  int barrier() {
+    const unsigned my = ++gen;
+    if (counter()->fetch_add(1, std::memory_order_acq_rel) + 1 == (unsigned)world) {
+      counter()->store(0, std::memory_order_relaxed);
+      sense()->store(my, std::memory_order_release);
+    } else {
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (sense()->load(std::memory_order_acquire) < my) {
+        if ((++spins & 0xffff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0)
+          return -1;
+      }
+    }
+    return 0;
+  }
+};
+
+static int shm_init(ba_handle* h, int rank, int world, const void* id128) {
+  ShmComm* c = new ShmComm();
+  c->rank = rank; c->world = world;
+  const unsigned char* id = (const unsigned char*)id128;
+  unsigned long long tag = 1469598103934665603ULL;
+  for (int i = 0; i < 128; ++i) tag = (tag ^ id[i]) * 1099511628211ULL;
+  snprintf(c->name, sizeof c->name, "/ba_hip_%016llx", tag);
+  c->bytes = 4096 + (size_t)world * ShmComm::SLOT;
+  int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
+  if (fd < 0) { delete c; return fail(BA_ERR_COMM, "shm_open(%s) failed", c->name); }
+  if (ftruncate(fd, (off_t)c->bytes) != 0) { close(fd); delete c; return fail(BA_ERR_COMM, "ftruncate failed"); }
+  c->base = (unsigned char*)mmap(nullptr, c->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (c->base == MAP_FAILED) { delete c; return fail(BA_ERR_COMM, "mmap failed"); }
+  if (hipHostMalloc((void**)&c->stage, ShmComm::SLOT) != hipSuccess) { delete c; return fail(BA_ERR_HIP, "hipHostMalloc failed"); }
+  h->shm = c;
+  if (c->barrier()) return fail(BA_ERR_COMM, "shm barrier timed out at init");
+  return BA_OK;
+}
+static void shm_destroy(ba_handle* h) {
+  if (!h->shm) return;
+  ShmComm* c = h->shm;
+  (void)c->barrier();
+  if (c->stage) (void)hipHostFree(c->stage);
+  if (c->base) munmap(c->base, c->bytes);
+  if (c->rank == 0) shm_unlink(c->name);
+  delete c;
+  h->shm = nullptr;
+}
+static int shm_allreduce(ba_handle* h, double* buf, size_t count, bool is_max) {
+  ShmComm* c = h->shm;
+  if (count * sizeof(double) > ShmComm::SLOT) return fail(BA_ERR_COMM, "shm all-reduce of %zu doubles exceeds the slot", count);
+  HIPCHECK(hipMemcpyAsync(c->stage, buf, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  memcpy(c->slot(c->rank), c->stage, count * sizeof(double));
+  if (c->barrier()) return fail(BA_ERR_COMM, "shm barrier timed out");
+  for (size_t i = 0; i < count; ++i) {            // rank order: identical bits on every rank
+    double a = c->slot(0)[i];
+    for (int r = 1; r < c->world; ++r) a = is_max ? std::max(a, c->slot(r)[i]) : a + c->slot(r)[i];
+    c->stage[i] = a;
+  }
+  if (c->barrier()) return fail(BA_ERR_COMM, "shm barrier timed out");
+  HIPCHECK(hipMemcpyAsync(buf, c->stage, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));      // the staging buffer is reused by the next call
+  return BA_OK;
+}
+
+static int allreduce(ba_handle* h, double* buf, size_t count, bool is_max = false) {
   if (h->world == 1) return BA_OK;
   Scope sc(h, BA_K_ALLREDUCE);
-  ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclDouble, ncclSum, h->nccl, h->stream);
+  if (h->shm) return shm_allreduce(h, buf, count, is_max);
+  ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclDouble, is_max ? ncclMax : ncclSum, h->nccl, h->stream);
   if (r != ncclSuccess) return fail(BA_ERR_COMM, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
   return BA_OK;
 }
@@ -430,6 +527,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
 
 static double* bc_ptr(ba_handle* h) { return h->HccBc.p + 21 * (size_t)h->Nc; }
 static int cam_grid(ba_handle* h) { return ((h->Nc + WPB - 1) / WPB) * NPART; }
+static int row_grid(ba_handle* h) { return ((h->Nc + ROWS - 1) / ROWS) * NPART; }
 
 extern "C" int ba_set_params(ba_handle* h, const double* cams, const double* pts) {
   if (!h || !cams || (!pts && h->Np > 0)) return fail(BA_ERR_INVALID, "null argument");
@@ -507,8 +605,8 @@ static int wait_flag(ba_handle* h, int idx, long long target) {
 // camera half of the linearisation at parameter set `which`, into buffer set `buf`
 static void launch_lin_cam(ba_handle* h, int which, int buf, bool robust, double fscale) {
   Scope sc(h, BA_K_LINEARIZE_CAM);
-  auto kern = robust ? k_cam_linearize<true> : k_cam_linearize<false>;
-  hipLaunchKernelGGL(kern, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[which].p, h->ptab[which].p, h->offk.p,
+  auto kern = robust ? k_camrow_linearize<true> : k_camrow_linearize<false>;
+  hipLaunchKernelGGL(kern, dim3(row_grid(h)), dim3(16 * ROWS), 0, h->stream, h->cs[which].p, h->ptab[which].p, h->offk.p,
                      h->c_pt.p, h->c_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, h->c_w[buf].p,
                      h->partL[buf].p);
 }
@@ -550,8 +648,9 @@ static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int
                 (h->Np > 0 ? h->nblkP : 0), h->comm.p + 6 * (size_t)h->Nc
   const dim3 g(cam_grid(h) + (pcg ? 1 : 0)), b(64 * WPB);
   if (diag) {
-    if (robust) hipLaunchKernelGGL((k_cam_schur<true, true, false>), g, b, 0, h->stream, CS_ARGS);
-    else        hipLaunchKernelGGL((k_cam_schur<false, true, false>), g, b, 0, h->stream, CS_ARGS);
+    auto kern = robust ? k_camrow_schur_diag<true> : k_camrow_schur_diag<false>;
+    hipLaunchKernelGGL(kern, dim3(row_grid(h)), dim3(16 * ROWS), 0, h->stream, h->cs[w].p, h->ptab[w].p, h->offk.p,
+                       h->c_pt.p, h->c_w[h->lb].p, h->Hppinv.p, h->K4[0], h->K4[1], h->Nc, h->fixed, h->part6.p, h->partE.p);
   } else if (pcg) {
     if (robust) hipLaunchKernelGGL((k_cam_schur<true, false, true>), g, b, 0, h->stream, CS_ARGS);
     else        hipLaunchKernelGGL((k_cam_schur<false, false, true>), g, b, 0, h->stream, CS_ARGS);
@@ -796,8 +895,7 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       double gmax = std::max(h->h_gmax[0], h->h_gmax[1]);
       if (h->world > 1) {   // bc is all-reduced (identical on every rank); bp is shard-local -> max over ranks
         HIPCHECK(hipMemcpyAsync(h->scal.p + 18, &gmax, sizeof(double), hipMemcpyHostToDevice, h->stream));
-        ncclResult_t r = g_rccl.AllReduce(h->scal.p + 18, h->scal.p + 18, 1, ncclDouble, ncclMax, h->nccl, h->stream);
-        if (r != ncclSuccess) return fail(BA_ERR_COMM, "ncclAllReduce(max) failed");
+        if (int rc = allreduce(h, h->scal.p + 18, 1, true)) return rc;
         HIPCHECK(hipMemcpyAsync(h->h_gmax, h->scal.p + 18, sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(hipStreamSynchronize(h->stream));
         gmax = h->h_gmax[0];

@@ -346,6 +346,157 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
   }
 }
 
+// ---- 27-sum camera passes, one 16-lane DPP row per (camera, partition) segment ------------
+// With 27 running sums the 64-lane reduction of the wave-per-segment mapping costs as much as
+// the arithmetic of a ~125-observation segment; a row walks the segment in 8 steps and only
+// needs the 4 in-row shifts.  Workgroup = 16 consecutive cameras of one partition.
+constexpr int ROWS = 16;     // rows (= cameras) per 256-thread workgroup
+struct RowSeg { int c, k, beg, end, l16; bool live; };
+__device__ inline void row_segment(const int* __restrict__ offk, int n_cams, RowSeg& s) {
+  s.k = blockIdx.x % NPART;
+  s.c = (int)(blockIdx.x / NPART) * ROWS + (int)(threadIdx.x >> 4);
+  s.l16 = threadIdx.x & 15;
+  s.live = s.c < n_cams;
+  s.beg = s.live ? offk[s.c * (NPART + 1) + s.k] : 0;
+  s.end = s.live ? offk[s.c * (NPART + 1) + s.k + 1] : 0;
+}
+__device__ inline double row_sum_dpp(double x) {     // lane 15 of every row ends with the row total
+  x += dpp_f64<DPP_ROW_SHR1, 0xf>(x);
+  x += dpp_f64<DPP_ROW_SHR2, 0xf>(x);
+  x += dpp_f64<DPP_ROW_SHR4, 0xf>(x);
+  x += dpp_f64<DPP_ROW_SHR8, 0xf>(x);
+  return x;
+}
+__device__ inline void load_cam12(const double* __restrict__ cs, int c, double (&cam)[12]) {
+  const double2* cp = (const double2*)(cs + CS * (size_t)c);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) { const double2 t = cp[q]; cam[2 * q] = t.x; cam[2 * q + 1] = t.y; }
+}
+
+// K2a (row form): same outputs as k_cam_linearize
+template <bool ROBUST>
+__global__ void __launch_bounds__(16 * ROWS)
+k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
+                   const int* __restrict__ c_pt, const double2* __restrict__ c_uv,
+                   double fx, double fy, double cx, double cy, double hub_c, int n_cams,
+                   double2* __restrict__ c_w, double* __restrict__ partL) {
+  RowSeg s;
+  row_segment(offk, n_cams, s);
+  double acc[27];
+#pragma unroll
+  for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+  if (s.live) {
+    double cam[12];
+    load_cam12(cs, s.c, cam);
+    int i = s.beg + s.l16;
+    int p = (i < s.end) ? c_pt[i] : 0;
+    double2 uv = (i < s.end) ? c_uv[i] : make_double2(0, 0);
+    while (i < s.end) {
+      const int in = i + 16;
+      const int pn = (in < s.end) ? c_pt[in] : 0;
+      const double2 uvn = (in < s.end) ? c_uv[in] : make_double2(0, 0);
+      const double4 X = *(const double4*)(ptab + PT * (size_t)p);
+      Geom g;
+      obs_geom(cam, X.x, X.y, X.z, fx, fy, g);
+      const double ru = uv.x - (g.xh * fx + cx);
+      const double rv = uv.y - (g.yh * fy + cy);
+      double w0 = 1.0, w1 = 1.0;
+      if (ROBUST) {
+        double t;
+        huber(ru, hub_c, t, w0);
+        huber(rv, hub_c, t, w1);
+        c_w[i] = make_double2(w0, w1);
+      }
+      double J0[6], J1[6];
+      cam_jac_rows(g, X.x, X.y, X.z, J0, J1);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const double wa0 = w0 * J0[a], wa1 = w1 * J1[a];
+#pragma unroll
+        for (int b = a; b < 6; ++b) acc[U6(a, b)] += wa0 * J0[b] + wa1 * J1[b];
+        acc[21 + a] += wa0 * ru + wa1 * rv;
+      }
+      i = in; p = pn; uv = uvn;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 27; ++q) acc[q] = row_sum_dpp(acc[q]);
+  if (s.live && s.l16 == 15) {
+    double* o = partL + ((size_t)s.k * n_cams + s.c) * 27;
+#pragma unroll
+    for (int q = 0; q < 27; ++q) o[q] = acc[q];
+  }
+}
+
+// right-hand side + Schur-Jacobi blocks (row form of k_cam_schur<.., DIAG = true, PCG = false>)
+template <bool ROBUST>
+__global__ void __launch_bounds__(16 * ROWS)
+k_camrow_schur_diag(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
+                    const int* __restrict__ c_pt, const double2* __restrict__ c_w, const double* __restrict__ Hppinv,
+                    double fx, double fy, int n_cams, int fixed_cam, double* __restrict__ part6, double* __restrict__ partE) {
+  RowSeg s;
+  row_segment(offk, n_cams, s);
+  double acc[27];
+#pragma unroll
+  for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+  if (s.live && s.c != fixed_cam) {
+    double cam[12];
+    load_cam12(cs, s.c, cam);
+    int i = s.beg + s.l16;
+    int p = (i < s.end) ? c_pt[i] : 0;
+    double2 w = make_double2(1.0, 1.0);
+    if (ROBUST && i < s.end) w = c_w[i];
+    while (i < s.end) {
+      const int in = i + 16;
+      const int pn = (in < s.end) ? c_pt[in] : 0;
+      double2 wn = make_double2(1.0, 1.0);
+      if (ROBUST && in < s.end) wn = c_w[in];
+      const double4 X = *(const double4*)(ptab + PT * (size_t)p);
+      const double4 Y = *(const double4*)(ptab + PT * (size_t)p + 4);
+      Geom g;
+      obs_geom(cam, X.x, X.y, X.z, fx, fy, g);
+      const double s0 = -(g.P[0] * Y.x + g.P[1] * Y.y + g.P[2] * Y.z) * w.x;
+      const double s1 = -(g.P[3] * Y.x + g.P[4] * Y.y + g.P[5] * Y.z) * w.y;
+      const double e0 = g.P[0] * s0 + g.P[3] * s1, e1 = g.P[1] * s0 + g.P[4] * s1, e2 = g.P[2] * s0 + g.P[5] * s1;
+      acc[0] += e1 * X.z - e2 * X.y;
+      acc[1] += e2 * X.x - e0 * X.z;
+      acc[2] += e0 * X.y - e1 * X.x;
+      acc[3] -= g.d00 * s0;
+      acc[4] -= g.d11 * s1;
+      acc[5] -= g.d02 * s0 + g.d12 * s1;
+      double hi[6];
+      const double2* hp = (const double2*)(Hppinv + 6 * (size_t)p);
+      const double2 h01 = hp[0], h23 = hp[1], h45 = hp[2];
+      hi[0] = h01.x; hi[1] = h01.y; hi[2] = h23.x; hi[3] = h23.y; hi[4] = h45.x; hi[5] = h45.y;
+      double t0[3], t1[3];
+      sym3_mul(hi, g.P, t0);
+      sym3_mul(hi, g.P + 3, t1);
+      const double G00 = w.x * w.x * (g.P[0] * t0[0] + g.P[1] * t0[1] + g.P[2] * t0[2]);
+      const double G01 = w.x * w.y * (g.P[0] * t1[0] + g.P[1] * t1[1] + g.P[2] * t1[2]);
+      const double G11 = w.y * w.y * (g.P[3] * t1[0] + g.P[4] * t1[1] + g.P[5] * t1[2]);
+      double J0[6], J1[6];
+      cam_jac_rows(g, X.x, X.y, X.z, J0, J1);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const double l0 = J0[a] * G00 + J1[a] * G01, l1 = J0[a] * G01 + J1[a] * G11;
+#pragma unroll
+        for (int b = a; b < 6; ++b) acc[6 + U6(a, b)] += l0 * J0[b] + l1 * J1[b];
+      }
+      i = in; p = pn; w = wn;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 27; ++q) acc[q] = row_sum_dpp(acc[q]);
+  if (s.live && s.l16 == 15) {
+    double* o6 = part6 + ((size_t)s.k * n_cams + s.c) * 6;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) o6[q] = acc[q];
+    double* oe = partE + ((size_t)s.k * n_cams + s.c) * 21;
+#pragma unroll
+    for (int q = 0; q < 21; ++q) oe[q] = acc[6 + q];
+  }
+}
+
 // Wy[c] = [M^T a ; b] from the NPART partial sums (fixed order)
 __device__ inline void combine_wy(const double* __restrict__ part6, int nparts, int n_cams, int c,
                                   const double* __restrict__ M, double (&wy)[6]) {
