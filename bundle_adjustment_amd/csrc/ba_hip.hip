@@ -905,8 +905,8 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     double t1 = now_s();
     sum->seconds_linearize += t1 - t0;
     // ---- PCG.  The vector kernel of iteration k publishes its verdict (go on / converged after
-    // n iterations) in host-mapped memory when it STARTS; the host keeps at most two iterations
-    // in flight: iteration j is launched once the verdict of iteration j-2 says "go on".  The
+    // n iterations) in host-mapped memory when it STARTS; iteration j is launched once the verdict
+    // of iteration j-1 says "go on".  The
     // rule only depends on the (deterministic, rank-identical) verdicts, never on timing.
     int k = 0, pcg_done_iters = -1;
     const long long base = h->flag_base;
@@ -924,8 +924,11 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       return BA_OK;
     };
     while (k < opts->pcg_max_iters) {
-      if (k >= 2) {
-        if (int rc = wait_flag(h, 0, base + (k - 2) + 1)) return rc;     // verdict of iteration k-2 (or later)
+      if (k >= 1) {
+        // verdict of iteration k-1 (published when its vector kernel STARTS, so the next point pass
+        // is queued while that kernel still runs; one iteration of early-exit kernels is the price
+        // of learning about convergence)
+        if (int rc = wait_flag(h, 0, base + (k - 1) + 1)) return rc;
         const long long payload = h->h_flags[1];
         if (payload > 0) { pcg_done_iters = (int)payload - 1; break; }
       }

@@ -690,21 +690,32 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
     double g, z;
     if (pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z)) return;
   }
-  if (LDS_TAB) fill_cam_table<PT_THREADS>(tab, camA, n_cams);
   const int sub = threadIdx.x % LPP;
   double acc[4] = {0, 0, 0, 0};
   const int pend = min(n_pts, (int)(blockIdx.x + 1) * pts_per_block);
+  bool table_ready = !LDS_TAB;
   for (int p0 = blockIdx.x * pts_per_block; p0 < pend; p0 += PT_THREADS / LPP) {
     const int p = p0 + threadIdx.x / LPP;
     double u[3] = {0, 0, 0};
     double4 X = make_double4(0, 0, 0, 0);
-    if (p < pend) {
+    double hi[6] = {0, 0, 0, 0, 0, 0};
+    int j = 0, end = 0, c = 0;
+    double2 w = make_double2(1.0, 1.0);
+    if (p < pend) {                      // first loads of the index stream go out before the table fill
       X = *(const double4*)(ptab + PT * (size_t)p);
-      const int beg = pt_off[p], end = pt_off[p + 1];
-      int j = beg + sub;
-      int c = (j < end) ? p_cam[j] : 0;
-      double2 w = make_double2(1.0, 1.0);
+      const int beg = pt_off[p];
+      end = pt_off[p + 1];
+      j = beg + sub;
+      c = (j < end) ? p_cam[j] : 0;
       if (ROBUST && j < end) w = p_w[j];
+      if (sub == LPP - 1) {
+        const double2* hp = (const double2*)(Hppinv + 6 * (size_t)p);
+        const double2 h01 = hp[0], h23 = hp[1], h45 = hp[2];
+        hi[0] = h01.x; hi[1] = h01.y; hi[2] = h23.x; hi[3] = h23.y; hi[4] = h45.x; hi[5] = h45.y;
+      }
+    }
+    if (!table_ready) { fill_cam_table<PT_THREADS>(tab, camA, n_cams); table_ready = true; }
+    if (p < pend) {
       while (j < end) {
         const int jn = j + LPP;
         const int cn = (jn < end) ? p_cam[jn] : 0;
@@ -731,9 +742,7 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
       for (int q = 0; q < 3; ++q) u[q] += dpp_f64<DPP_ROW_SHR1, 0xf>(u[q]);
     }
     if (p < pend && sub == LPP - 1) {
-      double hi[6], yy[3];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) hi[q] = Hppinv[6 * (size_t)p + q];
+      double yy[3];
       sym3_mul(hi, u, yy);
       if (MODE == 0) {
         double* o = ptab + PT * (size_t)p + 4;
