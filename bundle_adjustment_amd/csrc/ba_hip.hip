@@ -115,7 +115,8 @@ struct ba_handle {
   int Nc = 0, Np = 0, Nobs = 0, fixed = -1;
   double K4[4] = {1, 1, 0, 0};
   // observation lists (camera order, point order)
-  DBuf<int> offk, c_pt, c_orig, pt_off, p_cam;
+  DBuf<int> offk, c_pt, c_orig, pt_off, p_cam, slot;
+  DBuf<int2> blk_win;          // per point-pass workgroup: first camera and number of cameras its points see
   DBuf<double2> c_uv, p_uv, c_w[2], p_w;   // c_w / partL are double-buffered: the camera half of the next
                                            // linearisation is computed speculatively at the trial point
   // parameters (current / trial): cameras, camera state, point table
@@ -131,8 +132,8 @@ struct ba_handle {
   DBuf<double> gvec, x, r, p, s, z, vin, comm, commE, scal, rbuf;
   DBuf<PcgState> st;
   int nblkP = 1, ppb = 1, nblkV = 1;
-  bool lds_tab = true;
   size_t lds_bytes = 0;
+  bool all_lds = true;         // every point-pass workgroup's camera window fits in LDS
   // pinned host mirror for scalars
   double* h_scal = nullptr;
   double* d_scal_host = nullptr;   // device-side address of h_scal (host-mapped, coherent)
@@ -193,12 +194,12 @@ extern "C" int ba_create(int device_id, ba_handle** out) {
   memset(h->h_flags, 0, 8 * sizeof(long long));
   HIPCHECK(hipHostGetDevicePointer((void**)&h->d_flags, h->h_flags, 0));
   { const char* e = getenv("BA_DEBUG_FOLD"); h->force_fold = e && e[0] == '1'; }
-  HIPCHECK(allow_big_lds(k_pt_linearize<true, true>));
-  HIPCHECK(allow_big_lds(k_pt_linearize<false, true>));
-  HIPCHECK(allow_big_lds(k_pt_schur<true, 0, true>));
-  HIPCHECK(allow_big_lds(k_pt_schur<false, 0, true>));
-  HIPCHECK(allow_big_lds(k_pt_schur<true, 1, true>));
-  HIPCHECK(allow_big_lds(k_pt_schur<false, 1, true>));
+  HIPCHECK(allow_big_lds(k_pt_linearize<true, true>)); HIPCHECK(allow_big_lds(k_pt_linearize<true, false>));
+  HIPCHECK(allow_big_lds(k_pt_linearize<false, true>)); HIPCHECK(allow_big_lds(k_pt_linearize<false, false>));
+  HIPCHECK(allow_big_lds(k_pt_schur<true, 0, true>)); HIPCHECK(allow_big_lds(k_pt_schur<true, 0, false>));
+  HIPCHECK(allow_big_lds(k_pt_schur<false, 0, true>)); HIPCHECK(allow_big_lds(k_pt_schur<false, 0, false>));
+  HIPCHECK(allow_big_lds(k_pt_schur<true, 1, true>)); HIPCHECK(allow_big_lds(k_pt_schur<true, 1, false>));
+  HIPCHECK(allow_big_lds(k_pt_schur<false, 1, true>)); HIPCHECK(allow_big_lds(k_pt_schur<false, 1, false>));
   *out = h;
   return BA_OK;
 }
@@ -215,8 +216,9 @@ extern "C" int ba_destroy(ba_handle* h) {
   shm_destroy(h);
   for (auto e : h->ev) (void)hipEventDestroy(e);
   if (h->ev_decide) (void)hipEventDestroy(h->ev_decide);
-  DBuf<int>* ib[] = {&h->offk, &h->c_pt, &h->c_orig, &h->pt_off, &h->p_cam};
+  DBuf<int>* ib[] = {&h->offk, &h->c_pt, &h->c_orig, &h->pt_off, &h->p_cam, &h->slot};
   for (auto b : ib) b->release();
+  h->blk_win.release();
   DBuf<double2>* d2[] = {&h->c_uv, &h->p_uv, &h->c_w[0], &h->c_w[1], &h->p_w};
   for (auto b : d2) b->release();
   DBuf<double>* db[] = {&h->cams[0], &h->cams[1], &h->cs[0], &h->cs[1], &h->ptab[0], &h->ptab[1], &h->stage,
@@ -418,7 +420,8 @@ static int allreduce(ba_handle* h, double* buf, size_t count, bool is_max = fals
 
 // ---------------------------------------------------------------------------- problem
 extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64_t n_obs, const int32_t* cam_idx,
-                              const int32_t* pt_idx, const double* uv, const double K4[4], int32_t fixed_cam) {
+                              const int32_t* pt_idx_in, const double* uv, const double K4[4], int32_t fixed_cam) {
+  const int32_t* pt_idx = pt_idx_in;
   if (!h) return fail(BA_ERR_INVALID, "null handle");
   if (n_cams <= 0 || n_pts < 0 || n_obs < 0 || n_obs > 0x7fffffffLL) return fail(BA_ERR_INVALID, "bad sizes");
   if (n_obs > 0 && (!cam_idx || !pt_idx || !uv)) return fail(BA_ERR_INVALID, "null observation arrays");
@@ -430,6 +433,26 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   }
   if (set_device(h)) return BA_ERR_HIP;
   const int Nc = n_cams, Np = n_pts, No = (int)n_obs;
+  // internal point numbering.  When the whole camera table fits in LDS nothing is gained by
+  // moving points, so the caller's order is kept.  Otherwise points are sorted by the mean index of
+  // the cameras that observe them: consecutive points are then seen from a narrow window of cameras
+  // whenever the data has that locality (and per-camera partitions stay balanced when it has not).
+  // Pure locality: results do not depend on it.
+  std::vector<int> slot(Np);
+  if ((size_t)Nc * TA * sizeof(double) <= (size_t)LDS_TAB_BYTES) {
+    for (int p = 0; p < Np; ++p) slot[p] = p;
+  } else {
+    std::vector<double> sum(Np, 0.0);
+    std::vector<int> n(Np, 0);
+    for (int i = 0; i < No; ++i) { sum[pt_idx[i]] += cam_idx[i]; n[pt_idx[i]]++; }
+    std::vector<int> order(Np);
+    for (int p = 0; p < Np; ++p) { order[p] = p; sum[p] = n[p] ? sum[p] / n[p] : (double)Nc; }
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sum[a] < sum[b]; });
+    for (int r = 0; r < Np; ++r) slot[order[r]] = r;
+  }
+  std::vector<int> pt_new(No);
+  for (int i = 0; i < No; ++i) pt_new[i] = slot[pt_idx[i]];
+  pt_idx = pt_new.data();
   // point order: stable counting sort by point (keeps the caller's order inside a point)
   std::vector<int> pt_off(Np + 1, 0);
   for (int i = 0; i < No; ++i) pt_off[pt_idx[i] + 1]++;
@@ -474,14 +497,32 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   memcpy(h->K4, K4, sizeof h->K4);
   h->nblkV = (Nc + VEC_BLOCK - 1) / VEC_BLOCK;
   if (h->nblkV > 4096) return fail(BA_ERR_INVALID, "more than %d cameras are not supported", 4096 * VEC_BLOCK);
-  h->lds_bytes = (size_t)Nc * TA * sizeof(double);
-  h->lds_tab = h->lds_bytes <= 150 * 1024;
+  // point-pass workgroups: contiguous point ranges, one workgroup per CU when the camera windows
+  // are wide (LDS-limited), more when they are narrow
   const int pts_per_pass = PT_THREADS / LPP;
   const int want = std::max(1, (Np + pts_per_pass - 1) / pts_per_pass);
-  h->nblkP = std::min(want, h->lds_tab ? 256 : 4096);
+  h->nblkP = std::min(want, 4096);
   h->ppb = std::max(1, (Np + h->nblkP - 1) / h->nblkP);
+  std::vector<int2> win(h->nblkP);
+  size_t max_win = 0;
+  h->all_lds = true;
+  for (int b = 0; b < h->nblkP; ++b) {
+    const int p0 = std::min(Np, b * h->ppb), p1 = std::min(Np, (b + 1) * h->ppb);
+    int lo = Nc, hi = -1;
+    for (int j = pt_off[p0]; j < pt_off[p1]; ++j) { lo = std::min(lo, p_cam[j]); hi = std::max(hi, p_cam[j]); }
+    if (hi < lo) { lo = 0; hi = -1; }
+    win[b] = make_int2(lo, hi - lo + 1);
+    const size_t bytes = (size_t)(hi - lo + 1) * TA * sizeof(double);
+    if (bytes <= (size_t)LDS_TAB_BYTES) max_win = std::max(max_win, bytes);
+    else h->all_lds = false;
+  }
+  h->lds_bytes = max_win;
   const size_t nobs1 = std::max(No, 1), np1 = std::max(Np, 1);
   HIPCHECK(h->offk.alloc((size_t)Nc * (NPART + 1))); HIPCHECK(h->pt_off.alloc(Np + 1));
+  HIPCHECK(h->slot.alloc(np1));
+  if (Np > 0) HIPCHECK(hipMemcpyAsync(h->slot.p, slot.data(), Np * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h->blk_win.alloc(h->nblkP));
+  HIPCHECK(hipMemcpyAsync(h->blk_win.p, win.data(), h->nblkP * sizeof(int2), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(h->c_pt.alloc(nobs1)); HIPCHECK(h->c_orig.alloc(nobs1)); HIPCHECK(h->p_cam.alloc(nobs1));
   HIPCHECK(h->c_uv.alloc(nobs1)); HIPCHECK(h->p_uv.alloc(nobs1));
   HIPCHECK(h->c_w[0].alloc(nobs1)); HIPCHECK(h->c_w[1].alloc(nobs1)); HIPCHECK(h->p_w.alloc(nobs1));
@@ -537,7 +578,7 @@ extern "C" int ba_set_params(ba_handle* h, const double* cams, const double* pts
   HIPCHECK(hipMemcpyAsync(h->cams[0].p, cams, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (h->Np > 0) {
     HIPCHECK(hipMemcpyAsync(h->stage.p, pts, 3 * (size_t)h->Np * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_pack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->stage.p, h->Np, h->ptab[0].p);
+    hipLaunchKernelGGL(k_pack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->stage.p, h->slot.p, h->Np, h->ptab[0].p);
   }
   hipLaunchKernelGGL(k_cam_prepare, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->cams[0].p, h->cs[0].p, h->camA[0].p, h->Nc);
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -552,7 +593,7 @@ extern "C" int ba_get_params(ba_handle* h, double* cams, double* pts) {
   if (set_device(h)) return BA_ERR_HIP;
   if (cams) HIPCHECK(hipMemcpyAsync(cams, h->cams[h->cur].p, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (pts && h->Np > 0) {
-    hipLaunchKernelGGL(k_unpack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->ptab[h->cur].p, h->Np, h->stage.p);
+    hipLaunchKernelGGL(k_unpack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->ptab[h->cur].p, h->slot.p, h->Np, h->stage.p);
     HIPCHECK(hipMemcpyAsync(pts, h->stage.p, 3 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   }
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -620,15 +661,15 @@ static void launch_lin_pt(ba_handle* h, bool robust, double fscale, double lambd
   if (h->Np == 0) return;
   Scope sc(h, BA_K_LINEARIZE_PT);
   const int w = h->cur;
-#define LP_ARGS h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, \
-                h->Np, h->Nc, h->ppb, lambda, h->Hpp.p, h->bp.p, h->p_w.p, h->Hppinv.p, h->y0.p
-  const size_t lds = h->lds_tab ? h->lds_bytes : 0;
-  if (h->lds_tab) {
-    if (robust) hipLaunchKernelGGL((k_pt_linearize<true, true>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, LP_ARGS);
-    else        hipLaunchKernelGGL((k_pt_linearize<false, true>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, LP_ARGS);
+#define LP_ARGS h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_uv.p, h->blk_win.p, h->K4[0], h->K4[1], h->K4[2],  \
+                h->K4[3], fscale, h->Np, h->Nc, h->ppb, lambda, h->Hpp.p, h->bp.p, h->p_w.p, h->Hppinv.p, h->y0.p
+  const dim3 g(h->nblkP), b(PT_THREADS);
+  if (h->all_lds) {
+    if (robust) hipLaunchKernelGGL((k_pt_linearize<true, true>), g, b, h->lds_bytes, h->stream, LP_ARGS);
+    else        hipLaunchKernelGGL((k_pt_linearize<false, true>), g, b, h->lds_bytes, h->stream, LP_ARGS);
   } else {
-    if (robust) hipLaunchKernelGGL((k_pt_linearize<true, false>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, LP_ARGS);
-    else        hipLaunchKernelGGL((k_pt_linearize<false, false>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, LP_ARGS);
+    if (robust) hipLaunchKernelGGL((k_pt_linearize<true, false>), g, b, h->lds_bytes, h->stream, LP_ARGS);
+    else        hipLaunchKernelGGL((k_pt_linearize<false, false>), g, b, h->lds_bytes, h->stream, LP_ARGS);
   }
 #undef LP_ARGS
 }
@@ -665,13 +706,13 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
   if (h->Np == 0) return;
   Scope sc(h, mode == 0 ? BA_K_SCHUR_PT : BA_K_BACKSUB);
   const int w = h->cur;
-#define PS_ARGS h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_w.p, h->Hppinv.p, h->K4[0], h->K4[1], h->Np, h->Nc, \
-                h->fixed, h->ppb, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0.p, h->Hpp.p,       \
-                h->bp.p, h->ptab[1 - w].p, h->partB.p
+#define PS_ARGS h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_w.p, h->Hppinv.p, h->blk_win.p, h->K4[0], h->K4[1], \
+                h->Np, h->Nc, h->fixed, h->ppb, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0.p,       \
+                h->Hpp.p, h->bp.p, h->ptab[1 - w].p, h->partB.p
   const dim3 g(h->nblkP), b(PT_THREADS);
-  const size_t lds = h->lds_tab ? h->lds_bytes : 0;
+  const size_t lds = h->lds_bytes;
 #define PS_LAUNCH(R, M, L) hipLaunchKernelGGL((k_pt_schur<R, M, L>), g, b, lds, h->stream, PS_ARGS)
-  if (h->lds_tab) {
+  if (h->all_lds) {
     if (mode == 0) { if (robust) PS_LAUNCH(true, 0, true); else PS_LAUNCH(false, 0, true); }
     else           { if (robust) PS_LAUNCH(true, 1, true); else PS_LAUNCH(false, 1, true); }
   } else {
@@ -749,8 +790,17 @@ extern "C" int ba_linearize(ba_handle* h, int32_t loss, double f_scale, double* 
   h->lin_fscale = f_scale;
   if (Hcc) HIPCHECK(hipMemcpyAsync(Hcc, h->HccBc.p, 21 * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (bc) HIPCHECK(hipMemcpyAsync(bc, bc_ptr(h), 6 * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (Hpp && h->Np) HIPCHECK(hipMemcpyAsync(Hpp, h->Hpp.p, 6 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (bp && h->Np) HIPCHECK(hipMemcpyAsync(bp, h->bp.p, 3 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if ((Hpp || bp) && h->Np) {          // per-point blocks back in the caller's point order
+    HIPCHECK(h->rbuf.alloc(6 * (size_t)h->Np));
+    if (Hpp) {
+      hipLaunchKernelGGL(k_unpermute_rows, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp.p, h->slot.p, h->Np, 6, h->rbuf.p);
+      HIPCHECK(hipMemcpyAsync(Hpp, h->rbuf.p, 6 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (bp) {
+      hipLaunchKernelGGL(k_unpermute_rows, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->bp.p, h->slot.p, h->Np, 3, h->stage.p);
+      HIPCHECK(hipMemcpyAsync(bp, h->stage.p, 3 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+  }
   HIPCHECK(hipStreamSynchronize(h->stream));
   return BA_OK;
 }

@@ -1,6 +1,8 @@
 // HIP kernels of the bundle-adjustment solve step (gfx950).
 //
 // Data in HBM (built once per problem in ba_set_problem, see DESIGN.md "Layout"):
+//   points are renumbered internally by the first camera that sees them (slot[]), so that a run of
+//   consecutive points is seen from a narrow window of cameras whenever the data has that locality
 //   ptab[2][Np][8]   point records {X0 X1 X2 - y0 y1 y2 -}: one 64-byte sector per point, so a
 //                    camera-ordered pass fetches everything it needs about a point with one
 //                    sector; [cur] = accepted points, [1-cur] = trial points; y = PCG scratch
@@ -60,18 +62,28 @@ __global__ void k_cam_prepare(const double* __restrict__ cams, double* __restric
 }
 
 // pts (Np,3) -> X slots of the point table; table (Np,8) -> pts
-__global__ void k_pack_points(const double* __restrict__ pts, int n_pts, double* __restrict__ ptab) {
+// `slot[p]` = internal (locality-sorted) index of the caller's point p
+__global__ void k_pack_points(const double* __restrict__ pts, const int* __restrict__ slot, int n_pts,
+                              double* __restrict__ ptab) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pts) return;
-  double* o = ptab + PT * (size_t)p;
+  double* o = ptab + PT * (size_t)slot[p];
   o[0] = pts[3 * (size_t)p]; o[1] = pts[3 * (size_t)p + 1]; o[2] = pts[3 * (size_t)p + 2];
   o[3] = 0; o[4] = 0; o[5] = 0; o[6] = 0; o[7] = 0;
 }
-__global__ void k_unpack_points(const double* __restrict__ ptab, int n_pts, double* __restrict__ pts) {
+__global__ void k_unpack_points(const double* __restrict__ ptab, const int* __restrict__ slot, int n_pts,
+                                double* __restrict__ pts) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pts) return;
-  const double* s = ptab + PT * (size_t)p;
+  const double* s = ptab + PT * (size_t)slot[p];
   pts[3 * (size_t)p] = s[0]; pts[3 * (size_t)p + 1] = s[1]; pts[3 * (size_t)p + 2] = s[2];
+}
+// dst[p][0..W) = src[slot[p]][0..W)   (per-point outputs back in the caller's point order)
+__global__ void k_unpermute_rows(const double* __restrict__ src, const int* __restrict__ slot, int n_pts, int width,
+                                 double* __restrict__ dst) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pts) return;
+  for (int q = 0; q < width; ++q) dst[(size_t)p * width + q] = src[(size_t)slot[p] * width + q];
 }
 
 // -------------------------------------------------------------------------------------
@@ -540,17 +552,22 @@ k_fold_partials(const double* __restrict__ part6, const double* __restrict__ par
 // -------------------------------------------------------------------------------------
 // point passes: LPP lanes per point, camera table (camA) in LDS when it fits
 // -------------------------------------------------------------------------------------
-// row c of the packed camera table camA = R[9] t[3] | vtil[6]; ROWLEN 12 reads R|t only
-template <bool LDS_TAB, int ROWLEN>
-__device__ inline void load_cam_row(const double* __restrict__ tab, const double* __restrict__ camA, int c,
-                                    double (&row)[ROWLEN]) {
-  const double2* src = LDS_TAB ? (const double2*)(tab + TA * c) : (const double2*)(camA + TA * (size_t)c);
+// Camera table of a point-pass workgroup: rows [lo, lo + n) of the packed table camA =
+// R[9] t[3] | vtil[6] -- the window of cameras its points are observed from (host-computed per
+// workgroup).  The window is staged in LDS when it fits (use_lds, workgroup-uniform), else rows
+// are gathered from L2.  ROWLEN 12 reads R|t only.
+constexpr int LDS_TAB_BYTES = 150 * 1024;
+template <int ROWLEN>
+__device__ inline void load_cam_row(bool use_lds, const double* __restrict__ tab, const double* __restrict__ camA,
+                                    int lo, int c, double (&row)[ROWLEN]) {
+  const double2* src = use_lds ? (const double2*)(tab + TA * (c - lo)) : (const double2*)(camA + TA * (size_t)c);
 #pragma unroll
   for (int q = 0; q < ROWLEN / 2; ++q) { const double2 t = src[q]; row[2 * q] = t.x; row[2 * q + 1] = t.y; }
 }
 template <int BLOCK>
-__device__ inline void fill_cam_table(double* __restrict__ tab, const double* __restrict__ camA, int n_cams) {
-  for (int i = threadIdx.x; i < n_cams * TA / 2; i += BLOCK) ((double2*)tab)[i] = ((const double2*)camA)[i];
+__device__ inline void fill_cam_table(double* __restrict__ tab, const double* __restrict__ camA, int lo, int n) {
+  const double2* src = (const double2*)(camA + TA * (size_t)lo);
+  for (int i = threadIdx.x; i < n * TA / 2; i += BLOCK) ((double2*)tab)[i] = src[i];
   __syncthreads();
 }
 // deterministic workgroup sum of N values held by every wave's lane 0 -> thread 0
@@ -574,15 +591,17 @@ __device__ inline void block_combine(double (&v)[N], double* __restrict__ sm) {
 
 // K2b: point half of the normal equations.  Hpp[p] (6) = sum P^T w P, bp[p] (3) = -sum P^T w r,
 // IRLS weights of point-ordered observations (p_w) when ROBUST.
-template <bool ROBUST, bool LDS_TAB>
+template <bool ROBUST, bool ALL_LDS>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_linearize(const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,
-               const int* __restrict__ p_cam, const double2* __restrict__ p_uv,
+               const int* __restrict__ p_cam, const double2* __restrict__ p_uv, const int2* __restrict__ blk_win,
                double fx, double fy, double cx, double cy, double hub_c, int n_pts, int n_cams, int pts_per_block,
                double lambda, double* __restrict__ Hpp, double* __restrict__ bp, double2* __restrict__ p_w,
                double* __restrict__ Hppinv, double* __restrict__ y0) {
   extern __shared__ double tab[];
-  if (LDS_TAB) fill_cam_table<PT_THREADS>(tab, camA, n_cams);
+  const int2 win = blk_win[blockIdx.x];
+  const bool use_lds = ALL_LDS || (size_t)win.y * TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
+  if (use_lds) fill_cam_table<PT_THREADS>(tab, camA, win.x, win.y);
   const int sub = threadIdx.x % LPP;
   const int pend = min(n_pts, (int)(blockIdx.x + 1) * pts_per_block);
   for (int p0 = blockIdx.x * pts_per_block; p0 < pend; p0 += PT_THREADS / LPP) {
@@ -599,7 +618,7 @@ k_pt_linearize(const double* __restrict__ camA, double* __restrict__ ptab, const
         const int cn = (jn < end) ? p_cam[jn] : 0;
         const double2 uvn = (jn < end) ? p_uv[jn] : make_double2(0, 0);
         double row[12];
-        load_cam_row<LDS_TAB, 12>(tab, camA, c, row);
+        load_cam_row<12>(use_lds, tab, camA, win.x, c, row);
         Geom g;
         obs_geom(row, X.x, X.y, X.z, fx, fy, g);
         const double ru = uv.x - (g.xh * fx + cx);
@@ -675,10 +694,11 @@ k_point_invert(const double* __restrict__ Hpp, const double* __restrict__ bp, do
 // MODE 0 (PCG): y[p] = Hppinv u into the point table, partA[block] = sum u.y; early exit when done.
 // MODE 1 (back substitution): dp = -(y0 + Hppinv u), trial point = X + dp, partB[block][4] =
 //         bp.dp, sum Dp dp^2, |dp|^2, |X|^2.
-template <bool ROBUST, int MODE, bool LDS_TAB>
+template <bool ROBUST, int MODE, bool ALL_LDS>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,
            const int* __restrict__ p_cam, const double2* __restrict__ p_w, const double* __restrict__ Hppinv,
+           const int2* __restrict__ blk_win,
            double fx, double fy, int n_pts, int n_cams, int fixed_cam, int pts_per_block, double* __restrict__ partA,
            int kit, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2,
            int min_iters,
@@ -690,10 +710,12 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
     double g, z;
     if (pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z)) return;
   }
+  const int2 win = blk_win[blockIdx.x];
+  const bool use_lds = ALL_LDS || (size_t)win.y * TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
   const int sub = threadIdx.x % LPP;
   double acc[4] = {0, 0, 0, 0};
   const int pend = min(n_pts, (int)(blockIdx.x + 1) * pts_per_block);
-  bool table_ready = !LDS_TAB;
+  bool table_ready = !use_lds;
   for (int p0 = blockIdx.x * pts_per_block; p0 < pend; p0 += PT_THREADS / LPP) {
     const int p = p0 + threadIdx.x / LPP;
     double u[3] = {0, 0, 0};
@@ -714,7 +736,7 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
         hi[0] = h01.x; hi[1] = h01.y; hi[2] = h23.x; hi[3] = h23.y; hi[4] = h45.x; hi[5] = h45.y;
       }
     }
-    if (!table_ready) { fill_cam_table<PT_THREADS>(tab, camA, n_cams); table_ready = true; }
+    if (!table_ready) { fill_cam_table<PT_THREADS>(tab, camA, win.x, win.y); table_ready = true; }
     if (p < pend) {
       while (j < end) {
         const int jn = j + LPP;
@@ -723,7 +745,7 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
         if (ROBUST && jn < end) wn = p_w[jn];
         if (c != fixed_cam) {
           double row[TA];
-          load_cam_row<LDS_TAB, TA>(tab, camA, c, row);
+          load_cam_row<TA>(use_lds, tab, camA, win.x, c, row);
           const double* v = row + 12;
           Geom g;
           obs_geom(row, X.x, X.y, X.z, fx, fy, g);

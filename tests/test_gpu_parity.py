@@ -250,3 +250,21 @@ def test_bal_like_topology(solver):
     assert np.abs(r - ref).max() <= 1e-9
     out = solver.solve(loss="huber", max_iters=30, ftol=1e-8, xtol=1e-12, gtol=0.0)
     assert out["final_cost"] < 0.05 * out["initial_cost"]
+
+
+def test_c5_full_size_l2_fallback(solver):
+    """BASELINE config 5 topology at full size (1723 cams / 156 502 pts / ~662k obs): more cameras
+    than the LDS camera table holds, so the point passes take the L2-gather path."""
+    p = make_bal_like(seed=0)
+    assert p.n_cams == 1723 and p.n_pts == 156502
+    solver.set_problem(p)
+    r, sse, _ = solver.residuals()
+    ref = o.residuals(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4)
+    assert np.abs(r - ref).max() <= 1e-9
+    Hcc, bc, Hpp, bp = solver.linearize("huber")
+    sel = np.arange(0, p.n_obs, 1)            # oracle blocks on the full list (vectorised)
+    ne = o.normal_equations(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, 0, "huber")
+    assert _rel(Hcc, o.sym6_pack(ne["Hcc"])) <= 1e-9 and _rel(bp, ne["bp"]) <= 1e-9
+    out = solver.solve(loss="huber", max_iters=30, ftol=1e-9, xtol=1e-12, gtol=0.0)
+    assert out["final_cost"] < 0.05 * out["initial_cost"]
+    assert np.sqrt(out["final_sse"] / p.n_obs) < 0.75
