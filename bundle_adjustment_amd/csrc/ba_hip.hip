@@ -129,7 +129,7 @@ struct ba_handle {
   int lb = 0;                  // which c_w / partL buffer holds the current linearisation
   hipEvent_t ev_decide = nullptr;
   // PCG vectors, comm buffers (multi-rank), scalars
-  DBuf<double> gvec, x, r, p, s, z, vin, comm, commE, scal, rbuf;
+  DBuf<double> gvec, x, r, p, s, z, vin, scal, rbuf;
   DBuf<PcgState> st;
   int nblkP = 1, ppb = 1, nblkV = 1;
   size_t lds_bytes = 0;
@@ -145,7 +145,6 @@ struct ba_handle {
   long long flag_base = 1, step_seq = 1;
   // comm
   int rank = 0, world = 1;
-  bool force_fold = false;     // BA_DEBUG_FOLD=1: run the multi-rank kernel sequence (fold, folded consumers) on one rank
   ncclComm_t nccl = nullptr;
   // host-staged shared-memory transport (BA_COMM=shm): a test vehicle that lets several ranks
   // share ONE GPU (RCCL refuses that), so the multi-rank control flow can be exercised end to end
@@ -193,7 +192,6 @@ extern "C" int ba_create(int device_id, ba_handle** out) {
   HIPCHECK(hipHostMalloc((void**)&h->h_flags, 8 * sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent));
   memset(h->h_flags, 0, 8 * sizeof(long long));
   HIPCHECK(hipHostGetDevicePointer((void**)&h->d_flags, h->h_flags, 0));
-  { const char* e = getenv("BA_DEBUG_FOLD"); h->force_fold = e && e[0] == '1'; }
   HIPCHECK(allow_big_lds(k_pt_linearize<true, true>)); HIPCHECK(allow_big_lds(k_pt_linearize<true, false>));
   HIPCHECK(allow_big_lds(k_pt_linearize<false, true>)); HIPCHECK(allow_big_lds(k_pt_linearize<false, false>));
   HIPCHECK(allow_big_lds(k_pt_schur<true, 0, true>)); HIPCHECK(allow_big_lds(k_pt_schur<true, 0, false>));
@@ -224,7 +222,7 @@ extern "C" int ba_destroy(ba_handle* h) {
   DBuf<double>* db[] = {&h->cams[0], &h->cams[1], &h->cs[0], &h->cs[1], &h->ptab[0], &h->ptab[1], &h->stage,
                         &h->camA[0], &h->camA[1], &h->HccBc, &h->Hpp, &h->bp, &h->Hppinv, &h->y0, &h->Hccd, &h->Minv,
                         &h->partR, &h->partL[0], &h->partL[1], &h->part6, &h->partE, &h->partA, &h->partB, &h->partC, &h->partV,
-                        &h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin, &h->comm, &h->commE, &h->scal, &h->rbuf};
+                        &h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin, &h->scal, &h->rbuf};
   for (auto b : db) b->release();
   h->st.release();
   if (h->h_scal) (void)hipHostFree(h->h_scal);
@@ -539,12 +537,12 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(h->Hccd.alloc(21 * (size_t)Nc)); HIPCHECK(h->Minv.alloc(21 * (size_t)Nc));
   HIPCHECK(h->partR.alloc(2 * (size_t)NPART * Nc));
   HIPCHECK(h->partL[0].alloc(27 * (size_t)NPART * Nc)); HIPCHECK(h->partL[1].alloc(27 * (size_t)NPART * Nc));
-  HIPCHECK(h->part6.alloc(6 * (size_t)NPART * Nc)); HIPCHECK(h->partE.alloc(21 * (size_t)NPART * Nc));
+  HIPCHECK(h->part6.alloc(6 * (size_t)NPART * Nc + 8));   // + the u.y word: one all-reduce carries both
+  HIPCHECK(h->partE.alloc(21 * (size_t)NPART * Nc));
   HIPCHECK(h->partA.alloc(h->nblkP)); HIPCHECK(h->partB.alloc(4 * (size_t)h->nblkP));
   HIPCHECK(h->partC.alloc(5 * (size_t)h->nblkV)); HIPCHECK(h->partV.alloc(4 * (size_t)h->nblkV));
   DBuf<double>* v6[] = {&h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin};
   for (auto b : v6) HIPCHECK(b->alloc(6 * (size_t)Nc));
-  HIPCHECK(h->comm.alloc(6 * (size_t)Nc + 8)); HIPCHECK(h->commE.alloc(21 * (size_t)Nc));
   HIPCHECK(h->scal.alloc(64));
   HIPCHECK(h->st.alloc(2));
   HIPCHECK(hipMemsetAsync(h->camA[0].p, 0, TA * (size_t)Nc * sizeof(double), h->stream));
@@ -567,6 +565,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
 }
 
 static double* bc_ptr(ba_handle* h) { return h->HccBc.p + 21 * (size_t)h->Nc; }
+static double* uy_ptr(ba_handle* h) { return h->part6.p + 6 * (size_t)NPART * h->Nc; }
 static int cam_grid(ba_handle* h) { return ((h->Nc + WPB - 1) / WPB) * NPART; }
 static int row_grid(ba_handle* h) { return ((h->Nc + ROWS - 1) / ROWS) * NPART; }
 
@@ -686,7 +685,7 @@ static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int
   const int w = h->cur;
 #define CS_ARGS h->cs[w].p, h->ptab[w].p, h->offk.p, h->c_pt.p, h->c_w[h->lb].p, h->Hppinv.p, h->K4[0], h->K4[1], h->Nc, h->fixed, \
                 h->part6.p, h->partE.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->partA.p,              \
-                (h->Np > 0 ? h->nblkP : 0), h->comm.p + 6 * (size_t)h->Nc
+                (h->Np > 0 ? h->nblkP : 0), uy_ptr(h)
   const dim3 g(cam_grid(h) + (pcg ? 1 : 0)), b(64 * WPB);
   if (diag) {
     auto kern = robust ? k_camrow_schur_diag<true> : k_camrow_schur_diag<false>;
@@ -722,28 +721,19 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
 #undef PS_LAUNCH
 #undef PS_ARGS
 }
-// multi-rank: fold partials -> comm (+ commE) and all-reduce them.  Single rank: nothing.
-static bool folded(ba_handle* h) { return h->world > 1 || h->force_fold; }
-static int exchange_schur(ba_handle* h, bool with_diag, bool with_uy) {
-  if (!folded(h)) return BA_OK;
-  {
-    Scope sc(h, BA_K_MISC);
-    hipLaunchKernelGGL(k_fold_partials, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->part6.p,
-                       with_diag ? h->partE.p : (const double*)nullptr, with_uy ? h->partA.p : (const double*)nullptr,
-                       h->nblkP, h->Nc, h->comm.p, with_diag ? h->commE.p : (double*)nullptr);
-  }
-  if (int rc = allreduce(h, h->comm.p, 6 * (size_t)h->Nc + 1)) return rc;
-  if (with_diag) return allreduce(h, h->commE.p, 21 * (size_t)h->Nc);
+// multi-rank: the per-partition partial sums themselves are all-reduced (part6 with the u.y word
+// behind it; partE with the right-hand side pass), so every consumer kernel is the same as on one
+// rank and sums the NPART partitions afterwards.  Single rank: nothing.
+static int exchange_schur(ba_handle* h, bool with_diag) {
+  if (h->world == 1) return BA_OK;
+  if (int rc = allreduce(h, h->part6.p, 6 * (size_t)NPART * h->Nc + 1)) return rc;
+  if (with_diag) return allreduce(h, h->partE.p, 21 * (size_t)NPART * h->Nc);
   return BA_OK;
 }
-static const double* wy_src(ba_handle* h) { return folded(h) ? h->comm.p : h->part6.p; }
-static const double* e_src(ba_handle* h) { return folded(h) ? h->commE.p : h->partE.p; }
-static int wy_parts(ba_handle* h) { return folded(h) ? 1 : NPART; }
-
 // finalize = true: fold the fresh camera-half partials into Hcc | bc inside the same kernel
 static void launch_pcg_setup(ba_handle* h, double lambda, bool schur_diag, bool finalize) {
   Scope sc(h, BA_K_PCG_UPDATE);
-#define SU_ARGS h->partL[h->lb].p, h->HccBc.p, bc_ptr(h), wy_src(h), e_src(h), wy_parts(h), h->cs[h->cur].p, lambda,        \
+#define SU_ARGS h->partL[h->lb].p, h->HccBc.p, bc_ptr(h), h->part6.p, h->partE.p, NPART, h->cs[h->cur].p, lambda,           \
                 schur_diag ? 1 : 0, h->Nc, h->fixed, h->Hccd.p, h->Minv.p, h->gvec.p, h->x.p, h->r.p, h->p.p, h->s.p,     \
                 h->z.p, h->camA[h->cur].p, h->partV.p, h->st.p
   if (finalize) hipLaunchKernelGGL((k_pcg_setup<true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);
@@ -782,8 +772,8 @@ extern "C" int ba_linearize(ba_handle* h, int32_t loss, double f_scale, double* 
   if (!(f_scale > 0)) return fail(BA_ERR_INVALID, "f_scale must be positive");
   if (set_device(h)) return BA_ERR_HIP;
   launch_lin_cam(h, h->cur, h->lb, loss == BA_LOSS_HUBER, f_scale);
+  if (int rc = allreduce(h, h->partL[h->lb].p, 27 * (size_t)NPART * h->Nc)) return rc;
   launch_lin_finalize(h);
-  if (int rc = allreduce(h, h->HccBc.p, 27 * (size_t)h->Nc)) return rc;
   launch_lin_pt(h, loss == BA_LOSS_HUBER, f_scale, 1.0);
   h->linearized = true;
   h->lin_robust = (loss == BA_LOSS_HUBER);
@@ -811,7 +801,7 @@ extern "C" int ba_linearize(ba_handle* h, int32_t loss, double f_scale, double* 
 static int damped_system(ba_handle* h, double lambda, bool schur_diag, bool invert = true, bool finalize = false) {
   if (invert) launch_point_invert(h, lambda);
   launch_cam_schur(h, h->lin_robust, schur_diag, false, 0, 0.0, 0);
-  if (int rc = exchange_schur(h, schur_diag, false)) return rc;
+  if (int rc = exchange_schur(h, schur_diag)) return rc;
   launch_pcg_setup(h, lambda, schur_diag, finalize);
   return BA_OK;
 }
@@ -840,11 +830,11 @@ extern "C" int ba_schur_apply(ba_handle* h, double lambda, const double* v, doub
   }
   launch_pt_schur(h, h->lin_robust, 0, 0, -1.0, 1 << 30);        // y = Hppinv W^T v into the point table
   launch_cam_schur(h, h->lin_robust, false, false, 0, 0.0, 0);
-  if (int rc = exchange_schur(h, false, true)) return rc;
+  if (int rc = exchange_schur(h, false)) return rc;
   {
     Scope sc(h, BA_K_MISC);
-    hipLaunchKernelGGL(k_schur_combine, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->Hccd.p, h->vin.p, wy_src(h),
-                       wy_parts(h), h->cs[h->cur].p, h->Nc, h->fixed, h->z.p);
+    hipLaunchKernelGGL(k_schur_combine, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->Hccd.p, h->vin.p, h->part6.p,
+                       NPART, h->cs[h->cur].p, h->Nc, h->fixed, h->z.p);
   }
   HIPCHECK(hipMemcpyAsync(out, h->z.p, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -921,19 +911,19 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     double t0 = now_s();
     bool fresh = false;
     if (need_linearize) {
+      const bool cam_half_unreduced = !have_cam_half;
       if (!have_cam_half) launch_lin_cam(h, h->cur, h->lb, robust, fs);
       launch_lin_pt(h, robust, fs, lambda);          // also Hpp^-1, y0 at this lambda
       h->lin_robust = robust; h->lin_fscale = fs;
       need_linearize = false;
       have_cam_half = false;
       fresh = true;
-      if (folded(h)) {                                // Hcc | bc must be all-reduced before the setup kernel
-        launch_lin_finalize(h);
-        if (int rc = allreduce(h, h->HccBc.p, 27 * (size_t)Nc)) return rc;
-      }
+      // multi-rank: the camera-half partials of a freshly launched (not speculated) pass still
+      // have to be all-reduced; the speculated pass was reduced right behind its launch
+      if (cam_half_unreduced) { if (int rc = allreduce(h, h->partL[h->lb].p, 27 * (size_t)NPART * Nc)) return rc; }
     }
     // ---- damped system, right-hand side, preconditioner, first PCG vectors
-    if (int rc = damped_system(h, lambda, schur_diag, !fresh, fresh && !folded(h))) return rc;
+    if (int rc = damped_system(h, lambda, schur_diag, !fresh, fresh)) return rc;
     if (fresh && opts->gtol > 0) {
       {
         Scope sc(h, BA_K_MISC);
@@ -964,10 +954,10 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     auto launch_pcg_iteration = [&]() -> int {
       launch_pt_schur(h, robust, 0, k, tol2, opts->pcg_min_iters);
       launch_cam_schur(h, robust, false, true, k, tol2, opts->pcg_min_iters);
-      if (int rc = exchange_schur(h, false, true)) return rc;
+      if (int rc = exchange_schur(h, false)) return rc;
       Scope sc(h, BA_K_PCG_UPDATE);
-      hipLaunchKernelGGL(k_pcg_step, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, k, wy_src(h), wy_parts(h),
-                         (const double*)(h->comm.p + 6 * (size_t)Nc), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc,
+      hipLaunchKernelGGL(k_pcg_step, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, k, h->part6.p, NPART,
+                         (const double*)uy_ptr(h), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc,
                          h->fixed, tol2, opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA[h->cur].p,
                          h->partV.p, h->nblkV, h->st.p, h->d_flags, base);
       ++k;
@@ -1003,7 +993,10 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     // speculation: while the host decides, the GPU already computes the camera half of the next
     // linearisation at the trial point, into the other c_w / partL buffers
     const bool speculated = (it + 1 < opts->max_iters);
-    if (speculated) launch_lin_cam(h, 1 - h->cur, 1 - h->lb, robust, fs);
+    if (speculated) {
+      launch_lin_cam(h, 1 - h->cur, 1 - h->lb, robust, fs);
+      if (int rc = allreduce(h, h->partL[1 - h->lb].p, 27 * (size_t)NPART * Nc)) return rc;
+    }
     if (h->world > 1) HIPCHECK(hipEventSynchronize(h->ev_decide));
     else if (int rc = wait_flag(h, 2, seq)) return rc;
     if (pcg_done_iters < 0) pcg_done_iters = (h->h_scal[S_PCG_FIN] != 0.0) ? (int)h->h_scal[S_PCG_ITERS] : k;

@@ -524,31 +524,6 @@ __device__ inline void combine_wy(const double* __restrict__ part6, int nparts, 
   wy[3] = a[3]; wy[4] = a[4]; wy[5] = a[5];
 }
 
-// Multi-rank only: fold the partial sums into one buffer that is then all-reduced:
-//   comm[6c..] = sum_k part6 (pre-M), comm[6 Nc] = sum partA, and (DIAG) commE[21c..] = sum_k partE
-__global__ void __launch_bounds__(VEC_BLOCK)
-k_fold_partials(const double* __restrict__ part6, const double* __restrict__ partE, const double* __restrict__ partA,
-                int nblkA, int n_cams, double* __restrict__ comm, double* __restrict__ commE) {
-  const int c = blockIdx.x * VEC_BLOCK + threadIdx.x;
-  if (c < n_cams) {
-    for (int q = 0; q < 6; ++q) {
-      double a = 0;
-      for (int k = 0; k < NPART; ++k) a += part6[((size_t)k * n_cams + c) * 6 + q];
-      comm[6 * c + q] = a;
-    }
-    if (commE) for (int q = 0; q < 21; ++q) {
-      double a = 0;
-      for (int k = 0; k < NPART; ++k) a += partE[((size_t)k * n_cams + c) * 21 + q];
-      commE[21 * c + q] = a;
-    }
-  }
-  if (c == 0) {
-    double a = 0;
-    if (partA) for (int b = 0; b < nblkA; ++b) a += partA[b];
-    comm[6 * n_cams] = a;
-  }
-}
-
 // -------------------------------------------------------------------------------------
 // point passes: LPP lanes per point, camera table (camA) in LDS when it fits
 // -------------------------------------------------------------------------------------

@@ -119,32 +119,3 @@ def test_gpu_shards_sum_to_the_whole():
         assert np.abs(acc_b - bc).max() <= 1e-10 * np.abs(bc).max()
         acc_sv[0] = sv[0]
         assert np.abs(acc_sv - sv).max() <= 1e-9 * np.abs(sv).max()
-
-
-@pytest.mark.gpu
-def test_gpu_folded_multi_rank_kernel_sequence(monkeypatch):
-    """BA_DEBUG_FOLD=1 makes a single rank run the exact kernel sequence of a multi-rank job
-    (fold partials -> comm buffers -> folded consumers), minus the RCCL call itself: same
-    answers as the direct path."""
-    from bundle_adjustment_amd import hip_backend
-    p = make_problem(12, 800, 5, seed=4, outlier_frac=0.02)
-    kw = dict(loss="huber", max_iters=25, ftol=1e-13, xtol=1e-13, gtol=0.0, pcg_tol=1e-3)
-    with hip_backend.Solver(0) as s:
-        s.set_problem(p)
-        ref = s.solve(**kw)
-        ref_params = s.get_params()
-    monkeypatch.setenv("BA_DEBUG_FOLD", "1")
-    with hip_backend.Solver(0) as s:
-        s.set_problem(p)
-        s.linearize("huber")
-        g1 = s.schur_rhs(1e-3)
-        out = s.solve(**kw)
-        cams, pts = s.get_params()
-    monkeypatch.delenv("BA_DEBUG_FOLD")
-    with hip_backend.Solver(0) as s:
-        s.set_problem(p)
-        s.linearize("huber")
-        g0 = s.schur_rhs(1e-3)
-    assert np.abs(g1 - g0).max() <= 1e-12 * np.abs(g0).max()
-    assert abs(out["final_cost"] - ref["final_cost"]) <= 1e-10 * ref["final_cost"]
-    assert np.abs(cams - ref_params[0]).max() <= 1e-7 and np.abs(pts - ref_params[1]).max() <= 1e-6
