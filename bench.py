@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--pcg-tol", type=float, default=0.1)
     ap.add_argument("--pcg-max-iters", type=int, default=200)
+    ap.add_argument("--precond", default="schur_jacobi", choices=["schur_jacobi", "jacobi"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -126,7 +127,8 @@ def main():
         solver.comm_init(rank, world, uid[0])
     solver.set_problem(shard)
 
-    kw = dict(loss=args.loss, ftol=0.0, xtol=0.0, gtol=0.0, pcg_tol=args.pcg_tol, pcg_max_iters=args.pcg_max_iters)
+    kw = dict(loss=args.loss, ftol=0.0, xtol=0.0, gtol=0.0, pcg_tol=args.pcg_tol, pcg_max_iters=args.pcg_max_iters,
+              preconditioner=args.precond)
 
     def barrier():
         solver.synchronize()
@@ -158,7 +160,7 @@ def main():
     prof = solver.profile()
     ab = algorithmic_bytes(prob.n_cams, shard.n_pts, shard.n_obs)
     dom = max(("schur_pt", "schur_cam"), key=lambda k: prof.get(k, {}).get("total_ms", 0.0))
-    dom_us = prof[dom]["mean_us"]
+    dom_us = prof[dom]["working_mean_us"]        # launches that exit at once after PCG convergence are left out
     achieved = ab[dom] / (dom_us * 1e-6) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -170,7 +172,7 @@ def main():
     roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     algorithmic_bytes_per_launch=ab[dom], mean_launch_us=round(dom_us, 3),
-                    launches=prof[dom]["launches"])
+                    launches=prof[dom]["working_launches"], early_exit_launches=prof[dom]["launches"] - prof[dom]["working_launches"])
 
     line = None
     if rank == 0:
@@ -191,7 +193,7 @@ def main():
                        "accepted_steps": out["accepted"],
                        "seconds": {k: round(out[k], 6) for k in ("seconds_total", "seconds_linearize", "seconds_pcg", "seconds_update")}},
             "roofline": roofline,
-            "kernel_profile_us": {k: round(v["mean_us"], 3) for k, v in prof.items()},
+            "kernel_profile_us": {k: round(v["working_mean_us"], 3) for k, v in prof.items()},
         }
         if cpu is not None:
             line["cpu_baseline"] = cpu

@@ -155,6 +155,7 @@ struct ba_handle {
   std::vector<int> ev_slot;
   size_t ev_used = 0;
   ba_profile prof = {};
+  std::vector<float> prof_ms[BA_PROFILE_SLOTS];   // every measured duration, per slot
 };
 
 static int set_device(ba_handle* h) {
@@ -311,6 +312,7 @@ static void flush_profile(ba_handle* h) {
     const int slot = h->ev_slot[i / 2];
     h->prof.launches[slot] += 1;
     h->prof.total_ms[slot] += ms;
+    h->prof_ms[slot].push_back(ms);
   }
   h->ev_used = 0;
   h->ev_slot.clear();
@@ -318,6 +320,13 @@ static void flush_profile(ba_handle* h) {
 extern "C" int ba_get_profile(ba_handle* h, ba_profile* out) {
   if (!h || !out) return fail(BA_ERR_INVALID, "null argument");
   flush_profile(h);
+  for (int sl = 0; sl < BA_PROFILE_SLOTS; ++sl) {
+    float mx = 0;
+    for (float v : h->prof_ms[sl]) mx = std::max(mx, v);
+    h->prof.working_launches[sl] = 0;
+    h->prof.working_ms[sl] = 0;
+    for (float v : h->prof_ms[sl]) if (v >= 0.5f * mx) { h->prof.working_launches[sl]++; h->prof.working_ms[sl] += v; }
+  }
   *out = h->prof;
   return BA_OK;
 }
@@ -325,6 +334,7 @@ extern "C" int ba_reset_profile(ba_handle* h) {
   if (!h) return fail(BA_ERR_INVALID, "null handle");
   flush_profile(h);
   memset(&h->prof, 0, sizeof h->prof);
+  for (auto& v : h->prof_ms) v.clear();
   return BA_OK;
 }
 

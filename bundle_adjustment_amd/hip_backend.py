@@ -49,7 +49,8 @@ class BASummary(C.Structure):
 
 
 class BAProfile(C.Structure):
-    _fields_ = [("launches", C.c_int32 * PROFILE_SLOTS), ("total_ms", C.c_double * PROFILE_SLOTS)]
+    _fields_ = [("launches", C.c_int32 * PROFILE_SLOTS), ("total_ms", C.c_double * PROFILE_SLOTS),
+                ("working_launches", C.c_int32 * PROFILE_SLOTS), ("working_ms", C.c_double * PROFILE_SLOTS)]
 
 
 _lib = None
@@ -233,8 +234,10 @@ class Solver:
         out = {}
         for i in range(PROFILE_SLOTS):
             if p.launches[i]:
-                out[self._lib.ba_kernel_name(i).decode()] = dict(launches=p.launches[i], total_ms=p.total_ms[i],
-                                                                 mean_us=1e3 * p.total_ms[i] / p.launches[i])
+                w = max(p.working_launches[i], 1)
+                out[self._lib.ba_kernel_name(i).decode()] = dict(
+                    launches=p.launches[i], total_ms=p.total_ms[i], mean_us=1e3 * p.total_ms[i] / p.launches[i],
+                    working_launches=p.working_launches[i], working_mean_us=1e3 * p.working_ms[i] / w)
         if reset:
             _check(self._lib.ba_reset_profile(self._h))
         return out

@@ -83,8 +83,10 @@ typedef struct ba_summary {
 /* Per-kernel event timing collected when ba_options.profile = 1. */
 #define BA_PROFILE_SLOTS 16
 typedef struct ba_profile {
-  int32_t launches[BA_PROFILE_SLOTS];
+  int32_t launches[BA_PROFILE_SLOTS];          /* every launch */
   double total_ms[BA_PROFILE_SLOTS];
+  int32_t working_launches[BA_PROFILE_SLOTS];  /* launches that did their work: PCG kernels exit at once */
+  double working_ms[BA_PROFILE_SLOTS];         /* after convergence; those (< half the slot's longest) are left out */
 } ba_profile;
 /* slot ids */
 enum ba_kernel_slot {
