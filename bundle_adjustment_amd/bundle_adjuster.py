@@ -26,7 +26,7 @@ import numpy as np
 from . import hip_backend
 from .map_structures import Map
 from .parameters import DEBUG_DIRS
-from .problem import BAProblem, flatten_window, gather_window
+from .problem import BAProblem, flatten_map_window, gather_window
 from .rotations import matrices_to_rvecs
 
 
@@ -142,13 +142,14 @@ class BundleAdjuster:
         if not adjustable_kf_ids:
             print("    -> LBA Skipped: No adjustable keyframes.")
             return
-        local_map_point_ids, observations, keypoints_2d = self._gather_local_data(gmap, local_kf_ids)
+        # array-level form of _gather_local_data + the parameter packing of :157-162
+        prob, local_map_point_ids = flatten_map_window(gmap, local_kf_ids, self.camera_matrix)
         if not local_map_point_ids:
             print("    -> LBA Skipped: No points in the local window.")
             return
 
-        prob = flatten_window(gmap, local_kf_ids, local_map_point_ids, observations, keypoints_2d, self.camera_matrix)
         if self.sparsity_plot_hook is not None:
+            _, observations, _ = self._gather_local_data(gmap, local_kf_ids)
             self.sparsity_plot_hook(self._prepare_sparsity_matrix(len(adjustable_kf_ids), len(local_map_point_ids),
                                                                   adjustable_kf_ids, local_map_point_ids, observations),
                                     fixed_kf_id, local_kf_ids[-1])

@@ -96,6 +96,52 @@ def flatten_window(gmap, local_kf_ids, mp_ids, observations, keypoints_2d, camer
     return BAProblem(cams, pts.reshape(-1, 3), cam_idx, pt_idx, uv, K4, fixed_cam=0).validate()
 
 
+def flatten_map_window(gmap, local_kf_ids, camera_matrix):
+    """``gather_window`` + ``flatten_window`` in one array-level pass (no per-observation Python
+    tuples or dict entries): same ``BAProblem`` (same row order, same last-pixel-wins rule for a
+    repeated ``(keyframe, map point)`` pair) plus the sorted map-point ids.  Used by
+    ``BundleAdjuster.run``; the tuple/dict form stays available through ``_gather_local_data``."""
+    have = gmap.map_points
+    have_ids = np.fromiter(have.keys(), dtype=np.int64, count=len(have))
+    cam_parts, mp_parts, uv_parts = [], [], []
+    for ci, kf_id in enumerate(local_kf_ids):
+        kf = gmap.keyframes[kf_id]
+        if not kf.observations:
+            continue
+        ob = np.asarray(kf.observations, dtype=np.int64).reshape(-1, 2)
+        keep = np.isin(ob[:, 0], have_ids)
+        if not keep.all():
+            ob = ob[keep]
+        if ob.shape[0] == 0:
+            continue
+        mp, kp_idx = ob[:, 0], ob[:, 1]
+        # a repeated map point inside one keyframe: every row takes the LAST keypoint listed for it
+        uniq, inv = np.unique(mp, return_inverse=True)
+        if uniq.shape[0] != mp.shape[0]:
+            last = np.zeros(uniq.shape[0], dtype=np.int64)
+            last[inv] = np.arange(mp.shape[0])            # later rows overwrite earlier ones
+            kp_idx = kp_idx[last[inv]]
+        kps = kf.keypoints
+        used, uinv = np.unique(kp_idx, return_inverse=True)
+        pix = np.array([kps[i].pt for i in used.tolist()], dtype=np.float64).reshape(-1, 2)
+        cam_parts.append(np.full(mp.shape[0], ci, dtype=np.int32))
+        mp_parts.append(mp)
+        uv_parts.append(pix[uinv])
+    if not mp_parts:
+        return None, []
+    mp_all = np.concatenate(mp_parts)
+    mp_ids, pt_idx = np.unique(mp_all, return_inverse=True)
+    Rs = np.array([gmap.keyframes[k].R for k in local_kf_ids], dtype=np.float64)
+    ts = np.array([np.asarray(gmap.keyframes[k].t, dtype=np.float64).ravel() for k in local_kf_ids])
+    cams = np.concatenate([matrices_to_rvecs(Rs), ts], axis=1)
+    pts = np.array([np.asarray(have[int(m)].position, dtype=np.float64).ravel() for m in mp_ids.tolist()]).reshape(-1, 3)
+    K = np.asarray(camera_matrix, dtype=np.float64)
+    K4 = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]])
+    prob = BAProblem(cams, pts, np.concatenate(cam_parts), pt_idx.astype(np.int32), np.concatenate(uv_parts), K4,
+                     fixed_cam=0).validate()
+    return prob, [int(m) for m in mp_ids.tolist()]
+
+
 def shard_by_landmark(problem: BAProblem, n_shards: int):
     """Split the points into ``n_shards`` contiguous index ranges balanced by
     observation count.  Returns ``[(p_begin, p_end)]``; shard g owns those points and

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from bundle_adjustment_amd import bundle_adjuster as ba_mod
-from bundle_adjustment_amd.problem import flatten_window, gather_window
+from bundle_adjustment_amd.problem import flatten_map_window, flatten_window, gather_window
 from bundle_adjustment_amd.synthetic import make_problem, problem_to_map
 from tests.fake_solver import OracleSolver
 from tests.helpers import golden_flat_problem, load_golden, rebuild_map
@@ -50,6 +50,11 @@ def test_gather_and_flatten_match_reference_layout(name):
     np.testing.assert_array_equal(p.pt_idx, q.pt_idx)
     np.testing.assert_allclose(p.cams, q.cams, atol=1e-12)     # rvec of R (incl. the non-orthogonal one) and t
     np.testing.assert_array_equal(p.pts, q.pts)
+    # the array-level pass used by run() builds the identical problem
+    f, f_ids = flatten_map_window(gmap, local, g["K"])
+    assert f_ids == mp_ids
+    for a, b in ((f.cam_idx, p.cam_idx), (f.pt_idx, p.pt_idx), (f.uv, p.uv), (f.cams, p.cams), (f.pts, p.pts), (f.K4, p.K4)):
+        np.testing.assert_array_equal(a, b)
     na = len(local) - 1
     x0 = np.concatenate([p.cams[1:, :3].ravel(), p.cams[1:, 3:].ravel(), p.pts.ravel()])
     np.testing.assert_allclose(x0, g["x0"], atol=1e-12)
