@@ -711,13 +711,14 @@ static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int
 #undef CS_ARGS
 }
 // point pass with the camera vector in vtil; mode 0 = PCG iteration k, mode 1 = back substitution
-static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double tol2, int min_iters) {
+static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double tol2, int min_iters, long long flag_base = 0) {
   if (h->Np == 0) return;
   Scope sc(h, mode == 0 ? BA_K_SCHUR_PT : BA_K_BACKSUB);
   const int w = h->cur;
 #define PS_ARGS h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_w.p, h->Hppinv.p, h->blk_win.p, h->K4[0], h->K4[1], \
                 h->Np, h->Nc, h->fixed, h->ppb, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0.p,       \
-                h->Hpp.p, h->bp.p, h->ptab[1 - w].p, h->partB.p
+                h->Hpp.p, h->bp.p, h->ptab[1 - w].p, h->partB.p, (mode == 0 && flag_base > 0) ? h->d_flags : (long long*)nullptr, \
+                flag_base
   const dim3 g(h->nblkP), b(PT_THREADS);
   const size_t lds = h->lds_bytes;
 #define PS_LAUNCH(R, M, L) hipLaunchKernelGGL((k_pt_schur<R, M, L>), g, b, lds, h->stream, PS_ARGS)
@@ -911,6 +912,12 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   if (!std::isfinite(cost)) return fail(BA_ERR_NUMERIC, "non-finite cost at the initial parameters");
   sum->initial_sse = sse;
   sum->initial_cost = cost;
+  if (h->Np == 0 || h->Nobs == 0) {       // nothing to adjust
+    sum->final_sse = sse; sum->final_cost = cost; sum->final_lambda = opts->initial_lambda;
+    sum->seconds_total = now_s() - t_begin;
+    h->profile = false;
+    return BA_OK;
+  }
   double lambda = opts->initial_lambda, nu = 2.0;
   int it = 0, status = 0;
   bool need_linearize = true;      // point half (and, unless speculated, camera half) to be recomputed
@@ -961,28 +968,30 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     int k = 0, pcg_done_iters = -1;
     const long long base = h->flag_base;
     h->flag_base += opts->pcg_max_iters + 8;
-    auto launch_pcg_iteration = [&]() -> int {
-      launch_pt_schur(h, robust, 0, k, tol2, opts->pcg_min_iters);
-      launch_cam_schur(h, robust, false, true, k, tol2, opts->pcg_min_iters);
+    auto launch_point_pass = [&](int kk) { launch_pt_schur(h, robust, 0, kk, tol2, opts->pcg_min_iters, base); };
+    auto launch_rest = [&](int kk) -> int {
+      launch_cam_schur(h, robust, false, true, kk, tol2, opts->pcg_min_iters);
       if (int rc = exchange_schur(h, false)) return rc;
       Scope sc(h, BA_K_PCG_UPDATE);
-      hipLaunchKernelGGL(k_pcg_step, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, k, h->part6.p, NPART,
+      hipLaunchKernelGGL(k_pcg_step, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, kk, h->part6.p, NPART,
                          (const double*)uy_ptr(h), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc,
                          h->fixed, tol2, opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA[h->cur].p,
                          h->partV.p, h->nblkV, h->st.p, h->d_flags, base);
-      ++k;
       return BA_OK;
     };
-    while (k < opts->pcg_max_iters) {
-      if (k >= 1) {
-        // verdict of iteration k-1 (published when its vector kernel STARTS, so the next point pass
-        // is queued while that kernel still runs; one iteration of early-exit kernels is the price
-        // of learning about convergence)
-        if (int rc = wait_flag(h, 0, base + (k - 1) + 1)) return rc;
-        const long long payload = h->h_flags[1];
-        if (payload > 0) { pcg_done_iters = (int)payload - 1; break; }
-      }
-      if (int rc = launch_pcg_iteration()) return rc;
+    // The point pass of iteration k is the probe: it publishes the verdict for k when it starts.
+    // Only after a "go on" are the camera pass and the vector kernel of k queued (the point pass
+    // is still running then), followed at once by the probe of k+1.  Convergence costs one
+    // early-exit point pass.
+    launch_point_pass(0);
+    while (true) {
+      if (int rc = wait_flag(h, 0, base + k + 1)) return rc;
+      const long long payload = h->h_flags[1];
+      if (payload > 0) { pcg_done_iters = (int)payload - 1; break; }
+      if (int rc = launch_rest(k)) return rc;
+      ++k;
+      if (k >= opts->pcg_max_iters) break;
+      launch_point_pass(k);
     }
     // ---- step, trial point, gain-ratio scalars
     {

@@ -678,12 +678,20 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
            int kit, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2,
            int min_iters,
            const double* __restrict__ y0, const double* __restrict__ Hpp, const double* __restrict__ bp,
-           double* __restrict__ ptab_trial, double* __restrict__ partB) {
+           double* __restrict__ ptab_trial, double* __restrict__ partB,
+           long long* __restrict__ host_flag, long long flag_base) {
   extern __shared__ double tab[];
   __shared__ double sm[4 * (PT_THREADS / 64)];
   if (MODE == 0) {
     double g, z;
-    if (pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z)) return;
+    const bool fin = pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z);
+    // first kernel of iteration kit: tell the host now whether this iteration runs (it then queues
+    // the next one behind it) or PCG is over (it queues the step kernels instead)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const PcgState& s = st[kit & 1];
+      publish_flag(host_flag, flag_base + kit + 1, fin ? (long long)(s.done ? s.iters : kit) + 1 : 0);
+    }
+    if (fin) return;
   }
   const int2 win = blk_win[blockIdx.x];
   const bool use_lds = ALL_LDS || (size_t)win.y * TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
