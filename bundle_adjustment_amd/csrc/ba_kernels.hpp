@@ -1002,24 +1002,31 @@ k_scalars(const double* __restrict__ partR, int nR, const double* __restrict__ p
     for (int q = 0; q < 11; ++q) sm[wv * 11 + q] = a[q];
   }
   __syncthreads();
+  __shared__ double res[S_COUNT];
+  if (threadIdx.x < S_COUNT) res[threadIdx.x] = 0.0;
+  __syncthreads();
   if (threadIdx.x < 11) {
     double t = 0;
     for (int w = 0; w < 16; ++w) t += sm[w * 11 + threadIdx.x];
     const int slot = threadIdx.x < 2 ? S_SSE + threadIdx.x : (threadIdx.x < 6 ? S_PT_GD + (threadIdx.x - 2) : S_CAM_GD + (threadIdx.x - 6));
-    scal[slot] = t;
-    if (scal_host) scal_host[slot] = t;
+    res[slot] = t;
   }
   if (threadIdx.x == 64 && st) {
     double g, z;
     const bool fin = pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z);
     const PcgState& s = st[kit & 1];
-    const double iters = s.done ? (double)s.iters : (double)kit;
-    scal[S_PCG_FIN] = fin ? 1.0 : 0.0; scal[S_PCG_ITERS] = iters;
-    if (scal_host) { scal_host[S_PCG_FIN] = fin ? 1.0 : 0.0; scal_host[S_PCG_ITERS] = iters; }
+    res[S_PCG_FIN] = fin ? 1.0 : 0.0;
+    res[S_PCG_ITERS] = s.done ? (double)s.iters : (double)kit;
   }
-  if (host_flag) {                 // every scalar is out: publish the step's sequence number
+  __syncthreads();
+  if (threadIdx.x < S_COUNT) {
+    scal[threadIdx.x] = res[threadIdx.x];
+    if (scal_host) scal_host[threadIdx.x] = res[threadIdx.x];   // one wave: 24 consecutive host-mapped words
+  }
+  // one wave wrote every host word: a system-scope fence in that wave, then its lane 0 publishes
+  // the sequence number behind them
+  if (host_flag && threadIdx.x < 64) {
     __threadfence_system();
-    __syncthreads();
     if (threadIdx.x == 0) publish_flag(host_flag, seq, 0);
   }
 }
