@@ -115,7 +115,9 @@ struct ba_handle {
   int Nc = 0, Np = 0, Nobs = 0, fixed = -1;
   double K4[4] = {1, 1, 0, 0};
   // observation lists (camera order, point order)
-  DBuf<int> offk, c_pt, c_orig, pt_off, p_cam, slot;
+  DBuf<int> offk, c_pt, c_orig, pt_off, p_cam, slot, long_pts;
+  int long_thr = 16;           // tracks longer than this get a DPP row each (set in ba_set_problem)
+  int n_long = 0, nblkL = 0;   // points with more than LONG_TRACK observations: one DPP row each, own launch
   DBuf<int2> blk_win;          // per point-pass workgroup: first camera and number of cameras its points see
   DBuf<double2> c_uv, p_uv, c_w[2], p_w;   // c_w / partL are double-buffered: the camera half of the next
                                            // linearisation is computed speculatively at the trial point
@@ -193,12 +195,15 @@ extern "C" int ba_create(int device_id, ba_handle** out) {
   HIPCHECK(hipHostMalloc((void**)&h->h_flags, 8 * sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent));
   memset(h->h_flags, 0, 8 * sizeof(long long));
   HIPCHECK(hipHostGetDevicePointer((void**)&h->d_flags, h->h_flags, 0));
-  HIPCHECK(allow_big_lds(k_pt_linearize<true, true>)); HIPCHECK(allow_big_lds(k_pt_linearize<true, false>));
-  HIPCHECK(allow_big_lds(k_pt_linearize<false, true>)); HIPCHECK(allow_big_lds(k_pt_linearize<false, false>));
-  HIPCHECK(allow_big_lds(k_pt_schur<true, 0, true>)); HIPCHECK(allow_big_lds(k_pt_schur<true, 0, false>));
-  HIPCHECK(allow_big_lds(k_pt_schur<false, 0, true>)); HIPCHECK(allow_big_lds(k_pt_schur<false, 0, false>));
-  HIPCHECK(allow_big_lds(k_pt_schur<true, 1, true>)); HIPCHECK(allow_big_lds(k_pt_schur<true, 1, false>));
-  HIPCHECK(allow_big_lds(k_pt_schur<false, 1, true>)); HIPCHECK(allow_big_lds(k_pt_schur<false, 1, false>));
+#define BA_BIG_LDS(K) HIPCHECK(allow_big_lds(K))
+#define BA_BIG_LDS_LIN(R, L) BA_BIG_LDS((k_pt_linearize<R, L, LPP>)); BA_BIG_LDS((k_pt_linearize<R, L, LPP_LONG>))
+#define BA_BIG_LDS_SCH(R, M, L) BA_BIG_LDS((k_pt_schur<R, M, L, LPP>)); BA_BIG_LDS((k_pt_schur<R, M, L, LPP_LONG>))
+  BA_BIG_LDS_LIN(true, true); BA_BIG_LDS_LIN(true, false); BA_BIG_LDS_LIN(false, true); BA_BIG_LDS_LIN(false, false);
+  BA_BIG_LDS_SCH(true, 0, true); BA_BIG_LDS_SCH(true, 0, false); BA_BIG_LDS_SCH(false, 0, true); BA_BIG_LDS_SCH(false, 0, false);
+  BA_BIG_LDS_SCH(true, 1, true); BA_BIG_LDS_SCH(true, 1, false); BA_BIG_LDS_SCH(false, 1, true); BA_BIG_LDS_SCH(false, 1, false);
+#undef BA_BIG_LDS_SCH
+#undef BA_BIG_LDS_LIN
+#undef BA_BIG_LDS
   *out = h;
   return BA_OK;
 }
@@ -215,7 +220,7 @@ extern "C" int ba_destroy(ba_handle* h) {
   shm_destroy(h);
   for (auto e : h->ev) (void)hipEventDestroy(e);
   if (h->ev_decide) (void)hipEventDestroy(h->ev_decide);
-  DBuf<int>* ib[] = {&h->offk, &h->c_pt, &h->c_orig, &h->pt_off, &h->p_cam, &h->slot};
+  DBuf<int>* ib[] = {&h->offk, &h->c_pt, &h->c_orig, &h->pt_off, &h->p_cam, &h->slot, &h->long_pts};
   for (auto b : ib) b->release();
   h->blk_win.release();
   DBuf<double2>* d2[] = {&h->c_uv, &h->p_uv, &h->c_w[0], &h->c_w[1], &h->p_w};
@@ -321,11 +326,15 @@ extern "C" int ba_get_profile(ba_handle* h, ba_profile* out) {
   if (!h || !out) return fail(BA_ERR_INVALID, "null argument");
   flush_profile(h);
   for (int sl = 0; sl < BA_PROFILE_SLOTS; ++sl) {
-    float mx = 0;
-    for (float v : h->prof_ms[sl]) mx = std::max(mx, v);
+    // working launches: within [0.5, 4] x the 90th percentile (early exits below, rare host-side
+    // hiccups between the two events above)
+    std::vector<float> v = h->prof_ms[sl];
     h->prof.working_launches[sl] = 0;
     h->prof.working_ms[sl] = 0;
-    for (float v : h->prof_ms[sl]) if (v >= 0.5f * mx) { h->prof.working_launches[sl]++; h->prof.working_ms[sl] += v; }
+    if (v.empty()) continue;
+    std::sort(v.begin(), v.end());
+    const float ref = v[(size_t)(0.9 * (v.size() - 1))];
+    for (float d : v) if (d >= 0.5f * ref && d <= 4.0f * ref) { h->prof.working_launches[sl]++; h->prof.working_ms[sl] += d; }
   }
   *out = h->prof;
   return BA_OK;
@@ -511,26 +520,51 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   const int want = std::max(1, (Np + pts_per_pass - 1) / pts_per_pass);
   h->nblkP = std::min(want, 4096);
   h->ppb = std::max(1, (Np + h->nblkP - 1) / h->nblkP);
-  std::vector<int2> win(h->nblkP);
+  // long tracks: one DPP row (16 lanes) per point in a launch of their own
+  std::vector<int> long_pts;
+  {   // long = more than max(8, 2 x median track length) observations (BA_LONG_TRACK overrides)
+    std::vector<int> len(Np);
+    for (int p = 0; p < Np; ++p) len[p] = pt_off[p + 1] - pt_off[p];
+    int med = 0;
+    if (Np > 0) { std::nth_element(len.begin(), len.begin() + Np / 2, len.end()); med = len[Np / 2]; }
+    const char* e = getenv("BA_LONG_TRACK");
+    h->long_thr = e ? std::max(1, atoi(e)) : std::max(8, 2 * med);
+  }
+  for (int p = 0; p < Np; ++p) if (pt_off[p + 1] - pt_off[p] > h->long_thr) long_pts.push_back(p);
+  h->n_long = (int)long_pts.size();
+  const int long_per_blk = PT_THREADS / LPP_LONG;
+  h->nblkL = (h->n_long + long_per_blk - 1) / long_per_blk;
+  std::vector<int2> win(h->nblkP + h->nblkL);
   size_t max_win = 0;
   h->all_lds = true;
+  auto window_of = [&](int lo, int hi) {
+    if (hi < lo) { lo = 0; hi = -1; }
+    const size_t bytes = (size_t)(hi - lo + 1) * TA * sizeof(double);
+    if (bytes <= (size_t)LDS_TAB_BYTES) max_win = std::max(max_win, bytes);
+    else h->all_lds = false;
+    return make_int2(lo, hi - lo + 1);
+  };
   for (int b = 0; b < h->nblkP; ++b) {
     const int p0 = std::min(Np, b * h->ppb), p1 = std::min(Np, (b + 1) * h->ppb);
     int lo = Nc, hi = -1;
     for (int j = pt_off[p0]; j < pt_off[p1]; ++j) { lo = std::min(lo, p_cam[j]); hi = std::max(hi, p_cam[j]); }
-    if (hi < lo) { lo = 0; hi = -1; }
-    win[b] = make_int2(lo, hi - lo + 1);
-    const size_t bytes = (size_t)(hi - lo + 1) * TA * sizeof(double);
-    if (bytes <= (size_t)LDS_TAB_BYTES) max_win = std::max(max_win, bytes);
-    else h->all_lds = false;
+    win[b] = window_of(lo, hi);
+  }
+  for (int b = 0; b < h->nblkL; ++b) {
+    int lo = Nc, hi = -1;
+    for (int q = b * long_per_blk; q < std::min(h->n_long, (b + 1) * long_per_blk); ++q)
+      for (int j = pt_off[long_pts[q]]; j < pt_off[long_pts[q] + 1]; ++j) { lo = std::min(lo, p_cam[j]); hi = std::max(hi, p_cam[j]); }
+    win[h->nblkP + b] = window_of(lo, hi);
   }
   h->lds_bytes = max_win;
   const size_t nobs1 = std::max(No, 1), np1 = std::max(Np, 1);
   HIPCHECK(h->offk.alloc((size_t)Nc * (NPART + 1))); HIPCHECK(h->pt_off.alloc(Np + 1));
   HIPCHECK(h->slot.alloc(np1));
   if (Np > 0) HIPCHECK(hipMemcpyAsync(h->slot.p, slot.data(), Np * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  HIPCHECK(h->blk_win.alloc(h->nblkP));
-  HIPCHECK(hipMemcpyAsync(h->blk_win.p, win.data(), h->nblkP * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h->blk_win.alloc(win.size()));
+  HIPCHECK(hipMemcpyAsync(h->blk_win.p, win.data(), win.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(h->long_pts.alloc(std::max(h->n_long, 1)));
+  if (h->n_long) HIPCHECK(hipMemcpyAsync(h->long_pts.p, long_pts.data(), h->n_long * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(h->c_pt.alloc(nobs1)); HIPCHECK(h->c_orig.alloc(nobs1)); HIPCHECK(h->p_cam.alloc(nobs1));
   HIPCHECK(h->c_uv.alloc(nobs1)); HIPCHECK(h->p_uv.alloc(nobs1));
   HIPCHECK(h->c_w[0].alloc(nobs1)); HIPCHECK(h->c_w[1].alloc(nobs1)); HIPCHECK(h->p_w.alloc(nobs1));
@@ -549,7 +583,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(h->partL[0].alloc(27 * (size_t)NPART * Nc)); HIPCHECK(h->partL[1].alloc(27 * (size_t)NPART * Nc));
   HIPCHECK(h->part6.alloc(6 * (size_t)NPART * Nc + 8));   // + the u.y word: one all-reduce carries both
   HIPCHECK(h->partE.alloc(21 * (size_t)NPART * Nc));
-  HIPCHECK(h->partA.alloc(h->nblkP)); HIPCHECK(h->partB.alloc(4 * (size_t)h->nblkP));
+  HIPCHECK(h->partA.alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partB.alloc(4 * (size_t)(h->nblkP + h->nblkL)));
   HIPCHECK(h->partC.alloc(5 * (size_t)h->nblkV)); HIPCHECK(h->partV.alloc(4 * (size_t)h->nblkV));
   DBuf<double>* v6[] = {&h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin};
   for (auto b : v6) HIPCHECK(b->alloc(6 * (size_t)Nc));
@@ -634,7 +668,7 @@ static void launch_scalars(ba_handle* h, bool with_step, int k = 0, double tol2 
   Scope sc(h, BA_K_MISC);
   const bool direct = with_step && h->world == 1;     // results straight into host-mapped memory + sequence word
   hipLaunchKernelGGL(k_scalars, dim3(1), dim3(1024), 0, h->stream, h->partR.p, NPART * h->Nc, h->partB.p,
-                     (with_step && h->Np > 0) ? h->nblkP : 0, h->partC.p, with_step ? h->nblkV : 0, k,
+                     (with_step && h->Np > 0) ? h->nblkP + h->nblkL : 0, h->partC.p, with_step ? h->nblkV : 0, k,
                      with_step ? (const PcgState*)h->st.p : (const PcgState*)nullptr, h->partV.p, h->nblkV, tol2, min_iters,
                      h->scal.p, direct ? h->d_scal_host : (double*)nullptr, direct ? h->d_flags + 2 : (long long*)nullptr, seq);
 }
@@ -665,21 +699,26 @@ static void launch_lin_finalize(ba_handle* h) {
   hipLaunchKernelGGL(k_lin_finalize, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->partL[h->lb].p, h->cs[h->cur].p,
                      h->Nc, h->fixed, h->HccBc.p, bc_ptr(h));
 }
+static PtWork pt_work(ba_handle* h) {        // every point; long tracks skipped when they have a launch of their own
+  return PtWork{nullptr, h->Np, h->nblkL ? h->long_thr : 0x7fffffff, 0, h->ppb};
+}
+static PtWork pt_work_long(ba_handle* h) { return PtWork{h->long_pts.p, h->n_long, 0x7fffffff, h->nblkP, PT_THREADS / LPP_LONG}; }
 // point half at the current parameters, with the damped inverse / y0 at `lambda` fused in
 static void launch_lin_pt(ba_handle* h, bool robust, double fscale, double lambda) {
   if (h->Np == 0) return;
   Scope sc(h, BA_K_LINEARIZE_PT);
   const int w = h->cur;
-#define LP_ARGS h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_uv.p, h->blk_win.p, h->K4[0], h->K4[1], h->K4[2],  \
-                h->K4[3], fscale, h->Np, h->Nc, h->ppb, lambda, h->Hpp.p, h->bp.p, h->p_w.p, h->Hppinv.p, h->y0.p
-  const dim3 g(h->nblkP), b(PT_THREADS);
-  if (h->all_lds) {
-    if (robust) hipLaunchKernelGGL((k_pt_linearize<true, true>), g, b, h->lds_bytes, h->stream, LP_ARGS);
-    else        hipLaunchKernelGGL((k_pt_linearize<false, true>), g, b, h->lds_bytes, h->stream, LP_ARGS);
-  } else {
-    if (robust) hipLaunchKernelGGL((k_pt_linearize<true, false>), g, b, h->lds_bytes, h->stream, LP_ARGS);
-    else        hipLaunchKernelGGL((k_pt_linearize<false, false>), g, b, h->lds_bytes, h->stream, LP_ARGS);
+#define LP_ARGS(WK) h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_uv.p, h->blk_win.p, WK, h->K4[0], h->K4[1],    \
+                    h->K4[2], h->K4[3], fscale, lambda, h->Hpp.p, h->bp.p, h->p_w.p, h->Hppinv.p, h->y0.p
+#define LP_LAUNCH(R, L, LN, G, WK) hipLaunchKernelGGL((k_pt_linearize<R, L, LN>), dim3(G), dim3(PT_THREADS), h->lds_bytes, h->stream, LP_ARGS(WK))
+  const PtWork wk = pt_work(h), wl = pt_work_long(h);
+  if (h->all_lds) { if (robust) LP_LAUNCH(true, true, LPP, h->nblkP, wk); else LP_LAUNCH(false, true, LPP, h->nblkP, wk); }
+  else            { if (robust) LP_LAUNCH(true, false, LPP, h->nblkP, wk); else LP_LAUNCH(false, false, LPP, h->nblkP, wk); }
+  if (h->nblkL) {
+    if (h->all_lds) { if (robust) LP_LAUNCH(true, true, LPP_LONG, h->nblkL, wl); else LP_LAUNCH(false, true, LPP_LONG, h->nblkL, wl); }
+    else            { if (robust) LP_LAUNCH(true, false, LPP_LONG, h->nblkL, wl); else LP_LAUNCH(false, false, LPP_LONG, h->nblkL, wl); }
   }
+#undef LP_LAUNCH
 #undef LP_ARGS
 }
 static void launch_point_invert(ba_handle* h, double lambda) {
@@ -695,7 +734,7 @@ static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int
   const int w = h->cur;
 #define CS_ARGS h->cs[w].p, h->ptab[w].p, h->offk.p, h->c_pt.p, h->c_w[h->lb].p, h->Hppinv.p, h->K4[0], h->K4[1], h->Nc, h->fixed, \
                 h->part6.p, h->partE.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->partA.p,              \
-                (h->Np > 0 ? h->nblkP : 0), uy_ptr(h)
+                (h->Np > 0 ? h->nblkP + h->nblkL : 0), uy_ptr(h)
   const dim3 g(cam_grid(h) + (pcg ? 1 : 0)), b(64 * WPB);
   if (diag) {
     auto kern = robust ? k_camrow_schur_diag<true> : k_camrow_schur_diag<false>;
@@ -715,23 +754,31 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
   if (h->Np == 0) return;
   Scope sc(h, mode == 0 ? BA_K_SCHUR_PT : BA_K_BACKSUB);
   const int w = h->cur;
-#define PS_ARGS h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_w.p, h->Hppinv.p, h->blk_win.p, h->K4[0], h->K4[1], \
-                h->Np, h->Nc, h->fixed, h->ppb, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0.p,       \
-                h->Hpp.p, h->bp.p, h->ptab[1 - w].p, h->partB.p, (mode == 0 && flag_base > 0) ? h->d_flags : (long long*)nullptr, \
-                flag_base
-  const dim3 g(h->nblkP), b(PT_THREADS);
+#define PS_ARGS(WK, FLAG) h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_w.p, h->Hppinv.p, h->blk_win.p, WK, h->K4[0],  \
+                h->K4[1], h->fixed, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0.p, h->Hpp.p, h->bp.p,  \
+                h->ptab[1 - w].p, h->partB.p, FLAG, flag_base
   const size_t lds = h->lds_bytes;
-#define PS_LAUNCH(R, M, L) hipLaunchKernelGGL((k_pt_schur<R, M, L>), g, b, lds, h->stream, PS_ARGS)
+  long long* flag = (mode == 0 && flag_base > 0) ? h->d_flags : (long long*)nullptr;
+  long long* noflag = nullptr;
+#define PS_LAUNCH(R, M, L, LN, G, WK, FLAG) hipLaunchKernelGGL((k_pt_schur<R, M, L, LN>), dim3(G), dim3(PT_THREADS), lds, h->stream, PS_ARGS(WK, FLAG))
+#define PS_BOTH(R, M, L)                                                              \
+  do {                                                                                \
+    PS_LAUNCH(R, M, L, LPP, h->nblkP, wk, flag);                                      \
+    if (h->nblkL) PS_LAUNCH(R, M, L, LPP_LONG, h->nblkL, wl, noflag);                 \
+  } while (0)
+  const PtWork wk = pt_work(h), wl = pt_work_long(h);
   if (h->all_lds) {
-    if (mode == 0) { if (robust) PS_LAUNCH(true, 0, true); else PS_LAUNCH(false, 0, true); }
-    else           { if (robust) PS_LAUNCH(true, 1, true); else PS_LAUNCH(false, 1, true); }
+    if (mode == 0) { if (robust) PS_BOTH(true, 0, true); else PS_BOTH(false, 0, true); }
+    else           { if (robust) PS_BOTH(true, 1, true); else PS_BOTH(false, 1, true); }
   } else {
-    if (mode == 0) { if (robust) PS_LAUNCH(true, 0, false); else PS_LAUNCH(false, 0, false); }
-    else           { if (robust) PS_LAUNCH(true, 1, false); else PS_LAUNCH(false, 1, false); }
+    if (mode == 0) { if (robust) PS_BOTH(true, 0, false); else PS_BOTH(false, 0, false); }
+    else           { if (robust) PS_BOTH(true, 1, false); else PS_BOTH(false, 1, false); }
   }
+#undef PS_BOTH
 #undef PS_LAUNCH
 #undef PS_ARGS
 }
+
 // multi-rank: the per-partition partial sums themselves are all-reduced (part6 with the u.y word
 // behind it; partE with the right-hand side pass), so every consumer kernel is the same as on one
 // rank and sums the NPART partitions afterwards.  Single rank: nothing.

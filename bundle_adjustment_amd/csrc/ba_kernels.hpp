@@ -34,7 +34,8 @@ constexpr int WPB = 4;           // waves (= cameras) per workgroup in camera pa
 constexpr int PT = 8;            // doubles per point record
 constexpr int TA = 18;           // doubles per camera in camA: R[9] t[3] vtil[6]
 constexpr int PT_THREADS = 1024; // threads per workgroup in point passes
-constexpr int LPP = 2;           // lanes per point in point passes
+constexpr int LPP = 2;           // lanes per point in point passes (short tracks)
+constexpr int LPP_LONG = 16;     // one DPP row per point for long tracks (threshold chosen per problem)
 constexpr int VEC_BLOCK = 64;    // threads (= cameras) per workgroup in camera-vector kernels
 
 // PCG device state, two copies indexed by iteration parity (see k_pcg_step)
@@ -564,32 +565,51 @@ __device__ inline void block_combine(double (&v)[N], double* __restrict__ sm) {
   }
 }
 
+// Work list of a point-pass launch.  Range mode (plist == nullptr): slot s is point s, points
+// with more than skip_thr observations are left to the long-track launch.  List mode: slot s is
+// point plist[s] (the long tracks, LANES = 16: one DPP row per point).
+struct PtWork { const int* plist; int n_slots; int skip_thr; int blk_base; int slots_per_block; };
+
+template <int LANES>
+__device__ inline double lanes_sum(double x) {      // last lane of every LANES-group ends with the group sum
+  x += dpp_f64<DPP_ROW_SHR1, 0xf>(x);
+  if (LANES >= 4) x += dpp_f64<DPP_ROW_SHR2, 0xf>(x);
+  if (LANES >= 8) x += dpp_f64<DPP_ROW_SHR4, 0xf>(x);
+  if (LANES >= 16) x += dpp_f64<DPP_ROW_SHR8, 0xf>(x);
+  return x;
+}
+
 // K2b: point half of the normal equations.  Hpp[p] (6) = sum P^T w P, bp[p] (3) = -sum P^T w r,
-// IRLS weights of point-ordered observations (p_w) when ROBUST.
-template <bool ROBUST, bool ALL_LDS>
+// IRLS weights of point-ordered observations (p_w) when ROBUST; K3 fused: damped inverse and y0.
+template <bool ROBUST, bool ALL_LDS, int LANES>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_linearize(const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,
                const int* __restrict__ p_cam, const double2* __restrict__ p_uv, const int2* __restrict__ blk_win,
-               double fx, double fy, double cx, double cy, double hub_c, int n_pts, int n_cams, int pts_per_block,
+               PtWork wk, double fx, double fy, double cx, double cy, double hub_c,
                double lambda, double* __restrict__ Hpp, double* __restrict__ bp, double2* __restrict__ p_w,
                double* __restrict__ Hppinv, double* __restrict__ y0) {
   extern __shared__ double tab[];
-  const int2 win = blk_win[blockIdx.x];
+  const int2 win = blk_win[wk.blk_base + blockIdx.x];
   const bool use_lds = ALL_LDS || (size_t)win.y * TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
   if (use_lds) fill_cam_table<PT_THREADS>(tab, camA, win.x, win.y);
-  const int sub = threadIdx.x % LPP;
-  const int pend = min(n_pts, (int)(blockIdx.x + 1) * pts_per_block);
-  for (int p0 = blockIdx.x * pts_per_block; p0 < pend; p0 += PT_THREADS / LPP) {
-    const int p = p0 + threadIdx.x / LPP;
+  const int sub = threadIdx.x % LANES;
+  const int send = min(wk.n_slots, (int)(blockIdx.x + 1) * wk.slots_per_block);
+  for (int sb = blockIdx.x * wk.slots_per_block; sb < send; sb += PT_THREADS / LANES) {
+    const int sl = sb + threadIdx.x / LANES;
+    int p = -1, beg = 0, end = 0;
+    if (sl < send) {
+      p = wk.plist ? wk.plist[sl] : sl;
+      beg = pt_off[p]; end = pt_off[p + 1];
+      if (end - beg > wk.skip_thr) p = -1;          // long track: handled by the list-mode launch
+    }
     double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (p < pend) {
+    if (p >= 0) {
       const double4 X = *(const double4*)(ptab + PT * (size_t)p);
-      const int beg = pt_off[p], end = pt_off[p + 1];
       int j = beg + sub;
       int c = (j < end) ? p_cam[j] : 0;
       double2 uv = (j < end) ? p_uv[j] : make_double2(0, 0);
       while (j < end) {
-        const int jn = j + LPP;
+        const int jn = j + LANES;
         const int cn = (jn < end) ? p_cam[jn] : 0;
         const double2 uvn = (jn < end) ? p_uv[jn] : make_double2(0, 0);
         double row[12];
@@ -615,16 +635,13 @@ k_pt_linearize(const double* __restrict__ camA, double* __restrict__ ptab, const
         j = jn; c = cn; uv = uvn;
       }
     }
-    if (LPP >= 2) {
 #pragma unroll
-      for (int q = 0; q < 9; ++q) a[q] += dpp_f64<DPP_ROW_SHR1, 0xf>(a[q]);
-    }
-    if (p < pend && sub == LPP - 1) {
+    for (int q = 0; q < 9; ++q) a[q] = lanes_sum<LANES>(a[q]);
+    if (p >= 0 && sub == LANES - 1) {
 #pragma unroll
       for (int q = 0; q < 6; ++q) Hpp[6 * (size_t)p + q] = a[q];
 #pragma unroll
       for (int q = 0; q < 3; ++q) bp[3 * (size_t)p + q] = a[6 + q];
-      // K3 fused: damped inverse and y0 at the damping this linearisation starts with
       double h[6] = {a[0], a[1], a[2], a[3], a[4], a[5]}, inv[6], y[3];
       h[0] += lambda * fmax(h[0], DIAG_FLOOR);
       h[3] += lambda * fmax(h[3], DIAG_FLOOR);
@@ -669,12 +686,12 @@ k_point_invert(const double* __restrict__ Hpp, const double* __restrict__ bp, do
 // MODE 0 (PCG): y[p] = Hppinv u into the point table, partA[block] = sum u.y; early exit when done.
 // MODE 1 (back substitution): dp = -(y0 + Hppinv u), trial point = X + dp, partB[block][4] =
 //         bp.dp, sum Dp dp^2, |dp|^2, |X|^2.
-template <bool ROBUST, int MODE, bool ALL_LDS>
+template <bool ROBUST, int MODE, bool ALL_LDS, int LANES>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,
            const int* __restrict__ p_cam, const double2* __restrict__ p_w, const double* __restrict__ Hppinv,
-           const int2* __restrict__ blk_win,
-           double fx, double fy, int n_pts, int n_cams, int fixed_cam, int pts_per_block, double* __restrict__ partA,
+           const int2* __restrict__ blk_win, PtWork wk,
+           double fx, double fy, int fixed_cam, double* __restrict__ partA,
            int kit, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2,
            int min_iters,
            const double* __restrict__ y0, const double* __restrict__ Hpp, const double* __restrict__ bp,
@@ -693,36 +710,40 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
     }
     if (fin) return;
   }
-  const int2 win = blk_win[blockIdx.x];
+  const int2 win = blk_win[wk.blk_base + blockIdx.x];
   const bool use_lds = ALL_LDS || (size_t)win.y * TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
-  const int sub = threadIdx.x % LPP;
+  const int sub = threadIdx.x % LANES;
   double acc[4] = {0, 0, 0, 0};
-  const int pend = min(n_pts, (int)(blockIdx.x + 1) * pts_per_block);
+  const int send = min(wk.n_slots, (int)(blockIdx.x + 1) * wk.slots_per_block);
   bool table_ready = !use_lds;
-  for (int p0 = blockIdx.x * pts_per_block; p0 < pend; p0 += PT_THREADS / LPP) {
-    const int p = p0 + threadIdx.x / LPP;
+  for (int sb = blockIdx.x * wk.slots_per_block; sb < send; sb += PT_THREADS / LANES) {
+    const int sl = sb + threadIdx.x / LANES;
+    int p = -1, j = 0, end = 0, c = 0;
     double u[3] = {0, 0, 0};
     double4 X = make_double4(0, 0, 0, 0);
     double hi[6] = {0, 0, 0, 0, 0, 0};
-    int j = 0, end = 0, c = 0;
     double2 w = make_double2(1.0, 1.0);
-    if (p < pend) {                      // first loads of the index stream go out before the table fill
-      X = *(const double4*)(ptab + PT * (size_t)p);
+    if (sl < send) {                     // first loads of the index stream go out before the table fill
+      p = wk.plist ? wk.plist[sl] : sl;
       const int beg = pt_off[p];
       end = pt_off[p + 1];
-      j = beg + sub;
-      c = (j < end) ? p_cam[j] : 0;
-      if (ROBUST && j < end) w = p_w[j];
-      if (sub == LPP - 1) {
-        const double2* hp = (const double2*)(Hppinv + 6 * (size_t)p);
-        const double2 h01 = hp[0], h23 = hp[1], h45 = hp[2];
-        hi[0] = h01.x; hi[1] = h01.y; hi[2] = h23.x; hi[3] = h23.y; hi[4] = h45.x; hi[5] = h45.y;
+      if (end - beg > wk.skip_thr) { p = -1; end = 0; }     // long track: list-mode launch
+      else {
+        X = *(const double4*)(ptab + PT * (size_t)p);
+        j = beg + sub;
+        c = (j < end) ? p_cam[j] : 0;
+        if (ROBUST && j < end) w = p_w[j];
+        if (sub == LANES - 1) {
+          const double2* hp = (const double2*)(Hppinv + 6 * (size_t)p);
+          const double2 h01 = hp[0], h23 = hp[1], h45 = hp[2];
+          hi[0] = h01.x; hi[1] = h01.y; hi[2] = h23.x; hi[3] = h23.y; hi[4] = h45.x; hi[5] = h45.y;
+        }
       }
     }
     if (!table_ready) { fill_cam_table<PT_THREADS>(tab, camA, win.x, win.y); table_ready = true; }
-    if (p < pend) {
+    if (p >= 0) {
       while (j < end) {
-        const int jn = j + LPP;
+        const int jn = j + LANES;
         const int cn = (jn < end) ? p_cam[jn] : 0;
         double2 wn = make_double2(1.0, 1.0);
         if (ROBUST && jn < end) wn = p_w[jn];
@@ -742,11 +763,9 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
         j = jn; c = cn; w = wn;
       }
     }
-    if (LPP >= 2) {
 #pragma unroll
-      for (int q = 0; q < 3; ++q) u[q] += dpp_f64<DPP_ROW_SHR1, 0xf>(u[q]);
-    }
-    if (p < pend && sub == LPP - 1) {
+    for (int q = 0; q < 3; ++q) u[q] = lanes_sum<LANES>(u[q]);
+    if (p >= 0 && sub == LANES - 1) {
       double yy[3];
       sym3_mul(hi, u, yy);
       if (MODE == 0) {
@@ -772,8 +791,8 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
   for (int q = 0; q < 4; ++q) acc[q] = wave_total_dpp(acc[q]);
   block_combine<4, PT_THREADS>(acc, sm);
   if (threadIdx.x == 0) {
-    if (MODE == 0) partA[blockIdx.x] = acc[0];
-    else { for (int q = 0; q < 4; ++q) partB[4 * blockIdx.x + q] = acc[q]; }
+    if (MODE == 0) partA[wk.blk_base + blockIdx.x] = acc[0];
+    else { for (int q = 0; q < 4; ++q) partB[4 * (wk.blk_base + blockIdx.x) + q] = acc[q]; }
   }
 }
 
