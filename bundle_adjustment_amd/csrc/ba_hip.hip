@@ -498,17 +498,14 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
         c_pt[a] = p; c_orig[a] = p_src[j]; c_uv[a] = p_uv[j];
       }
   }
-  // partition split: offk[c][k] = first observation of camera c whose point is >= k * psz
+  // partition split: every camera's (point-sorted) list is cut into NPART equal-count chunks.  For
+  // uniformly spread observations chunk k covers about the k-th eighth of the point table (what
+  // keeps it resident in XCD k's L2); for band-structured data the chunks stay balanced and are
+  // narrow in point index anyway.
   std::vector<int> offk((size_t)Nc * (NPART + 1));
-  const int psz = std::max(1, (Np + NPART - 1) / NPART);
   for (int c = 0; c < Nc; ++c) {
-    int i = cam_off[c];
-    for (int k = 0; k <= NPART; ++k) {
-      const long long lim = (k == NPART) ? (long long)Np + 1 : (long long)k * psz;
-      while (i < cam_off[c + 1] && c_pt[i] < lim) ++i;
-      offk[(size_t)c * (NPART + 1) + k] = i;
-    }
-    offk[(size_t)c * (NPART + 1)] = cam_off[c];
+    const long long n = cam_off[c + 1] - cam_off[c];
+    for (int k = 0; k <= NPART; ++k) offk[(size_t)c * (NPART + 1) + k] = cam_off[c] + (int)((n * k) / NPART);
   }
   h->Nc = Nc; h->Np = Np; h->Nobs = No; h->fixed = fixed_cam;
   memcpy(h->K4, K4, sizeof h->K4);

@@ -7,7 +7,7 @@
 //                    camera-ordered pass fetches everything it needs about a point with one
 //                    sector; [cur] = accepted points, [1-cur] = trial points; y = PCG scratch
 //   camera order:    observations of camera c are [cam_off[c], cam_off[c+1]), sorted by point;
-//                    offk[c][k] splits them at the NPART point-partition boundaries
+//                    offk[c][k] cuts them into NPART equal-count chunks ("partitions")
 //                    -> c_pt (int32), c_uv, c_w (double2), c_orig (caller's row)
 //   point order:     observations of point p are [pt_off[p], pt_off[p+1]) -> p_cam, p_uv, p_w
 //   cs[2][Nc][24]    per-camera state R t M (camera_state), camA[2][Nc][18] = R t | vtil, the
