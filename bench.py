@@ -138,12 +138,38 @@ def main():
         shard, _ = extract_shard(prob, b, e)
 
     ndev = hip_backend.device_count()
-    solver = hip_backend.Solver((local_rank % ndev) if world > 1 else 0)
+    dev = (local_rank % ndev) if world > 1 else 0
+    solver = hip_backend.Solver(dev)
+    comm_note = "none (single rank)"
     if world > 1:
-        uid = [hip_backend.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        solver.comm_init(rank, world, uid[0])
-    solver.set_problem(shard)
+        import torch
+
+        def connect(s):
+            uid = [hip_backend.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            s.comm_init(rank, world, uid[0])
+            s.set_problem(shard)
+            s.residuals("linear", want_vector=False)        # first collective: proves the transport works
+        comm_note = os.environ.get("BA_COMM", "rccl")
+        ok, err = 1, ""
+        try:
+            connect(solver)
+        except hip_backend.BAHipError as e:
+            ok, err = 0, str(e)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if comm_note == "shm":
+                raise SystemExit(f"shared-memory transport failed: {err}")
+            # RCCL could not be brought up on some rank: every rank moves to the host-staged
+            # shared-memory transport (slow; labelled in the output) rather than report nothing
+            os.environ["BA_COMM"] = "shm"
+            solver.close()
+            solver = hip_backend.Solver(dev)
+            connect(solver)
+            comm_note = "shm FALLBACK (RCCL failed: %s)" % (err or "on another rank")
+    else:
+        solver.set_problem(shard)
 
     kw = dict(loss=args.loss, ftol=0.0, xtol=0.0, gtol=0.0, pcg_tol=args.pcg_tol, pcg_max_iters=args.pcg_max_iters,
               preconditioner=args.precond)
@@ -205,7 +231,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {prob.n_cams} cams / {prob.n_pts} pts / {n_obs_total} obs, "
                                    f"loss={args.loss}, LM+Schur+PCG(tol {args.pcg_tol})",
-                       "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU",
+                       "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU", "comm": comm_note,
                        "final_rmse_px": round(rmse, 6), "initial_rmse_px": round(float(np.sqrt(out['initial_sse'] / n_obs_total)), 6),
                        "pcg_iterations_per_lm": round(out["pcg_iterations"] / max(steps_done, 1), 2),
                        "accepted_steps": out["accepted"],

@@ -1,6 +1,6 @@
 // Device-side building blocks shared by every kernel: camera state, per-observation
 // geometry (projection + the factors of the analytic Jacobian blocks), small dense
-// algebra on packed symmetric blocks, and block-level sum reductions.
+// algebra on packed symmetric blocks.  (Reductions: ba_dpp.hpp.)
 //
 // Jacobian factorisation used everywhere (residual = observed - pi(R X + t), additive
 // rotation-vector update as scipy applies it, scipy/optimize/_lsq/trf.py:497-498):
@@ -192,36 +192,6 @@ __device__ inline void spd6_inverse(const double* __restrict__ h, double* __rest
       for (int k = 0; k < 6; ++k) if (k >= j) t += Li[k][i] * Li[k][j];
       inv[U6(i, j)] = t;
     }
-}
-
-// ---- reductions --------------------------------------------------------------------
-__device__ inline double wave_sum(double x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-  return x;
-}
-
-// Sum v[0..N) over the block; result valid in thread 0.  sm needs N * (blockDim.x/64)
-// doubles.  Fixed order (lanes by shuffle tree, then waves 0..n-1): deterministic.
-template <int N>
-__device__ inline void block_sum(double (&v)[N], double* __restrict__ sm) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-#pragma unroll
-  for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < N; ++k) sm[wv * N + k] = v[k];
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      double s = 0;
-      for (int w = 0; w < nw; ++w) s += sm[w * N + k];
-      v[k] = s;
-    }
-  }
-  __syncthreads();
 }
 
 }  // namespace ba

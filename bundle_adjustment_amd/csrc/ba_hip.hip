@@ -139,8 +139,6 @@ struct ba_handle {
   // pinned host mirror for scalars
   double* h_scal = nullptr;
   double* d_scal_host = nullptr;   // device-side address of h_scal (host-mapped, coherent)
-  PcgState* h_st = nullptr;
-  double* h_partV = nullptr;
   double* h_gmax = nullptr;
   long long* h_flags = nullptr;    // host-mapped progress words: [0..1] PCG verdicts, [2..3] step scalars
   long long* d_flags = nullptr;
@@ -189,8 +187,6 @@ extern "C" int ba_create(int device_id, ba_handle** out) {
   HIPCHECK(hipEventCreateWithFlags(&h->ev_decide, hipEventDisableTiming));
   HIPCHECK(hipHostMalloc((void**)&h->h_scal, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
   HIPCHECK(hipHostGetDevicePointer((void**)&h->d_scal_host, h->h_scal, 0));
-  HIPCHECK(hipHostMalloc((void**)&h->h_st, 2 * sizeof(PcgState)));
-  HIPCHECK(hipHostMalloc((void**)&h->h_partV, 4 * 4096 * sizeof(double)));
   HIPCHECK(hipHostMalloc((void**)&h->h_gmax, 8 * sizeof(double)));
   HIPCHECK(hipHostMalloc((void**)&h->h_flags, 8 * sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent));
   memset(h->h_flags, 0, 8 * sizeof(long long));
@@ -232,8 +228,6 @@ extern "C" int ba_destroy(ba_handle* h) {
   for (auto b : db) b->release();
   h->st.release();
   if (h->h_scal) (void)hipHostFree(h->h_scal);
-  if (h->h_st) (void)hipHostFree(h->h_st);
-  if (h->h_partV) (void)hipHostFree(h->h_partV);
   if (h->h_gmax) (void)hipHostFree(h->h_gmax);
   if (h->h_flags) (void)hipHostFree(h->h_flags);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -729,8 +723,8 @@ static void launch_point_invert(ba_handle* h, double lambda) {
 static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int k, double tol2, int min_iters) {
   Scope sc(h, diag ? BA_K_PRECOND : BA_K_SCHUR_CAM);
   const int w = h->cur;
-#define CS_ARGS h->cs[w].p, h->ptab[w].p, h->offk.p, h->c_pt.p, h->c_w[h->lb].p, h->Hppinv.p, h->K4[0], h->K4[1], h->Nc, h->fixed, \
-                h->part6.p, h->partE.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->partA.p,              \
+#define CS_ARGS h->cs[w].p, h->ptab[w].p, h->offk.p, h->c_pt.p, h->c_w[h->lb].p, h->K4[0], h->K4[1], h->Nc, h->fixed,        \
+                h->part6.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->partA.p,                                   \
                 (h->Np > 0 ? h->nblkP + h->nblkL : 0), uy_ptr(h)
   const dim3 g(cam_grid(h) + (pcg ? 1 : 0)), b(64 * WPB);
   if (diag) {
@@ -738,11 +732,11 @@ static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int
     hipLaunchKernelGGL(kern, dim3(row_grid(h)), dim3(16 * ROWS), 0, h->stream, h->cs[w].p, h->ptab[w].p, h->offk.p,
                        h->c_pt.p, h->c_w[h->lb].p, h->Hppinv.p, h->K4[0], h->K4[1], h->Nc, h->fixed, h->part6.p, h->partE.p);
   } else if (pcg) {
-    if (robust) hipLaunchKernelGGL((k_cam_schur<true, false, true>), g, b, 0, h->stream, CS_ARGS);
-    else        hipLaunchKernelGGL((k_cam_schur<false, false, true>), g, b, 0, h->stream, CS_ARGS);
+    if (robust) hipLaunchKernelGGL((k_cam_schur<true, true>), g, b, 0, h->stream, CS_ARGS);
+    else        hipLaunchKernelGGL((k_cam_schur<false, true>), g, b, 0, h->stream, CS_ARGS);
   } else {
-    if (robust) hipLaunchKernelGGL((k_cam_schur<true, false, false>), g, b, 0, h->stream, CS_ARGS);
-    else        hipLaunchKernelGGL((k_cam_schur<false, false, false>), g, b, 0, h->stream, CS_ARGS);
+    if (robust) hipLaunchKernelGGL((k_cam_schur<true, false>), g, b, 0, h->stream, CS_ARGS);
+    else        hipLaunchKernelGGL((k_cam_schur<false, false>), g, b, 0, h->stream, CS_ARGS);
   }
 #undef CS_ARGS
 }

@@ -49,8 +49,6 @@ enum { S_SSE = 0, S_RHO = 1, S_PT_GD = 2, S_PT_DDD = 3, S_PT_DD = 4, S_PT_XX = 5
        S_CAM_GD = 8, S_CAM_DDD = 9, S_DC_R = 10, S_CAM_DD = 11, S_CAM_XX = 12, S_GMAX_C = 16, S_GMAX_P = 17,
        S_PCG_FIN = 20, S_PCG_ITERS = 21, S_COUNT = 24 };
 
-__device__ inline double rcp_guarded(double z) { return (z != 0.0) ? 1.0 / z : 1.0; }
-
 // -------------------------------------------------------------------------------------
 // small per-camera / per-point kernels
 // -------------------------------------------------------------------------------------
@@ -154,49 +152,6 @@ __device__ inline void cam_jac_rows(const Geom& g, double X0, double X1, double 
   J1[3] = 0.0;    J1[4] = -g.d11; J1[5] = -g.d12;
 }
 
-// K2a: camera half of the normal equations, pre-M sums (the M^T . M congruence is applied
-// once per camera in k_lin_finalize):  partL[(k*Nc + c)*27 + ..] = 21 (A upper) + 6 (g).
-// Stores the IRLS weights of camera-ordered observations (c_w) when ROBUST.
-template <bool ROBUST>
-__global__ void __launch_bounds__(64 * WPB)
-k_cam_linearize(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
-                const int* __restrict__ c_pt, const double2* __restrict__ c_uv,
-                double fx, double fy, double cx, double cy, double hub_c, int n_cams,
-                double2* __restrict__ c_w, double* __restrict__ partL) {
-  Seg s;
-  if (!cam_segment(offk, n_cams, s)) return;
-  const double* cam = cs + CS * s.c;
-  double acc[27];
-#pragma unroll
-  for (int q = 0; q < 27; ++q) acc[q] = 0.0;
-  for (int i = s.beg + s.lane; i < s.end; i += 64) {
-    const int p = c_pt[i];
-    const double2 uv = c_uv[i];
-    const double4 X = *(const double4*)(ptab + PT * (size_t)p);
-    Geom g;
-    obs_geom(cam, X.x, X.y, X.z, fx, fy, g);
-    const double ru = uv.x - (g.xh * fx + cx);
-    const double rv = uv.y - (g.yh * fy + cy);
-    double w0 = 1.0, w1 = 1.0;
-    if (ROBUST) {
-      double t;
-      huber(ru, hub_c, t, w0);
-      huber(rv, hub_c, t, w1);
-      c_w[i] = make_double2(w0, w1);
-    }
-    double J0[6], J1[6];
-    cam_jac_rows(g, X.x, X.y, X.z, J0, J1);
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      const double wa0 = w0 * J0[a], wa1 = w1 * J1[a];
-#pragma unroll
-      for (int b = a; b < 6; ++b) acc[U6(a, b)] += wa0 * J0[b] + wa1 * J1[b];
-      acc[21 + a] += wa0 * ru + wa1 * rv;
-    }
-  }
-  wave_store_sums<27>(acc, s.lane, partL + ((size_t)s.k * n_cams + s.c) * 27);
-}
-
 // symmetric congruence H = T^T A T, T = diag(M, I6-3), A given as full 6x6
 __device__ inline void m_congruence(const double* __restrict__ M, double (&A)[6][6]) {
   double B[6][6];
@@ -248,9 +203,9 @@ k_lin_finalize(const double* __restrict__ partL, const double* __restrict__ cs, 
 }
 
 // K4b: camera pass of the Schur product, pre-M:  part6[(k*Nc + c)*6 + ..] = sum Jc^T w (Jp y_p)
-// with y read from the point table.  DIAG additionally accumulates the pre-M Schur-Jacobi
-// block sum_o W_o Hppinv_p W_o^T (21 values) into partE -- used once per damping change,
-// together with the right-hand side pass (y = y0).  PCG = true: early exit once converged.
+// with y read from the point table.  PCG = true: iteration kit of the solve (early exit once
+// converged; an extra workgroup folds the point pass's u.y partials).  The right-hand side
+// pass that also builds the Schur-Jacobi blocks is k_camrow_schur_diag.
 // Host-visible progress word (host-mapped, coherent memory): payload first, then the
 // sequence number with a system-scope release; the host spins on the sequence number.
 __device__ inline void publish_flag(long long* __restrict__ host_flag, long long seq, long long payload) {
@@ -272,11 +227,11 @@ __device__ inline bool pcg_finished(int k, const PcgState* __restrict__ st, cons
   return (k >= min_iters && g <= tol2 * g0);
 }
 
-template <bool ROBUST, bool DIAG, bool PCG>
+template <bool ROBUST, bool PCG>
 __global__ void __launch_bounds__(64 * WPB)
 k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
-            const int* __restrict__ c_pt, const double2* __restrict__ c_w, const double* __restrict__ Hppinv,
-            double fx, double fy, int n_cams, int fixed_cam, double* __restrict__ part6, double* __restrict__ partE,
+            const int* __restrict__ c_pt, const double2* __restrict__ c_w,
+            double fx, double fy, int n_cams, int fixed_cam, double* __restrict__ part6,
             int kit, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2,
             int min_iters, const double* __restrict__ partA, int nblkA, double* __restrict__ uy) {
   if (PCG) {
@@ -296,9 +251,7 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
   Seg s;
   if (!cam_segment(offk, n_cams, s)) return;
   const double* cam = cs + CS * s.c;
-  double acc[DIAG ? 27 : 6];
-#pragma unroll
-  for (int q = 0; q < (DIAG ? 27 : 6); ++q) acc[q] = 0.0;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
   if (s.c != fixed_cam) {
     int i = s.beg + s.lane;
     int p = (i < s.end) ? c_pt[i] : 0;
@@ -322,41 +275,10 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
       acc[3] -= g.d00 * s0;
       acc[4] -= g.d11 * s1;
       acc[5] -= g.d02 * s0 + g.d12 * s1;
-      if (DIAG) {
-        double hi[6];
-        const double2* hp = (const double2*)(Hppinv + 6 * (size_t)p);
-        const double2 h01 = hp[0], h23 = hp[1], h45 = hp[2];
-        hi[0] = h01.x; hi[1] = h01.y; hi[2] = h23.x; hi[3] = h23.y; hi[4] = h45.x; hi[5] = h45.y;
-        double t0[3], t1[3];
-        sym3_mul(hi, g.P, t0);
-        sym3_mul(hi, g.P + 3, t1);
-        const double G00 = w.x * w.x * (g.P[0] * t0[0] + g.P[1] * t0[1] + g.P[2] * t0[2]);
-        const double G01 = w.x * w.y * (g.P[0] * t1[0] + g.P[1] * t1[1] + g.P[2] * t1[2]);
-        const double G11 = w.y * w.y * (g.P[3] * t1[0] + g.P[4] * t1[1] + g.P[5] * t1[2]);
-        double J0[6], J1[6];
-        cam_jac_rows(g, X.x, X.y, X.z, J0, J1);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          const double l0 = J0[a] * G00 + J1[a] * G01, l1 = J0[a] * G01 + J1[a] * G11;
-#pragma unroll
-          for (int b = a; b < 6; ++b) acc[6 + U6(a, b)] += l0 * J0[b] + l1 * J1[b];
-        }
-      }
       i = in; p = pn; w = wn;
     }
   }
-#pragma unroll
-  for (int q = 0; q < (DIAG ? 27 : 6); ++q) acc[q] = wave_scan_sum_dpp(acc[q]);
-  if (s.lane == 63) {
-    double* o6 = part6 + ((size_t)s.k * n_cams + s.c) * 6;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) o6[q] = acc[q];
-    if (DIAG) {
-      double* oe = partE + ((size_t)s.k * n_cams + s.c) * 21;
-#pragma unroll
-      for (int q = 0; q < 21; ++q) oe[q] = acc[6 + q];
-    }
-  }
+  wave_store_sums<6>(acc, s.lane, part6 + ((size_t)s.k * n_cams + s.c) * 6);
 }
 
 // ---- 27-sum camera passes, one 16-lane DPP row per (camera, partition) segment ------------
