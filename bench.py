@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--pcg-tol", type=float, default=0.1)
     ap.add_argument("--pcg-max-iters", type=int, default=200)
     ap.add_argument("--precond", default="schur_jacobi", choices=["schur_jacobi", "jacobi"])
+    ap.add_argument("--jacobian", default="f64", choices=["f64", "f32"], help="f32: config 5's fp32 Jacobian blocks in the PCG passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -172,7 +173,7 @@ def main():
         solver.set_problem(shard)
 
     kw = dict(loss=args.loss, ftol=0.0, xtol=0.0, gtol=0.0, pcg_tol=args.pcg_tol, pcg_max_iters=args.pcg_max_iters,
-              preconditioner=args.precond)
+              preconditioner=args.precond, jacobian_precision=1 if args.jacobian == "f32" else 0)
 
     def barrier():
         solver.synchronize()
@@ -227,7 +228,8 @@ def main():
             "metric": "LM iterations/sec (final reprojection RMSE in config.final_rmse_px), 1k cams / 100k pts",
             "value": round(steps_done / dt, 3), "unit": "LM iterations/s", "n_gpus": world, "steps": steps_done,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / max(steps_done, 1), 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64" if args.jacobian == "f64" else "f64 (f32 Jacobian blocks in the PCG passes)",
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {prob.n_cams} cams / {prob.n_pts} pts / {n_obs_total} obs, "
                                    f"loss={args.loss}, LM+Schur+PCG(tol {args.pcg_tol})",

@@ -66,19 +66,23 @@ __device__ inline void camera_state(const double* __restrict__ cam, double* __re
 }
 
 // ---- per-observation geometry ------------------------------------------------------
-struct Geom {
-  double xh, yh;            // Xc.x / Xc.z, Xc.y / Xc.z
-  double d00, d02, d11, d12;  // dpi = [d00 0 d02; 0 d11 d12]
-  double P[6];              // dpi R, row-major 2x3
+// T = double everywhere except the PCG passes of jacobian_precision = 1 (config 5: Jacobian
+// blocks in fp32, every accumulation in fp64).
+template <typename T>
+struct GeomT {
+  T xh, yh;                 // Xc.x / Xc.z, Xc.y / Xc.z
+  T d00, d02, d11, d12;     // dpi = [d00 0 d02; 0 d11 d12]
+  T P[6];                   // dpi R, row-major 2x3
 };
+using Geom = GeomT<double>;
 
-template <typename CamT>
-__device__ inline void obs_geom(const CamT* __restrict__ cs, const double X0, const double X1, const double X2,
-                                const double fx, const double fy, Geom& g) {
-  const double Xc0 = cs[0] * X0 + cs[1] * X1 + cs[2] * X2 + cs[9];
-  const double Xc1 = cs[3] * X0 + cs[4] * X1 + cs[5] * X2 + cs[10];
-  const double Xc2 = cs[6] * X0 + cs[7] * X1 + cs[8] * X2 + cs[11];
-  const double iz = (Xc2 != 0.0) ? 1.0 / Xc2 : 1.0;   // cv2.projectPoints guards z == 0 as 1
+template <typename T, typename CamT>
+__device__ inline void obs_geom(const CamT* __restrict__ cs, const T X0, const T X1, const T X2,
+                                const T fx, const T fy, GeomT<T>& g) {
+  const T Xc0 = cs[0] * X0 + cs[1] * X1 + cs[2] * X2 + cs[9];
+  const T Xc1 = cs[3] * X0 + cs[4] * X1 + cs[5] * X2 + cs[10];
+  const T Xc2 = cs[6] * X0 + cs[7] * X1 + cs[8] * X2 + cs[11];
+  const T iz = (Xc2 != T(0)) ? T(1) / Xc2 : T(1);   // cv2.projectPoints guards z == 0 as 1
   g.xh = Xc0 * iz;
   g.yh = Xc1 * iz;
   g.d00 = fx * iz;

@@ -135,6 +135,7 @@ struct ba_handle {
   DBuf<PcgState> st;
   int nblkP = 1, ppb = 1, nblkV = 1;
   size_t lds_bytes = 0;
+  bool jac_f32 = false;        // PCG passes recompute the Jacobian blocks in fp32 (ba_options.jacobian_precision = 1)
   bool all_lds = true;         // every point-pass workgroup's camera window fits in LDS
   // pinned host mirror for scalars
   double* h_scal = nullptr;
@@ -193,7 +194,8 @@ extern "C" int ba_create(int device_id, ba_handle** out) {
   HIPCHECK(hipHostGetDevicePointer((void**)&h->d_flags, h->h_flags, 0));
 #define BA_BIG_LDS(K) HIPCHECK(allow_big_lds(K))
 #define BA_BIG_LDS_LIN(R, L) BA_BIG_LDS((k_pt_linearize<R, L, LPP>)); BA_BIG_LDS((k_pt_linearize<R, L, LPP_LONG>))
-#define BA_BIG_LDS_SCH(R, M, L) BA_BIG_LDS((k_pt_schur<R, M, L, LPP>)); BA_BIG_LDS((k_pt_schur<R, M, L, LPP_LONG>))
+#define BA_BIG_LDS_SCH(R, M, L) BA_BIG_LDS((k_pt_schur<R, M, L, LPP, double>)); BA_BIG_LDS((k_pt_schur<R, M, L, LPP_LONG, double>)); \
+  BA_BIG_LDS((k_pt_schur<R, M, L, LPP, float>)); BA_BIG_LDS((k_pt_schur<R, M, L, LPP_LONG, float>))
   BA_BIG_LDS_LIN(true, true); BA_BIG_LDS_LIN(true, false); BA_BIG_LDS_LIN(false, true); BA_BIG_LDS_LIN(false, false);
   BA_BIG_LDS_SCH(true, 0, true); BA_BIG_LDS_SCH(true, 0, false); BA_BIG_LDS_SCH(false, 0, true); BA_BIG_LDS_SCH(false, 0, false);
   BA_BIG_LDS_SCH(true, 1, true); BA_BIG_LDS_SCH(true, 1, false); BA_BIG_LDS_SCH(false, 1, true); BA_BIG_LDS_SCH(false, 1, false);
@@ -732,11 +734,16 @@ static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int
     hipLaunchKernelGGL(kern, dim3(row_grid(h)), dim3(16 * ROWS), 0, h->stream, h->cs[w].p, h->ptab[w].p, h->offk.p,
                        h->c_pt.p, h->c_w[h->lb].p, h->Hppinv.p, h->K4[0], h->K4[1], h->Nc, h->fixed, h->part6.p, h->partE.p);
   } else if (pcg) {
-    if (robust) hipLaunchKernelGGL((k_cam_schur<true, true>), g, b, 0, h->stream, CS_ARGS);
-    else        hipLaunchKernelGGL((k_cam_schur<false, true>), g, b, 0, h->stream, CS_ARGS);
+    if (h->jac_f32) {
+      if (robust) hipLaunchKernelGGL((k_cam_schur<true, true, float>), g, b, 0, h->stream, CS_ARGS);
+      else        hipLaunchKernelGGL((k_cam_schur<false, true, float>), g, b, 0, h->stream, CS_ARGS);
+    } else {
+      if (robust) hipLaunchKernelGGL((k_cam_schur<true, true, double>), g, b, 0, h->stream, CS_ARGS);
+      else        hipLaunchKernelGGL((k_cam_schur<false, true, double>), g, b, 0, h->stream, CS_ARGS);
+    }
   } else {
-    if (robust) hipLaunchKernelGGL((k_cam_schur<true, false>), g, b, 0, h->stream, CS_ARGS);
-    else        hipLaunchKernelGGL((k_cam_schur<false, false>), g, b, 0, h->stream, CS_ARGS);
+    if (robust) hipLaunchKernelGGL((k_cam_schur<true, false, double>), g, b, 0, h->stream, CS_ARGS);
+    else        hipLaunchKernelGGL((k_cam_schur<false, false, double>), g, b, 0, h->stream, CS_ARGS);
   }
 #undef CS_ARGS
 }
@@ -751,20 +758,24 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
   const size_t lds = h->lds_bytes;
   long long* flag = (mode == 0 && flag_base > 0) ? h->d_flags : (long long*)nullptr;
   long long* noflag = nullptr;
-#define PS_LAUNCH(R, M, L, LN, G, WK, FLAG) hipLaunchKernelGGL((k_pt_schur<R, M, L, LN>), dim3(G), dim3(PT_THREADS), lds, h->stream, PS_ARGS(WK, FLAG))
-#define PS_BOTH(R, M, L)                                                              \
+#define PS_LAUNCH(R, M, L, LN, JT, G, WK, FLAG) \
+  hipLaunchKernelGGL((k_pt_schur<R, M, L, LN, JT>), dim3(G), dim3(PT_THREADS), lds, h->stream, PS_ARGS(WK, FLAG))
+#define PS_BOTH(R, M, L, JT)                                                          \
   do {                                                                                \
-    PS_LAUNCH(R, M, L, LPP, h->nblkP, wk, flag);                                      \
-    if (h->nblkL) PS_LAUNCH(R, M, L, LPP_LONG, h->nblkL, wl, noflag);                 \
+    PS_LAUNCH(R, M, L, LPP, JT, h->nblkP, wk, flag);                                  \
+    if (h->nblkL) PS_LAUNCH(R, M, L, LPP_LONG, JT, h->nblkL, wl, noflag);             \
+  } while (0)
+#define PS_MODE(R, L)                                                                 \
+  do {                                                                                \
+    if (mode != 0) PS_BOTH(R, 1, L, double);                                          \
+    else if (f32) PS_BOTH(R, 0, L, float);                                            \
+    else PS_BOTH(R, 0, L, double);                                                    \
   } while (0)
   const PtWork wk = pt_work(h), wl = pt_work_long(h);
-  if (h->all_lds) {
-    if (mode == 0) { if (robust) PS_BOTH(true, 0, true); else PS_BOTH(false, 0, true); }
-    else           { if (robust) PS_BOTH(true, 1, true); else PS_BOTH(false, 1, true); }
-  } else {
-    if (mode == 0) { if (robust) PS_BOTH(true, 0, false); else PS_BOTH(false, 0, false); }
-    else           { if (robust) PS_BOTH(true, 1, false); else PS_BOTH(false, 1, false); }
-  }
+  const bool f32 = h->jac_f32 && flag_base > 0;       // only inside the PCG loop of ba_solve
+  if (h->all_lds) { if (robust) PS_MODE(true, true); else PS_MODE(false, true); }
+  else            { if (robust) PS_MODE(true, false); else PS_MODE(false, false); }
+#undef PS_MODE
 #undef PS_BOTH
 #undef PS_LAUNCH
 #undef PS_ARGS
@@ -933,7 +944,9 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   if (opts->loss != BA_LOSS_LINEAR && opts->loss != BA_LOSS_HUBER) return fail(BA_ERR_INVALID, "unknown loss");
   if (!(opts->f_scale > 0) || opts->max_iters < 0 || opts->pcg_max_iters < 1 || !(opts->initial_lambda > 0))
     return fail(BA_ERR_INVALID, "bad options");
-  if (opts->jacobian_precision != 0) return fail(BA_ERR_INVALID, "jacobian_precision %d not built", opts->jacobian_precision);
+  if (opts->jacobian_precision != 0 && opts->jacobian_precision != 1)
+    return fail(BA_ERR_INVALID, "jacobian_precision must be 0 (f64) or 1 (f32 blocks, f64 accumulation)");
+  h->jac_f32 = opts->jacobian_precision == 1;
   if (set_device(h)) return BA_ERR_HIP;
   memset(sum, 0, sizeof *sum);
   const bool robust = opts->loss == BA_LOSS_HUBER;
@@ -1099,6 +1112,7 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   sum->final_lambda = lambda;
   if (h->profile) flush_profile(h);
   h->profile = false;
+  h->jac_f32 = false;
   return BA_OK;
 }
 

@@ -227,7 +227,7 @@ __device__ inline bool pcg_finished(int k, const PcgState* __restrict__ st, cons
   return (k >= min_iters && g <= tol2 * g0);
 }
 
-template <bool ROBUST, bool PCG>
+template <bool ROBUST, bool PCG, typename JT>
 __global__ void __launch_bounds__(64 * WPB)
 k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
             const int* __restrict__ c_pt, const double2* __restrict__ c_w,
@@ -250,8 +250,12 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
   }
   Seg s;
   if (!cam_segment(offk, n_cams, s)) return;
-  const double* cam = cs + CS * s.c;
-  double acc[6] = {0, 0, 0, 0, 0, 0};
+  const double* camd = cs + CS * s.c;
+  JT cam[12];                                  // Jacobian blocks in JT (double, or float for config 5)
+#pragma unroll
+  for (int q = 0; q < 12; ++q) cam[q] = (JT)camd[q];
+  const JT fxj = (JT)fx, fyj = (JT)fy;
+  double acc[6] = {0, 0, 0, 0, 0, 0};          // sums always in fp64
   if (s.c != fixed_cam) {
     int i = s.beg + s.lane;
     int p = (i < s.end) ? c_pt[i] : 0;
@@ -262,19 +266,20 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
       const int pn = (in < s.end) ? c_pt[in] : 0;          // prefetch the next index / weight
       double2 wn = make_double2(1.0, 1.0);
       if (ROBUST && in < s.end) wn = c_w[in];
-      const double4 X = *(const double4*)(ptab + PT * (size_t)p);
-      const double4 Y = *(const double4*)(ptab + PT * (size_t)p + 4);
-      Geom g;
-      obs_geom(cam, X.x, X.y, X.z, fx, fy, g);
-      const double s0 = -(g.P[0] * Y.x + g.P[1] * Y.y + g.P[2] * Y.z) * w.x;
-      const double s1 = -(g.P[3] * Y.x + g.P[4] * Y.y + g.P[5] * Y.z) * w.y;
-      const double e0 = g.P[0] * s0 + g.P[3] * s1, e1 = g.P[1] * s0 + g.P[4] * s1, e2 = g.P[2] * s0 + g.P[5] * s1;
-      acc[0] += e1 * X.z - e2 * X.y;
-      acc[1] += e2 * X.x - e0 * X.z;
-      acc[2] += e0 * X.y - e1 * X.x;
-      acc[3] -= g.d00 * s0;
-      acc[4] -= g.d11 * s1;
-      acc[5] -= g.d02 * s0 + g.d12 * s1;
+      const double4 Xd = *(const double4*)(ptab + PT * (size_t)p);
+      const double4 Yd = *(const double4*)(ptab + PT * (size_t)p + 4);
+      const JT X0 = (JT)Xd.x, X1 = (JT)Xd.y, X2 = (JT)Xd.z, Y0 = (JT)Yd.x, Y1 = (JT)Yd.y, Y2 = (JT)Yd.z;
+      GeomT<JT> g;
+      obs_geom<JT>(cam, X0, X1, X2, fxj, fyj, g);
+      const JT s0 = -(g.P[0] * Y0 + g.P[1] * Y1 + g.P[2] * Y2) * (JT)w.x;
+      const JT s1 = -(g.P[3] * Y0 + g.P[4] * Y1 + g.P[5] * Y2) * (JT)w.y;
+      const JT e0 = g.P[0] * s0 + g.P[3] * s1, e1 = g.P[1] * s0 + g.P[4] * s1, e2 = g.P[2] * s0 + g.P[5] * s1;
+      acc[0] += (double)(e1 * X2 - e2 * X1);
+      acc[1] += (double)(e2 * X0 - e0 * X2);
+      acc[2] += (double)(e0 * X1 - e1 * X0);
+      acc[3] -= (double)(g.d00 * s0);
+      acc[4] -= (double)(g.d11 * s1);
+      acc[5] -= (double)(g.d02 * s0 + g.d12 * s1);
       i = in; p = pn; w = wn;
     }
   }
@@ -608,7 +613,7 @@ k_point_invert(const double* __restrict__ Hpp, const double* __restrict__ bp, do
 // MODE 0 (PCG): y[p] = Hppinv u into the point table, partA[block] = sum u.y; early exit when done.
 // MODE 1 (back substitution): dp = -(y0 + Hppinv u), trial point = X + dp, partB[block][4] =
 //         bp.dp, sum Dp dp^2, |dp|^2, |X|^2.
-template <bool ROBUST, int MODE, bool ALL_LDS, int LANES>
+template <bool ROBUST, int MODE, bool ALL_LDS, int LANES, typename JT>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,
            const int* __restrict__ p_cam, const double2* __restrict__ p_w, const double* __restrict__ Hppinv,
@@ -670,17 +675,21 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
         double2 wn = make_double2(1.0, 1.0);
         if (ROBUST && jn < end) wn = p_w[jn];
         if (c != fixed_cam) {
-          double row[TA];
-          load_cam_row<TA>(use_lds, tab, camA, win.x, c, row);
-          const double* v = row + 12;
-          Geom g;
-          obs_geom(row, X.x, X.y, X.z, fx, fy, g);
-          const double q0 = X.y * v[2] - X.z * v[1], q1 = X.z * v[0] - X.x * v[2], q2 = X.x * v[1] - X.y * v[0];
-          const double s0 = (g.P[0] * q0 + g.P[1] * q1 + g.P[2] * q2 - (g.d00 * v[3] + g.d02 * v[5])) * w.x;
-          const double s1 = (g.P[3] * q0 + g.P[4] * q1 + g.P[5] * q2 - (g.d11 * v[4] + g.d12 * v[5])) * w.y;
-          u[0] -= g.P[0] * s0 + g.P[3] * s1;
-          u[1] -= g.P[1] * s0 + g.P[4] * s1;
-          u[2] -= g.P[2] * s0 + g.P[5] * s1;
+          double rowd[TA];
+          load_cam_row<TA>(use_lds, tab, camA, win.x, c, rowd);
+          JT row[TA];                            // Jacobian blocks in JT (double, or float for config 5)
+#pragma unroll
+          for (int q = 0; q < TA; ++q) row[q] = (JT)rowd[q];
+          const JT* v = row + 12;
+          const JT X0 = (JT)X.x, X1 = (JT)X.y, X2 = (JT)X.z;
+          GeomT<JT> g;
+          obs_geom<JT>(row, X0, X1, X2, (JT)fx, (JT)fy, g);
+          const JT q0 = X1 * v[2] - X2 * v[1], q1 = X2 * v[0] - X0 * v[2], q2 = X0 * v[1] - X1 * v[0];
+          const JT s0 = (g.P[0] * q0 + g.P[1] * q1 + g.P[2] * q2 - (g.d00 * v[3] + g.d02 * v[5])) * (JT)w.x;
+          const JT s1 = (g.P[3] * q0 + g.P[4] * q1 + g.P[5] * q2 - (g.d11 * v[4] + g.d12 * v[5])) * (JT)w.y;
+          u[0] -= (double)(g.P[0] * s0 + g.P[3] * s1);      // sums always in fp64
+          u[1] -= (double)(g.P[1] * s0 + g.P[4] * s1);
+          u[2] -= (double)(g.P[2] * s0 + g.P[5] * s1);
         }
         j = jn; c = cn; w = wn;
       }

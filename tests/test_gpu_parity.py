@@ -268,3 +268,21 @@ def test_c5_full_size_l2_fallback(solver):
     out = solver.solve(loss="huber", max_iters=30, ftol=1e-9, xtol=1e-12, gtol=0.0)
     assert out["final_cost"] < 0.05 * out["initial_cost"]
     assert np.sqrt(out["final_sse"] / p.n_obs) < 0.75
+
+
+def test_fp32_jacobian_mode_reaches_the_fp64_solution(solver):
+    """BASELINE config 5's precision mode: Jacobian blocks of the PCG passes in fp32, every sum,
+    the gradient, the cost and the update in fp64.  Only the quasi-Newton operator changes, so the
+    converged solution is the fp64 one."""
+    p = make_problem(15, 1200, 5, seed=9, outlier_frac=0.02)
+    kw = dict(loss="huber", max_iters=40, ftol=1e-13, xtol=1e-13, gtol=0.0, pcg_tol=1e-3)
+    solver.set_problem(p)
+    ref = solver.solve(**kw)
+    cams_ref, pts_ref = solver.get_params()
+    solver.set_problem(p)
+    out = solver.solve(jacobian_precision=1, **kw)
+    cams, pts = solver.get_params()
+    assert abs(out["final_cost"] - ref["final_cost"]) <= 1e-9 * ref["final_cost"]
+    assert np.abs(cams - cams_ref).max() <= 1e-6 and np.abs(pts - pts_ref).max() <= 1e-5
+    with pytest.raises(hip_backend.BAHipError):
+        solver.solve(jacobian_precision=2, **kw)
