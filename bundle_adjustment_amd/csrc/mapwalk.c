@@ -1,0 +1,284 @@
+/*
+ * mapwalk.c -- CPython extension `bundle_adjustment_amd._mapwalk`: the walk over the Python
+ * Map objects that feeds the C-ABI (host side only; no arithmetic of the solve lives here).
+ *
+ * Restates, at C speed, what the reference does with dicts and tuples per observation:
+ *   walk_window       <-> BundleAdjuster._gather_local_data (src/bundle_adjuster.py:195-218):
+ *                         keyframes in the given order, kf.observations in list order, a row is
+ *                         kept when its map point still exists, and a (keyframe, map point) pair
+ *                         listed twice takes the LAST keypoint for every one of its rows (the
+ *                         reference keys its pixel dict by the pair, :214-216).
+ *   gather_positions  <-> the point packing of :161-162.
+ * Arrays cross as writable buffers (numpy arrays on the Python side), so no numpy headers are
+ * needed.  problem.flatten_map_window is the caller and keeps a numpy implementation of the
+ * same walk, which tests/test_bundle_adjuster_host.py compares this one with.
+ */
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static PyObject *s_observations, *s_keypoints, *s_pt, *s_position;
+
+/* ---- open-addressing int64 -> int64 map ------------------------------------------------ */
+typedef struct { int64_t *key, *val; uint8_t *used; size_t cap, n; } imap;
+
+static int imap_init(imap *m, size_t want) {
+  size_t cap = 16;
+  while (cap < 2 * want) cap <<= 1;
+  m->key = (int64_t *)malloc(cap * sizeof(int64_t));
+  m->val = (int64_t *)malloc(cap * sizeof(int64_t));
+  m->used = (uint8_t *)calloc(cap, 1);
+  m->cap = cap; m->n = 0;
+  if (!m->key || !m->val || !m->used) { free(m->key); free(m->val); free(m->used); m->key = m->val = NULL; m->used = NULL; return -1; }
+  return 0;
+}
+static void imap_free(imap *m) { free(m->key); free(m->val); free(m->used); m->key = m->val = NULL; m->used = NULL; }
+static void imap_clear(imap *m) { memset(m->used, 0, m->cap); m->n = 0; }
+static inline size_t imap_slot(const imap *m, int64_t k) {
+  uint64_t h = (uint64_t)k * 0x9E3779B97F4A7C15ull;
+  size_t i = (size_t)(h >> 17) & (m->cap - 1);
+  while (m->used[i] && m->key[i] != k) i = (i + 1) & (m->cap - 1);
+  return i;
+}
+static int imap_grow(imap *m) {
+  imap g;
+  if (imap_init(&g, m->cap) < 0) return -1;
+  for (size_t i = 0; i < m->cap; ++i) if (m->used[i]) {
+    size_t j = imap_slot(&g, m->key[i]);
+    g.used[j] = 1; g.key[j] = m->key[i]; g.val[j] = m->val[i]; ++g.n;
+  }
+  imap_free(m);
+  *m = g;
+  return 0;
+}
+/* returns the slot of k, inserting it with value v when absent (*fresh = 1) */
+static inline long imap_put(imap *m, int64_t k, int64_t v, int *fresh) {
+  if (2 * (m->n + 1) > m->cap && imap_grow(m) < 0) return -1;
+  size_t i = imap_slot(m, k);
+  *fresh = !m->used[i];
+  if (*fresh) { m->used[i] = 1; m->key[i] = k; m->val[i] = v; ++m->n; }
+  return (long)i;
+}
+
+/* ---- buffers ------------------------------------------------------------------------------ */
+static int get_out(PyObject *o, Py_buffer *b, Py_ssize_t itemsize, const char *what) {
+  if (PyObject_GetBuffer(o, b, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) < 0) return -1;
+  if (b->itemsize != itemsize) {
+    PyBuffer_Release(b);
+    PyErr_Format(PyExc_TypeError, "%s: item size %zd expected", what, itemsize);
+    return -1;
+  }
+  return 0;
+}
+
+static int as_double(PyObject *o, double *out) {
+  double v = PyFloat_AsDouble(o);
+  if (v == -1.0 && PyErr_Occurred()) return -1;
+  *out = v;
+  return 0;
+}
+
+/* two numbers out of kp.pt (tuple, list or any sequence) */
+static int read_pt(PyObject *kp, double *uv) {
+  PyObject *pt = PyObject_GetAttr(kp, s_pt);
+  if (!pt) return -1;
+  int rc = -1;
+  if (PyTuple_CheckExact(pt) && PyTuple_GET_SIZE(pt) >= 2) {
+    rc = (as_double(PyTuple_GET_ITEM(pt, 0), &uv[0]) < 0 || as_double(PyTuple_GET_ITEM(pt, 1), &uv[1]) < 0) ? -1 : 0;
+  } else {
+    PyObject *a = PySequence_GetItem(pt, 0), *b = a ? PySequence_GetItem(pt, 1) : NULL;
+    if (a && b) rc = (as_double(a, &uv[0]) < 0 || as_double(b, &uv[1]) < 0) ? -1 : 0;
+    Py_XDECREF(a); Py_XDECREF(b);
+  }
+  Py_DECREF(pt);
+  return rc;
+}
+
+/*
+ * walk_window(keyframes, map_points, local_kf_ids, cam_idx[int32], first_seen[int64], uv[f64 x2], distinct[int64])
+ *   -> (rows kept, distinct map points)
+ * cam_idx[i]    position of the row's keyframe in local_kf_ids
+ * first_seen[i] index of the row's map point in `distinct` (order of first appearance)
+ * uv[i]         pixel of the LAST keypoint the keyframe lists for that map point
+ * distinct[j]   map-point ids, first-appearance order
+ * Every output must hold sum(len(kf.observations)) entries.
+ */
+static PyObject *walk_window(PyObject *self, PyObject *args) {
+  PyObject *keyframes, *map_points, *kf_ids, *o_cam, *o_first, *o_uv, *o_distinct;
+  if (!PyArg_ParseTuple(args, "O!O!OOOOO", &PyDict_Type, &keyframes, &PyDict_Type, &map_points, &kf_ids,
+                        &o_cam, &o_first, &o_uv, &o_distinct)) return NULL;
+  Py_buffer b_cam, b_first, b_uv, b_distinct;
+  if (get_out(o_cam, &b_cam, 4, "cam_idx") < 0) return NULL;
+  if (get_out(o_first, &b_first, 8, "first_seen") < 0) { PyBuffer_Release(&b_cam); return NULL; }
+  if (get_out(o_uv, &b_uv, 8, "uv") < 0) { PyBuffer_Release(&b_cam); PyBuffer_Release(&b_first); return NULL; }
+  if (get_out(o_distinct, &b_distinct, 8, "distinct") < 0) {
+    PyBuffer_Release(&b_cam); PyBuffer_Release(&b_first); PyBuffer_Release(&b_uv); return NULL;
+  }
+  int32_t *cam = (int32_t *)b_cam.buf;
+  int64_t *first = (int64_t *)b_first.buf, *distinct = (int64_t *)b_distinct.buf;
+  double *uv = (double *)b_uv.buf;
+  const Py_ssize_t cap = b_cam.len / 4;
+  PyObject *ids = NULL, *result = NULL;
+  int64_t *kpidx = NULL;
+  imap seen = {0}, last = {0};
+  Py_ssize_t n = 0;
+  int ok = 0;
+
+  if (b_first.len / 8 < cap || b_uv.len / 16 < cap || b_distinct.len / 8 < cap) {
+    PyErr_SetString(PyExc_ValueError, "output buffers disagree in length");
+    goto done;
+  }
+  ids = PySequence_Fast(kf_ids, "local_kf_ids must be a sequence");
+  if (!ids) goto done;
+  kpidx = (int64_t *)malloc((size_t)(cap > 0 ? cap : 1) * sizeof(int64_t));
+  if (!kpidx || imap_init(&seen, 1024) < 0 || imap_init(&last, 1024) < 0) { PyErr_NoMemory(); goto done; }
+
+  for (Py_ssize_t ci = 0; ci < PySequence_Fast_GET_SIZE(ids); ++ci) {
+    PyObject *kf = PyDict_GetItemWithError(keyframes, PySequence_Fast_GET_ITEM(ids, ci));   /* borrowed */
+    if (!kf) { if (!PyErr_Occurred()) PyErr_SetObject(PyExc_KeyError, PySequence_Fast_GET_ITEM(ids, ci)); goto done; }
+    PyObject *obs_o = PyObject_GetAttr(kf, s_observations);
+    if (!obs_o) goto done;
+    PyObject *obs = PySequence_Fast(obs_o, "observations must be a sequence");
+    Py_DECREF(obs_o);
+    if (!obs) goto done;
+    PyObject *kps_o = PyObject_GetAttr(kf, s_keypoints);
+    PyObject *kps = kps_o ? PySequence_Fast(kps_o, "keypoints must be a sequence") : NULL;
+    Py_XDECREF(kps_o);
+    if (!kps) { Py_DECREF(obs); goto done; }
+
+    const Py_ssize_t start = n, m = PySequence_Fast_GET_SIZE(obs);
+    int bad = 0;
+    imap_clear(&last);
+    for (Py_ssize_t j = 0; j < m && !bad; ++j) {
+      PyObject *row = PySequence_Fast_GET_ITEM(obs, j);
+      PyObject *mp_o, *kp_o;
+      int own = 0;
+      if (PyTuple_CheckExact(row) && PyTuple_GET_SIZE(row) == 2) {
+        mp_o = PyTuple_GET_ITEM(row, 0); kp_o = PyTuple_GET_ITEM(row, 1);
+      } else {
+        mp_o = PySequence_GetItem(row, 0); kp_o = mp_o ? PySequence_GetItem(row, 1) : NULL; own = 1;
+        if (!mp_o || !kp_o) { Py_XDECREF(mp_o); bad = 1; break; }
+      }
+      const int have = PyDict_Contains(map_points, mp_o);
+      if (have < 0) bad = 1;
+      else if (have) {
+        const long long mp = PyLong_AsLongLong(mp_o);
+        const Py_ssize_t kp = PyNumber_AsSsize_t(kp_o, PyExc_IndexError);
+        if ((mp == -1 || kp == -1) && PyErr_Occurred()) bad = 1;
+        else if (n >= cap) { PyErr_SetString(PyExc_ValueError, "output buffers too small"); bad = 1; }
+        else {
+          int fresh_mp, fresh_kp;
+          const long s = imap_put(&seen, mp, (int64_t)seen.n, &fresh_mp);
+          const long l = s < 0 ? -1 : imap_put(&last, mp, kp, &fresh_kp);
+          if (s < 0 || l < 0) { PyErr_NoMemory(); bad = 1; }
+          else {
+            if (fresh_mp) distinct[seen.val[s]] = mp;
+            last.val[l] = kp;                          /* later rows overwrite: last keypoint wins */
+            cam[n] = (int32_t)ci;
+            first[n] = seen.val[s];
+            kpidx[n] = mp;                             /* resolved to a keypoint index below */
+            ++n;
+          }
+        }
+      }
+      if (own) { Py_DECREF(mp_o); Py_DECREF(kp_o); }
+    }
+    for (Py_ssize_t i = start; i < n && !bad; ++i) {
+      Py_ssize_t kp = (Py_ssize_t)last.val[imap_slot(&last, kpidx[i])];
+      if (kp < 0) kp += PySequence_Fast_GET_SIZE(kps);
+      if (kp < 0 || kp >= PySequence_Fast_GET_SIZE(kps)) { PyErr_SetString(PyExc_IndexError, "keypoint index out of range"); bad = 1; }
+      else if (read_pt(PySequence_Fast_GET_ITEM(kps, kp), &uv[2 * i]) < 0) bad = 1;
+    }
+    Py_DECREF(obs); Py_DECREF(kps);
+    if (bad) goto done;
+  }
+  ok = 1;
+done:
+  free(kpidx);
+  if (seen.key) { if (ok) result = Py_BuildValue("nn", n, (Py_ssize_t)seen.n); imap_free(&seen); }
+  if (last.key) imap_free(&last);
+  Py_XDECREF(ids);
+  PyBuffer_Release(&b_cam); PyBuffer_Release(&b_first); PyBuffer_Release(&b_uv); PyBuffer_Release(&b_distinct);
+  return result;
+}
+
+/* three doubles out of obj.position: a float64 buffer of 3 items in any shape, else a sequence */
+static int read_position(PyObject *obj, double *out) {
+  PyObject *pos = PyObject_GetAttr(obj, s_position);
+  if (!pos) return -1;
+  int rc = -1;
+  Py_buffer b;
+  if (PyObject_CheckBuffer(pos) && PyObject_GetBuffer(pos, &b, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) == 0) {
+    if (b.itemsize == 8 && b.len == 24 && b.format && (strcmp(b.format, "d") == 0 || strcmp(b.format, "<d") == 0)) {
+      memcpy(out, b.buf, 24);
+      rc = 0;
+    }
+    PyBuffer_Release(&b);
+  } else {
+    PyErr_Clear();
+  }
+  if (rc < 0) {   /* generic: flatten via float(pos.ravel()[i]) semantics = iterate nested sequences */
+    PyObject *flat = PyObject_CallMethod(pos, "ravel", NULL);
+    if (!flat) { PyErr_Clear(); flat = pos; Py_INCREF(flat); }
+    PyObject *seq = PySequence_Fast(flat, "position must be array-like");
+    Py_DECREF(flat);
+    if (seq) {
+      if (PySequence_Fast_GET_SIZE(seq) == 3) {
+        rc = 0;
+        for (int i = 0; i < 3 && rc == 0; ++i) rc = as_double(PySequence_Fast_GET_ITEM(seq, i), &out[i]);
+      } else {
+        PyErr_SetString(PyExc_ValueError, "position must have 3 elements");
+      }
+      Py_DECREF(seq);
+    }
+  }
+  Py_DECREF(pos);
+  return rc;
+}
+
+/* gather_positions(map_points, ids[int64 buffer], out[f64 x3 buffer]) */
+static PyObject *gather_positions(PyObject *self, PyObject *args) {
+  PyObject *map_points, *o_ids, *o_out;
+  if (!PyArg_ParseTuple(args, "O!OO", &PyDict_Type, &map_points, &o_ids, &o_out)) return NULL;
+  Py_buffer b_ids, b_out;
+  if (PyObject_GetBuffer(o_ids, &b_ids, PyBUF_C_CONTIGUOUS) < 0) return NULL;
+  if (get_out(o_out, &b_out, 8, "out") < 0) { PyBuffer_Release(&b_ids); return NULL; }
+  PyObject *result = NULL;
+  const Py_ssize_t n = b_ids.len / 8;
+  if (b_ids.itemsize != 8 || b_out.len / 24 < n) {
+    PyErr_SetString(PyExc_ValueError, "ids must be int64 and out hold 3 doubles per id");
+    goto done;
+  }
+  const int64_t *ids = (const int64_t *)b_ids.buf;
+  double *out = (double *)b_out.buf;
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    PyObject *key = PyLong_FromLongLong(ids[i]);
+    if (!key) goto done;
+    PyObject *obj = PyDict_GetItemWithError(map_points, key);   /* borrowed */
+    if (!obj) { if (!PyErr_Occurred()) PyErr_SetObject(PyExc_KeyError, key); Py_DECREF(key); goto done; }
+    Py_DECREF(key);
+    if (read_position(obj, &out[3 * i]) < 0) goto done;
+  }
+  result = Py_None; Py_INCREF(result);
+done:
+  PyBuffer_Release(&b_ids); PyBuffer_Release(&b_out);
+  return result;
+}
+
+static PyMethodDef methods[] = {
+  {"walk_window", walk_window, METH_VARARGS, "walk a keyframe window into flat observation arrays"},
+  {"gather_positions", gather_positions, METH_VARARGS, "copy MapPoint.position of the given ids into (n,3)"},
+  {NULL, NULL, 0, NULL}};
+
+static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_mapwalk", "native walk over Map objects", -1, methods};
+
+PyMODINIT_FUNC PyInit__mapwalk(void) {
+  s_observations = PyUnicode_InternFromString("observations");
+  s_keypoints = PyUnicode_InternFromString("keypoints");
+  s_pt = PyUnicode_InternFromString("pt");
+  s_position = PyUnicode_InternFromString("position");
+  if (!s_observations || !s_keypoints || !s_pt || !s_position) return NULL;
+  return PyModule_Create(&moddef);
+}

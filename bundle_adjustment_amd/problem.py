@@ -96,11 +96,17 @@ def flatten_window(gmap, local_kf_ids, mp_ids, observations, keypoints_2d, camer
     return BAProblem(cams, pts.reshape(-1, 3), cam_idx, pt_idx, uv, K4, fixed_cam=0).validate()
 
 
-def flatten_map_window(gmap, local_kf_ids, camera_matrix):
-    """``gather_window`` + ``flatten_window`` in one array-level pass (no per-observation Python
-    tuples or dict entries): same ``BAProblem`` (same row order, same last-pixel-wins rule for a
-    repeated ``(keyframe, map point)`` pair) plus the sorted map-point ids.  Used by
-    ``BundleAdjuster.run``; the tuple/dict form stays available through ``_gather_local_data``."""
+def _window_cameras(gmap, local_kf_ids, camera_matrix):
+    Rs = np.array([gmap.keyframes[k].R for k in local_kf_ids], dtype=np.float64)
+    ts = np.array([np.asarray(gmap.keyframes[k].t, dtype=np.float64).ravel() for k in local_kf_ids])
+    cams = np.concatenate([matrices_to_rvecs(Rs), ts], axis=1)
+    K = np.asarray(camera_matrix, dtype=np.float64)
+    return cams, np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]])
+
+
+def flatten_map_window_numpy(gmap, local_kf_ids, camera_matrix):
+    """Array-level numpy form of ``flatten_map_window`` (one pass per keyframe, no per-observation
+    tuples or dict entries).  Kept as the plain statement the native walk is tested against."""
     have = gmap.map_points
     have_ids = np.fromiter(have.keys(), dtype=np.int64, count=len(have))
     cam_parts, mp_parts, uv_parts = [], [], []
@@ -131,15 +137,41 @@ def flatten_map_window(gmap, local_kf_ids, camera_matrix):
         return None, []
     mp_all = np.concatenate(mp_parts)
     mp_ids, pt_idx = np.unique(mp_all, return_inverse=True)
-    Rs = np.array([gmap.keyframes[k].R for k in local_kf_ids], dtype=np.float64)
-    ts = np.array([np.asarray(gmap.keyframes[k].t, dtype=np.float64).ravel() for k in local_kf_ids])
-    cams = np.concatenate([matrices_to_rvecs(Rs), ts], axis=1)
+    cams, K4 = _window_cameras(gmap, local_kf_ids, camera_matrix)
     pts = np.array([np.asarray(have[int(m)].position, dtype=np.float64).ravel() for m in mp_ids.tolist()]).reshape(-1, 3)
-    K = np.asarray(camera_matrix, dtype=np.float64)
-    K4 = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]])
     prob = BAProblem(cams, pts, np.concatenate(cam_parts), pt_idx.astype(np.int32), np.concatenate(uv_parts), K4,
                      fixed_cam=0).validate()
     return prob, [int(m) for m in mp_ids.tolist()]
+
+
+def flatten_map_window(gmap, local_kf_ids, camera_matrix):
+    """``gather_window`` + ``flatten_window`` in one pass: same ``BAProblem`` (same row order, same
+    last-pixel-wins rule for a repeated ``(keyframe, map point)`` pair) plus the sorted map-point
+    ids.  The walk over the Map objects runs in the ``_mapwalk`` C extension (``csrc/mapwalk.c``,
+    built by ``__graft_entry__.build()``); what is left here is array work on its outputs.  Used by
+    ``BundleAdjuster.run``; the tuple/dict form stays available through ``_gather_local_data``."""
+    from . import _mapwalk
+    keyframes, have = gmap.keyframes, gmap.map_points
+    cap = sum(len(keyframes[k].observations) for k in local_kf_ids)
+    if cap == 0:
+        return None, []
+    cam_idx = np.empty(cap, dtype=np.int32)
+    first_seen = np.empty(cap, dtype=np.int64)
+    uv = np.empty((cap, 2), dtype=np.float64)
+    distinct = np.empty(cap, dtype=np.int64)
+    nobs, npts = _mapwalk.walk_window(keyframes, have, list(local_kf_ids), cam_idx, first_seen, uv, distinct)
+    if nobs == 0:
+        return None, []
+    distinct = distinct[:npts]
+    order = np.argsort(distinct, kind="stable")          # map-point ids ascending (:210 sorted(...))
+    rank = np.empty(npts, dtype=np.int32)
+    rank[order] = np.arange(npts, dtype=np.int32)
+    mp_ids = distinct[order]
+    pts = np.empty((npts, 3), dtype=np.float64)
+    _mapwalk.gather_positions(have, mp_ids, pts)
+    cams, K4 = _window_cameras(gmap, local_kf_ids, camera_matrix)
+    prob = BAProblem(cams, pts, cam_idx[:nobs], rank[first_seen[:nobs]], uv[:nobs], K4, fixed_cam=0).validate()
+    return prob, mp_ids.tolist()
 
 
 def shard_by_landmark(problem: BAProblem, n_shards: int):

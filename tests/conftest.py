@@ -12,6 +12,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the Map-walk extension is host code (gcc, under a second); build it if this checkout has not yet
+    import __graft_entry__
+    __graft_entry__.build_mapwalk()
 
 
 @pytest.fixture(scope="session")

@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 
 from bundle_adjustment_amd import bundle_adjuster as ba_mod
-from bundle_adjustment_amd.problem import flatten_map_window, flatten_window, gather_window
+from bundle_adjustment_amd.problem import (flatten_map_window, flatten_map_window_numpy, flatten_window,
+                                           gather_window)
 from bundle_adjustment_amd.synthetic import make_problem, problem_to_map
 from tests.fake_solver import OracleSolver
 from tests.helpers import golden_flat_problem, load_golden, rebuild_map
@@ -55,10 +56,64 @@ def test_gather_and_flatten_match_reference_layout(name):
     assert f_ids == mp_ids
     for a, b in ((f.cam_idx, p.cam_idx), (f.pt_idx, p.pt_idx), (f.uv, p.uv), (f.cams, p.cams), (f.pts, p.pts), (f.K4, p.K4)):
         np.testing.assert_array_equal(a, b)
+    n, n_ids = flatten_map_window_numpy(gmap, local, g["K"])
+    assert n_ids == mp_ids
+    for a, b in ((n.cam_idx, p.cam_idx), (n.pt_idx, p.pt_idx), (n.uv, p.uv), (n.cams, p.cams), (n.pts, p.pts)):
+        np.testing.assert_array_equal(a, b)
     na = len(local) - 1
     x0 = np.concatenate([p.cams[1:, :3].ravel(), p.cams[1:, 3:].ravel(), p.pts.ravel()])
     np.testing.assert_allclose(x0, g["x0"], atol=1e-12)
     assert x0.size == 6 * na + 3 * len(mp_ids)
+
+
+def test_native_map_walk_matches_the_tuple_and_dict_walk():
+    """csrc/mapwalk.c against gather_window + flatten_window on a map with everything the reference's
+    walk tolerates: a map point listed twice in one keyframe (last keypoint wins for both rows), culled
+    map points, list rows, a negative keypoint index, positions as (3,1), (3,) and plain lists, sparse and
+    negative ids, an empty keyframe."""
+    rng = np.random.default_rng(11)
+    p = make_problem(6, 300, 4, seed=21)
+    gmap = problem_to_map(p)
+    ids = sorted(gmap.keyframes)
+    kf = gmap.keyframes[ids[1]]
+    first_mp, first_kp = kf.observations[0]
+    kf.observations.append((first_mp, len(kf.keypoints) - 1))            # repeated pair: later keypoint wins
+    kf.observations[3] = list(kf.observations[3])                         # a list row
+    mp5, _ = kf.observations[5]
+    kf.observations[5] = (mp5, -2)                                        # python-style negative index
+    gmap.keyframes[ids[3]].observations = []                              # empty keyframe inside the window
+    for m in rng.choice(sorted(gmap.map_points), 25, replace=False):      # culled points
+        del gmap.map_points[int(m)]
+    keys = sorted(gmap.map_points)
+    gmap.map_points[keys[0]].position = gmap.map_points[keys[0]].position.reshape(3)
+    gmap.map_points[keys[1]].position = [float(v) for v in gmap.map_points[keys[1]].position.ravel()]
+    gmap.map_points[keys[2]].position = np.asfortranarray(gmap.map_points[keys[2]].position.reshape(1, 3)).T
+    # sparse / negative ids: rename two map points everywhere
+    for old, new in ((keys[3], 10**12 + 7), (keys[4], -5)):
+        gmap.map_points[new] = gmap.map_points.pop(old)
+        for k in ids:
+            gmap.keyframes[k].observations = [r if r[0] != old else (new, r[1]) for r in gmap.keyframes[k].observations]
+    K = np.array([[500.0, 0, 320], [0, 510.0, 240], [0, 0, 1]])
+    for local in (ids[:-1], ids[2:5], [ids[3]]):
+        mp_ids, observations, kp2d = gather_window(gmap, local)
+        f, f_ids = flatten_map_window(gmap, local, K)
+        n, n_ids = flatten_map_window_numpy(gmap, local, K)
+        if not mp_ids:
+            assert f is None and f_ids == [] and n is None and n_ids == []
+            continue
+        q = flatten_window(gmap, local, mp_ids, observations, kp2d, K)
+        assert f_ids == mp_ids == n_ids
+        for got in (f, n):
+            assert got.cam_idx.dtype == np.int32 and got.pt_idx.dtype == np.int32
+            for a, b in ((got.cam_idx, q.cam_idx), (got.pt_idx, q.pt_idx), (got.uv, q.uv), (got.cams, q.cams),
+                         (got.pts, q.pts), (got.K4, q.K4)):
+                np.testing.assert_array_equal(a, b)
+    # errors surface as Python exceptions, not crashes
+    gmap.keyframes[ids[1]].observations[-1] = (first_mp, 10**6)            # the winning (last) row of that pair
+    with pytest.raises(IndexError):
+        flatten_map_window(gmap, ids[:-1], K)
+    with pytest.raises(KeyError):
+        flatten_map_window(gmap, [12345], K)
 
 
 @pytest.mark.parametrize("name", ["cost_seed1", "cost_edge"])
