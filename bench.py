@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C5"])
+    ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C5", "C3x10"])
     ap.add_argument("--loss", default="huber", choices=["huber", "linear"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--pcg-tol", type=float, default=0.1)

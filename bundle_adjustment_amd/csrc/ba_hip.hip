@@ -108,6 +108,7 @@ struct DBuf {
 
 struct ba_handle {
   int device = 0;
+  int n_cu = 256;              // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   hipStream_t stream = nullptr;
   bool have_problem = false, have_params = false, linearized = false;
   int lin_robust = 0;
@@ -184,6 +185,8 @@ extern "C" int ba_create(int device_id, ba_handle** out) {
   ba_handle* h = new ba_handle();
   h->device = device_id;
   HIPCHECK(hipSetDevice(device_id));
+  HIPCHECK(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device_id));
+  if (h->n_cu < 1) h->n_cu = 1;
   HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   HIPCHECK(hipEventCreateWithFlags(&h->ev_decide, hipEventDisableTiming));
   HIPCHECK(hipHostMalloc((void**)&h->h_scal, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
@@ -507,11 +510,20 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   memcpy(h->K4, K4, sizeof h->K4);
   h->nblkV = (Nc + VEC_BLOCK - 1) / VEC_BLOCK;
   if (h->nblkV > 4096) return fail(BA_ERR_INVALID, "more than %d cameras are not supported", 4096 * VEC_BLOCK);
-  // point-pass workgroups: contiguous point ranges, one workgroup per CU when the camera windows
-  // are wide (LDS-limited), more when they are narrow
+  // point-pass workgroups: contiguous point ranges, PT_THREADS / LPP points per round.  When the
+  // whole camera table fits in LDS (so a wider range cannot overflow it) no more workgroups are
+  // started than the chip holds at once -- each then walks several rounds with one table fill
+  // (C3 x 10: Schur point pass 133 -> 93 us); with camera windows the ranges stay one round long
+  // so that the windows stay narrow.  BA_PT_BLOCKS overrides (tuning only).
   const int pts_per_pass = PT_THREADS / LPP;
   const int want = std::max(1, (Np + pts_per_pass - 1) / pts_per_pass);
   h->nblkP = std::min(want, 4096);
+  const size_t full_table = (size_t)Nc * TA * sizeof(double);
+  if (full_table <= (size_t)LDS_TAB_BYTES) {
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / PT_THREADS, (size_t)(160 * 1024) / std::max<size_t>(full_table + 1024, 1)));
+    h->nblkP = std::min(h->nblkP, h->n_cu * per_cu);
+  }
+  if (const char* e = getenv("BA_PT_BLOCKS")) h->nblkP = std::max(1, std::min(want, atoi(e)));
   h->ppb = std::max(1, (Np + h->nblkP - 1) / h->nblkP);
   // long tracks: one DPP row (16 lanes) per point in a launch of their own
   std::vector<int> long_pts;

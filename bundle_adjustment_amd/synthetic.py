@@ -22,6 +22,8 @@ CONFIGS = {
     "C1": dict(n_cams=2, n_pts=500, obs_per_pt=2, K4=DESK_K4, image_wh=(848.0, 480.0)),
     "C2": dict(n_cams=50, n_pts=5000, obs_per_pt=6),
     "C3": dict(n_cams=1000, n_pts=100000, obs_per_pt=10),
+    # not a BASELINE config: C3 with ten times the points, to see the same kernels away from the launch floor
+    "C3x10": dict(n_cams=1000, n_pts=1000000, obs_per_pt=10),
 }
 
 
