@@ -286,3 +286,31 @@ def test_fp32_jacobian_mode_reaches_the_fp64_solution(solver):
     assert np.abs(cams - cams_ref).max() <= 1e-6 and np.abs(pts - pts_ref).max() <= 1e-5
     with pytest.raises(hip_backend.BAHipError):
         solver.solve(jacobian_precision=2, **kw)
+
+
+def test_multi_round_point_ranges(solver, monkeypatch):
+    """Large problems give every point-pass workgroup a range of several rounds (one table fill per
+    workgroup, ba_set_problem).  Force that split on a small problem and check every point-pass
+    product against the default one-round split: per-point outputs bit-identical, sums over
+    workgroups to rounding, the solve to 1e-10."""
+    p = make_problem(40, 6000, 6, seed=4, outlier_frac=0.01)
+    v = np.random.default_rng(0).normal(size=(p.n_cams, 6))
+    kw = dict(loss="huber", max_iters=15, ftol=1e-12, xtol=1e-12, gtol=0.0, pcg_tol=1e-2)
+
+    def products():
+        solver.set_problem(p)
+        Hcc, bc, Hpp, bp = solver.linearize("huber")
+        g = solver.schur_rhs(1e-3)
+        Sv = solver.schur_apply(1e-3, v)
+        out = solver.solve(**kw)
+        return Hcc, bc, Hpp, bp, g, Sv, out, solver.get_params()
+
+    ref = products()
+    monkeypatch.setenv("BA_PT_BLOCKS", "3")              # 6000 points / 3 workgroups = 4 rounds of 512 each
+    got = products()
+    monkeypatch.delenv("BA_PT_BLOCKS")
+    for a, b in zip(ref[:4], got[:4]):
+        np.testing.assert_array_equal(a, b)
+    assert _rel(got[4], ref[4]) <= 1e-12 and _rel(got[5], ref[5]) <= 1e-12
+    assert abs(got[6]["final_cost"] - ref[6]["final_cost"]) <= 1e-10 * ref[6]["final_cost"]
+    assert np.abs(got[7][0] - ref[7][0]).max() <= 1e-8 and np.abs(got[7][1] - ref[7][1]).max() <= 1e-7
