@@ -47,7 +47,7 @@ def algorithmic_bytes(n_cams, n_pts, n_obs):
     return b
 
 
-def cpu_baseline_port(prob, budget_s=20.0):
+def cpu_baseline_port(prob, budget_s=15.0):
     """Reference CPU path (per-observation Python loop + 2-point finite differences over
     colour groups + TRF/LSMR, src/bundle_adjuster.py:24-72,170-174) timed on this host,
     single thread, on a bounded sample: the residual sweep is timed on a contiguous
@@ -56,7 +56,7 @@ def cpu_baseline_port(prob, budget_s=20.0):
     NOT timed (so the CPU figure is an upper bound on its throughput)."""
     from oracle import ba_oracle as o
     nobs = prob.n_obs
-    n_sample = min(nobs, 100_000)
+    n_sample = min(nobs, 1_000_000)           # C3: one full residual sweep, about 10 s of CPU work
     obs = [(int(c), int(p)) for c, p in zip(prob.cam_idx[:n_sample], prob.pt_idx[:n_sample])]
     kp = {ob: (float(u), float(v)) for ob, (u, v) in zip(obs, prob.uv[:n_sample])}
     x0, adj = o.pack_reference_params(prob.cams, prob.pts, prob.fixed_cam)

@@ -16,8 +16,10 @@ import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SLOT = {"k_pt_schur<true, 0": "schur_pt", "k_pt_schur<false, 0": "schur_pt",
-        "k_cam_schur<true, false, true>": "schur_cam", "k_cam_schur<false, false, true>": "schur_cam"}
+# the PCG instantiations: k_pt_schur<ROBUST, MODE 0, ALL_LDS, LPP lanes, JT>, k_cam_schur<ROBUST, PCG true, JT>
+SLOT = {"k_pt_schur<true, 0, true, 2,": "schur_pt", "k_pt_schur<false, 0, true, 2,": "schur_pt",
+        "k_pt_schur<true, 0, false, 2,": "schur_pt", "k_pt_schur<false, 0, false, 2,": "schur_pt",
+        "k_cam_schur<true, true,": "schur_cam", "k_cam_schur<false, true,": "schur_cam"}
 
 
 def agg(path, cname):
