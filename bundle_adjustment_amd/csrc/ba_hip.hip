@@ -109,6 +109,7 @@ struct DBuf {
 struct ba_handle {
   int device = 0;
   int n_cu = 256;              // compute units of the device (hipDeviceAttributeMultiprocessorCount)
+  int xcd_ranges = 1;          // point-pass ranges grouped per XCD (BA_XCD_RANGES=0 turns it off; speed only)
   hipStream_t stream = nullptr;
   bool have_problem = false, have_params = false, linearized = false;
   int lin_robust = 0;
@@ -117,6 +118,7 @@ struct ba_handle {
   double K4[4] = {1, 1, 0, 0};
   // observation lists (camera order, point order)
   DBuf<int> offk, c_pt, c_orig, pt_off, p_cam, slot, long_pts;
+  DBuf<int> c_ptf[2], p_camf;  // index streams with the "weights are not (1, 1)" flag (robust loss; c_ptf pairs with c_w)
   int long_thr = 16;           // tracks longer than this get a DPP row each (set in ba_set_problem)
   int n_long = 0, nblkL = 0;   // points with more than LONG_TRACK observations: one DPP row each, own launch
   DBuf<int2> blk_win;          // per point-pass workgroup: first camera and number of cameras its points see
@@ -221,7 +223,8 @@ extern "C" int ba_destroy(ba_handle* h) {
   shm_destroy(h);
   for (auto e : h->ev) (void)hipEventDestroy(e);
   if (h->ev_decide) (void)hipEventDestroy(h->ev_decide);
-  DBuf<int>* ib[] = {&h->offk, &h->c_pt, &h->c_orig, &h->pt_off, &h->p_cam, &h->slot, &h->long_pts};
+  DBuf<int>* ib[] = {&h->offk, &h->c_pt, &h->c_orig, &h->pt_off, &h->p_cam, &h->slot, &h->long_pts, &h->c_ptf[0], &h->c_ptf[1],
+                     &h->p_camf};
   for (auto b : ib) b->release();
   h->blk_win.release();
   DBuf<double2>* d2[] = {&h->c_uv, &h->p_uv, &h->c_w[0], &h->c_w[1], &h->p_w};
@@ -524,6 +527,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     h->nblkP = std::min(h->nblkP, h->n_cu * per_cu);
   }
   if (const char* e = getenv("BA_PT_BLOCKS")) h->nblkP = std::max(1, std::min(want, atoi(e)));
+  if (const char* e = getenv("BA_XCD_RANGES")) h->xcd_ranges = atoi(e) != 0;
   h->ppb = std::max(1, (Np + h->nblkP - 1) / h->nblkP);
   // long tracks: one DPP row (16 lanes) per point in a launch of their own
   std::vector<int> long_pts;
@@ -573,6 +577,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(h->c_pt.alloc(nobs1)); HIPCHECK(h->c_orig.alloc(nobs1)); HIPCHECK(h->p_cam.alloc(nobs1));
   HIPCHECK(h->c_uv.alloc(nobs1)); HIPCHECK(h->p_uv.alloc(nobs1));
   HIPCHECK(h->c_w[0].alloc(nobs1)); HIPCHECK(h->c_w[1].alloc(nobs1)); HIPCHECK(h->p_w.alloc(nobs1));
+  HIPCHECK(h->c_ptf[0].alloc(nobs1)); HIPCHECK(h->c_ptf[1].alloc(nobs1)); HIPCHECK(h->p_camf.alloc(nobs1));
   for (int k = 0; k < 2; ++k) {
     HIPCHECK(h->cams[k].alloc(6 * (size_t)Nc)); HIPCHECK(h->cs[k].alloc(CS * (size_t)Nc));
     HIPCHECK(h->ptab[k].alloc(PT * np1));
@@ -697,7 +702,7 @@ static void launch_lin_cam(ba_handle* h, int which, int buf, bool robust, double
   auto kern = robust ? k_camrow_linearize<true> : k_camrow_linearize<false>;
   hipLaunchKernelGGL(kern, dim3(row_grid(h)), dim3(16 * ROWS), 0, h->stream, h->cs[which].p, h->ptab[which].p, h->offk.p,
                      h->c_pt.p, h->c_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, h->c_w[buf].p,
-                     h->partL[buf].p);
+                     h->c_ptf[buf].p, h->partL[buf].p);
 }
 static void launch_lin_finalize(ba_handle* h) {
   Scope sc(h, BA_K_MISC);
@@ -705,16 +710,16 @@ static void launch_lin_finalize(ba_handle* h) {
                      h->Nc, h->fixed, h->HccBc.p, bc_ptr(h));
 }
 static PtWork pt_work(ba_handle* h) {        // every point; long tracks skipped when they have a launch of their own
-  return PtWork{nullptr, h->Np, h->nblkL ? h->long_thr : 0x7fffffff, 0, h->ppb};
+  return PtWork{nullptr, h->Np, h->nblkL ? h->long_thr : 0x7fffffff, 0, h->ppb, h->xcd_ranges};
 }
-static PtWork pt_work_long(ba_handle* h) { return PtWork{h->long_pts.p, h->n_long, 0x7fffffff, h->nblkP, PT_THREADS / LPP_LONG}; }
+static PtWork pt_work_long(ba_handle* h) { return PtWork{h->long_pts.p, h->n_long, 0x7fffffff, h->nblkP, PT_THREADS / LPP_LONG, 0}; }
 // point half at the current parameters, with the damped inverse / y0 at `lambda` fused in
 static void launch_lin_pt(ba_handle* h, bool robust, double fscale, double lambda) {
   if (h->Np == 0) return;
   Scope sc(h, BA_K_LINEARIZE_PT);
   const int w = h->cur;
 #define LP_ARGS(WK) h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_uv.p, h->blk_win.p, WK, h->K4[0], h->K4[1],    \
-                    h->K4[2], h->K4[3], fscale, lambda, h->Hpp.p, h->bp.p, h->p_w.p, h->Hppinv.p, h->y0.p
+                    h->K4[2], h->K4[3], fscale, lambda, h->Hpp.p, h->bp.p, h->p_w.p, h->p_camf.p, h->Hppinv.p, h->y0.p
 #define LP_LAUNCH(R, L, LN, G, WK) hipLaunchKernelGGL((k_pt_linearize<R, L, LN>), dim3(G), dim3(PT_THREADS), h->lds_bytes, h->stream, LP_ARGS(WK))
   const PtWork wk = pt_work(h), wl = pt_work_long(h);
   if (h->all_lds) { if (robust) LP_LAUNCH(true, true, LPP, h->nblkP, wk); else LP_LAUNCH(false, true, LPP, h->nblkP, wk); }
@@ -737,14 +742,15 @@ static void launch_point_invert(ba_handle* h, double lambda) {
 static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int k, double tol2, int min_iters) {
   Scope sc(h, diag ? BA_K_PRECOND : BA_K_SCHUR_CAM);
   const int w = h->cur;
-#define CS_ARGS h->cs[w].p, h->ptab[w].p, h->offk.p, h->c_pt.p, h->c_w[h->lb].p, h->K4[0], h->K4[1], h->Nc, h->fixed,        \
+#define CS_ARGS h->cs[w].p, h->ptab[w].p, h->offk.p, (robust ? h->c_ptf[h->lb].p : h->c_pt.p), h->c_w[h->lb].p, h->K4[0], h->K4[1], h->Nc, h->fixed,        \
                 h->part6.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->partA.p,                                   \
                 (h->Np > 0 ? h->nblkP + h->nblkL : 0), uy_ptr(h)
   const dim3 g(cam_grid(h) + (pcg ? 1 : 0)), b(64 * WPB);
   if (diag) {
     auto kern = robust ? k_camrow_schur_diag<true> : k_camrow_schur_diag<false>;
     hipLaunchKernelGGL(kern, dim3(row_grid(h)), dim3(16 * ROWS), 0, h->stream, h->cs[w].p, h->ptab[w].p, h->offk.p,
-                       h->c_pt.p, h->c_w[h->lb].p, h->Hppinv.p, h->K4[0], h->K4[1], h->Nc, h->fixed, h->part6.p, h->partE.p);
+                       (robust ? h->c_ptf[h->lb].p : h->c_pt.p), h->c_w[h->lb].p, h->Hppinv.p, h->K4[0], h->K4[1], h->Nc,
+                       h->fixed, h->part6.p, h->partE.p);
   } else if (pcg) {
     if (h->jac_f32) {
       if (robust) hipLaunchKernelGGL((k_cam_schur<true, true, float>), g, b, 0, h->stream, CS_ARGS);
@@ -764,7 +770,7 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
   if (h->Np == 0) return;
   Scope sc(h, mode == 0 ? BA_K_SCHUR_PT : BA_K_BACKSUB);
   const int w = h->cur;
-#define PS_ARGS(WK, FLAG) h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_w.p, h->Hppinv.p, h->blk_win.p, WK, h->K4[0],  \
+#define PS_ARGS(WK, FLAG) h->camA[w].p, h->ptab[w].p, h->pt_off.p, (robust ? h->p_camf.p : h->p_cam.p), h->p_w.p, h->Hppinv.p, h->blk_win.p, WK, h->K4[0],  \
                 h->K4[1], h->fixed, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0.p, h->Hpp.p, h->bp.p,  \
                 h->ptab[1 - w].p, h->partB.p, FLAG, flag_base
   const size_t lds = h->lds_bytes;

@@ -38,6 +38,15 @@ constexpr int LPP = 2;           // lanes per point in point passes (short track
 constexpr int LPP_LONG = 16;     // one DPP row per point for long tracks (threshold chosen per problem)
 constexpr int VEC_BLOCK = 64;    // threads (= cameras) per workgroup in camera-vector kernels
 
+// Flagged index streams.  With a robust loss the linearisation writes, next to the IRLS weights,
+// a copy of each index stream whose top bit says "this observation's weights are not (1, 1)".
+// The Schur passes read that copy and fetch the 16-byte weight only for flagged observations:
+// near the solution most observations are Huber inliers, and the weight streams are otherwise
+// the largest share of a pass's traffic.  Bit-identical results: an unflagged weight IS (1, 1).
+constexpr int IDX_FLAG = (int)0x80000000;
+constexpr int IDX_MASK = 0x7fffffff;
+__device__ inline int flagged_index(int idx, double w0, double w1) { return (w0 != 1.0 || w1 != 1.0) ? (idx | IDX_FLAG) : idx; }
+
 // PCG device state, two copies indexed by iteration parity (see k_pcg_step)
 struct PcgState {
   double gamma_prev, alpha_prev, gamma0, pad0;
@@ -258,16 +267,17 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
   double acc[6] = {0, 0, 0, 0, 0, 0};          // sums always in fp64
   if (s.c != fixed_cam) {
     int i = s.beg + s.lane;
-    int p = (i < s.end) ? c_pt[i] : 0;
+    int pf = (i < s.end) ? c_pt[i] : 0;          // ROBUST: the flagged copy of c_pt
     double2 w = make_double2(1.0, 1.0);
-    if (ROBUST && i < s.end) w = c_w[i];
+    if (ROBUST && pf < 0) w = c_w[i];
     while (i < s.end) {
       const int in = i + 64;
-      const int pn = (in < s.end) ? c_pt[in] : 0;          // prefetch the next index / weight
-      double2 wn = make_double2(1.0, 1.0);
-      if (ROBUST && in < s.end) wn = c_w[in];
+      const int pn = (in < s.end) ? c_pt[in] : 0;          // prefetch the next index
+      const int p = ROBUST ? (pf & IDX_MASK) : pf;
       const double4 Xd = *(const double4*)(ptab + PT * (size_t)p);
       const double4 Yd = *(const double4*)(ptab + PT * (size_t)p + 4);
+      double2 wn = make_double2(1.0, 1.0);                 // next weight, only where it is not (1, 1)
+      if (ROBUST && pn < 0) wn = c_w[in];
       const JT X0 = (JT)Xd.x, X1 = (JT)Xd.y, X2 = (JT)Xd.z, Y0 = (JT)Yd.x, Y1 = (JT)Yd.y, Y2 = (JT)Yd.z;
       GeomT<JT> g;
       obs_geom<JT>(cam, X0, X1, X2, fxj, fyj, g);
@@ -280,7 +290,7 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
       acc[3] -= (double)(g.d00 * s0);
       acc[4] -= (double)(g.d11 * s1);
       acc[5] -= (double)(g.d02 * s0 + g.d12 * s1);
-      i = in; p = pn; w = wn;
+      i = in; pf = pn; w = wn;
     }
   }
   wave_store_sums<6>(acc, s.lane, part6 + ((size_t)s.k * n_cams + s.c) * 6);
@@ -319,7 +329,7 @@ __global__ void __launch_bounds__(16 * ROWS)
 k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
                    const int* __restrict__ c_pt, const double2* __restrict__ c_uv,
                    double fx, double fy, double cx, double cy, double hub_c, int n_cams,
-                   double2* __restrict__ c_w, double* __restrict__ partL) {
+                   double2* __restrict__ c_w, int* __restrict__ c_ptf, double* __restrict__ partL) {
   RowSeg s;
   row_segment(offk, n_cams, s);
   double acc[27];
@@ -346,6 +356,7 @@ k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ pta
         huber(ru, hub_c, t, w0);
         huber(rv, hub_c, t, w1);
         c_w[i] = make_double2(w0, w1);
+        c_ptf[i] = flagged_index(p, w0, w1);
       }
       double J0[6], J1[6];
       cam_jac_rows(g, X.x, X.y, X.z, J0, J1);
@@ -383,16 +394,17 @@ k_camrow_schur_diag(const double* __restrict__ cs, const double* __restrict__ pt
     double cam[12];
     load_cam12(cs, s.c, cam);
     int i = s.beg + s.l16;
-    int p = (i < s.end) ? c_pt[i] : 0;
+    int pf = (i < s.end) ? c_pt[i] : 0;          // ROBUST: the flagged copy of c_pt
     double2 w = make_double2(1.0, 1.0);
-    if (ROBUST && i < s.end) w = c_w[i];
+    if (ROBUST && pf < 0) w = c_w[i];
     while (i < s.end) {
       const int in = i + 16;
       const int pn = (in < s.end) ? c_pt[in] : 0;
-      double2 wn = make_double2(1.0, 1.0);
-      if (ROBUST && in < s.end) wn = c_w[in];
+      const int p = ROBUST ? (pf & IDX_MASK) : pf;
       const double4 X = *(const double4*)(ptab + PT * (size_t)p);
       const double4 Y = *(const double4*)(ptab + PT * (size_t)p + 4);
+      double2 wn = make_double2(1.0, 1.0);
+      if (ROBUST && pn < 0) wn = c_w[in];
       Geom g;
       obs_geom(cam, X.x, X.y, X.z, fx, fy, g);
       const double s0 = -(g.P[0] * Y.x + g.P[1] * Y.y + g.P[2] * Y.z) * w.x;
@@ -422,7 +434,7 @@ k_camrow_schur_diag(const double* __restrict__ cs, const double* __restrict__ pt
 #pragma unroll
         for (int b = a; b < 6; ++b) acc[6 + U6(a, b)] += l0 * J0[b] + l1 * J1[b];
       }
-      i = in; p = pn; w = wn;
+      i = in; pf = pn; w = wn;
     }
   }
 #pragma unroll
@@ -495,7 +507,20 @@ __device__ inline void block_combine(double (&v)[N], double* __restrict__ sm) {
 // Work list of a point-pass launch.  Range mode (plist == nullptr): slot s is point s, points
 // with more than skip_thr observations are left to the long-track launch.  List mode: slot s is
 // point plist[s] (the long tracks, LANES = 16: one DPP row per point).
-struct PtWork { const int* plist; int n_slots; int skip_thr; int blk_base; int slots_per_block; };
+struct PtWork { const int* plist; int n_slots; int skip_thr; int blk_base; int slots_per_block; int xcd_ranges; };
+
+// Range a point-pass workgroup works on.  Workgroups are dealt round-robin over the NPART XCDs
+// (measured: XCC_ID = blockIdx % 8); with xcd_ranges the ranges of one XCD are consecutive, so XCD x
+// reads and writes the x-th eighth of the point table -- the same slice its camera-pass partition x
+// gathers from, which keeps y and X in that XCD's L2 between the two passes.  Speed only: the
+// range -> partial-sum slot mapping does not change, so results are bit-identical either way.
+__device__ inline int pt_range_of_block(int b, int n, int xcd_ranges) {
+  if (!xcd_ranges) return b;
+  const int x = b % NPART;
+  int start = 0;
+  for (int q = 0; q < x; ++q) start += (n - q + NPART - 1) / NPART;   // workgroups with blockIdx % NPART == q
+  return start + b / NPART;
+}
 
 template <int LANES>
 __device__ inline double lanes_sum(double x) {      // last lane of every LANES-group ends with the group sum
@@ -514,14 +539,15 @@ k_pt_linearize(const double* __restrict__ camA, double* __restrict__ ptab, const
                const int* __restrict__ p_cam, const double2* __restrict__ p_uv, const int2* __restrict__ blk_win,
                PtWork wk, double fx, double fy, double cx, double cy, double hub_c,
                double lambda, double* __restrict__ Hpp, double* __restrict__ bp, double2* __restrict__ p_w,
-               double* __restrict__ Hppinv, double* __restrict__ y0) {
+               int* __restrict__ p_camf, double* __restrict__ Hppinv, double* __restrict__ y0) {
   extern __shared__ double tab[];
-  const int2 win = blk_win[wk.blk_base + blockIdx.x];
+  const int rb = pt_range_of_block(blockIdx.x, gridDim.x, wk.xcd_ranges);
+  const int2 win = blk_win[wk.blk_base + rb];
   const bool use_lds = ALL_LDS || (size_t)win.y * TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
   if (use_lds) fill_cam_table<PT_THREADS>(tab, camA, win.x, win.y);
   const int sub = threadIdx.x % LANES;
-  const int send = min(wk.n_slots, (int)(blockIdx.x + 1) * wk.slots_per_block);
-  for (int sb = blockIdx.x * wk.slots_per_block; sb < send; sb += PT_THREADS / LANES) {
+  const int send = min(wk.n_slots, (rb + 1) * wk.slots_per_block);
+  for (int sb = rb * wk.slots_per_block; sb < send; sb += PT_THREADS / LANES) {
     const int sl = sb + threadIdx.x / LANES;
     int p = -1, beg = 0, end = 0;
     if (sl < send) {
@@ -551,6 +577,7 @@ k_pt_linearize(const double* __restrict__ camA, double* __restrict__ ptab, const
           huber(ru, hub_c, t, w0);
           huber(rv, hub_c, t, w1);
           p_w[j] = make_double2(w0, w1);
+          p_camf[j] = flagged_index(c, w0, w1);
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -637,15 +664,16 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
     }
     if (fin) return;
   }
-  const int2 win = blk_win[wk.blk_base + blockIdx.x];
+  const int rb = pt_range_of_block(blockIdx.x, gridDim.x, wk.xcd_ranges);
+  const int2 win = blk_win[wk.blk_base + rb];
   const bool use_lds = ALL_LDS || (size_t)win.y * TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
   const int sub = threadIdx.x % LANES;
   double acc[4] = {0, 0, 0, 0};
-  const int send = min(wk.n_slots, (int)(blockIdx.x + 1) * wk.slots_per_block);
+  const int send = min(wk.n_slots, (rb + 1) * wk.slots_per_block);
   bool table_ready = !use_lds;
-  for (int sb = blockIdx.x * wk.slots_per_block; sb < send; sb += PT_THREADS / LANES) {
+  for (int sb = rb * wk.slots_per_block; sb < send; sb += PT_THREADS / LANES) {
     const int sl = sb + threadIdx.x / LANES;
-    int p = -1, j = 0, end = 0, c = 0;
+    int p = -1, j = 0, end = 0, c = 0, cn = 0;   // ROBUST: p_cam is the flagged copy
     double u[3] = {0, 0, 0};
     double4 X = make_double4(0, 0, 0, 0);
     double hi[6] = {0, 0, 0, 0, 0, 0};
@@ -659,7 +687,8 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
         X = *(const double4*)(ptab + PT * (size_t)p);
         j = beg + sub;
         c = (j < end) ? p_cam[j] : 0;
-        if (ROBUST && j < end) w = p_w[j];
+        cn = (j + LANES < end) ? p_cam[j + LANES] : 0;
+        if (ROBUST && c < 0) w = p_w[j];
         if (sub == LANES - 1) {
           const double2* hp = (const double2*)(Hppinv + 6 * (size_t)p);
           const double2 h01 = hp[0], h23 = hp[1], h45 = hp[2];
@@ -670,13 +699,15 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
     if (!table_ready) { fill_cam_table<PT_THREADS>(tab, camA, win.x, win.y); table_ready = true; }
     if (p >= 0) {
       while (j < end) {
-        const int jn = j + LANES;
-        const int cn = (jn < end) ? p_cam[jn] : 0;
+        // index two observations ahead, weight (only where it is not (1, 1)) one ahead
+        const int jn = j + LANES, jnn = jn + LANES;
+        const int cnn = (jnn < end) ? p_cam[jnn] : 0;
         double2 wn = make_double2(1.0, 1.0);
-        if (ROBUST && jn < end) wn = p_w[jn];
-        if (c != fixed_cam) {
+        if (ROBUST && cn < 0) wn = p_w[jn];
+        const int cc = ROBUST ? (c & IDX_MASK) : c;
+        if (cc != fixed_cam) {
           double rowd[TA];
-          load_cam_row<TA>(use_lds, tab, camA, win.x, c, rowd);
+          load_cam_row<TA>(use_lds, tab, camA, win.x, cc, rowd);
           JT row[TA];                            // Jacobian blocks in JT (double, or float for config 5)
 #pragma unroll
           for (int q = 0; q < TA; ++q) row[q] = (JT)rowd[q];
@@ -691,7 +722,7 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
           u[1] -= (double)(g.P[1] * s0 + g.P[4] * s1);
           u[2] -= (double)(g.P[2] * s0 + g.P[5] * s1);
         }
-        j = jn; c = cn; w = wn;
+        j = jn; c = cn; cn = cnn; w = wn;
       }
     }
 #pragma unroll
@@ -722,8 +753,8 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
   for (int q = 0; q < 4; ++q) acc[q] = wave_total_dpp(acc[q]);
   block_combine<4, PT_THREADS>(acc, sm);
   if (threadIdx.x == 0) {
-    if (MODE == 0) partA[wk.blk_base + blockIdx.x] = acc[0];
-    else { for (int q = 0; q < 4; ++q) partB[4 * (wk.blk_base + blockIdx.x) + q] = acc[q]; }
+    if (MODE == 0) partA[wk.blk_base + rb] = acc[0];
+    else { for (int q = 0; q < 4; ++q) partB[4 * (wk.blk_base + rb) + q] = acc[q]; }
   }
 }
 
