@@ -355,8 +355,9 @@ k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ pta
         double t;
         huber(ru, hub_c, t, w0);
         huber(rv, hub_c, t, w1);
-        c_w[i] = make_double2(w0, w1);
-        c_ptf[i] = flagged_index(p, w0, w1);
+        const int pfl = flagged_index(p, w0, w1);
+        c_ptf[i] = pfl;
+        if (pfl < 0) c_w[i] = make_double2(w0, w1);        // unflagged weights are never read
       }
       double J0[6], J1[6];
       cam_jac_rows(g, X.x, X.y, X.z, J0, J1);
@@ -576,8 +577,9 @@ k_pt_linearize(const double* __restrict__ camA, double* __restrict__ ptab, const
           double t;
           huber(ru, hub_c, t, w0);
           huber(rv, hub_c, t, w1);
-          p_w[j] = make_double2(w0, w1);
-          p_camf[j] = flagged_index(c, w0, w1);
+          const int cfl = flagged_index(c, w0, w1);
+          p_camf[j] = cfl;
+          if (cfl < 0) p_w[j] = make_double2(w0, w1);      // unflagged weights are never read
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
