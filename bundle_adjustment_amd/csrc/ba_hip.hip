@@ -511,8 +511,8 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   }
   h->Nc = Nc; h->Np = Np; h->Nobs = No; h->fixed = fixed_cam;
   memcpy(h->K4, K4, sizeof h->K4);
-  h->nblkV = (Nc + VEC_BLOCK - 1) / VEC_BLOCK;
-  if (h->nblkV > 4096) return fail(BA_ERR_INVALID, "more than %d cameras are not supported", 4096 * VEC_BLOCK);
+  h->nblkV = (Nc + VEC_CAMS - 1) / VEC_CAMS;
+  if (h->nblkV > 16384) return fail(BA_ERR_INVALID, "more than %d cameras are not supported", 16384 * VEC_CAMS);
   // point-pass workgroups: contiguous point ranges, PT_THREADS / LPP points per round.  When the
   // whole camera table fits in LDS (so a wider range cannot overflow it) no more workgroups are
   // started than the chip holds at once -- each then walks several rounds with one table fill

@@ -36,7 +36,12 @@ constexpr int TA = 18;           // doubles per camera in camA: R[9] t[3] vtil[6
 constexpr int PT_THREADS = 1024; // threads per workgroup in point passes
 constexpr int LPP = 2;           // lanes per point in point passes (short tracks)
 constexpr int LPP_LONG = 16;     // one DPP row per point for long tracks (threshold chosen per problem)
-constexpr int VEC_BLOCK = 64;    // threads (= cameras) per workgroup in camera-vector kernels
+constexpr int VEC_BLOCK = 64;    // threads per workgroup in camera-vector kernels (one wave)
+#ifndef BA_VEC_CAMS
+#define BA_VEC_CAMS 16
+#endif
+constexpr int VEC_CAMS = BA_VEC_CAMS;   // cameras per workgroup: a thread per camera reads hundreds of strided words, i.e. one
+                                        // cache line per lane per load; 16 live lanes per wave spread that over 4x the CUs
 
 // Flagged index streams.  With a robust loss the linearisation writes, next to the IRLS weights,
 // a copy of each index stream whose top bit says "this observation's weights are not (1, 1)".
@@ -46,6 +51,10 @@ constexpr int VEC_BLOCK = 64;    // threads (= cameras) per workgroup in camera-
 constexpr int IDX_FLAG = (int)0x80000000;
 constexpr int IDX_MASK = 0x7fffffff;
 __device__ inline int flagged_index(int idx, double w0, double w1) { return (w0 != 1.0 || w1 != 1.0) ? (idx | IDX_FLAG) : idx; }
+
+__device__ inline int vec_camera(int n_cams) {      // camera of this thread in a camera-vector kernel, n_cams = none
+  return (threadIdx.x < VEC_CAMS) ? (int)(blockIdx.x * VEC_CAMS + threadIdx.x) : n_cams;
+}
 
 // PCG device state, two copies indexed by iteration parity (see k_pcg_step)
 struct PcgState {
@@ -206,7 +215,7 @@ __device__ inline void lin_finalize_camera(const double* __restrict__ partL, con
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_lin_finalize(const double* __restrict__ partL, const double* __restrict__ cs, int n_cams, int fixed_cam,
                double* __restrict__ Hcc, double* __restrict__ bc) {
-  const int c = blockIdx.x * VEC_BLOCK + threadIdx.x;
+  const int c = vec_camera(n_cams);
   if (c >= n_cams) return;
   lin_finalize_camera(partL, cs + CS * c, n_cams, c, fixed_cam, Hcc + 21 * c, bc + 6 * c);
 }
@@ -223,12 +232,16 @@ __device__ inline void publish_flag(long long* __restrict__ host_flag, long long
   __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Called by whole waves (all 64 lanes live): the nblkV partial pairs are summed lane-strided, then
+// across the wave -- a fixed order, the same in every wave of every kernel.
 __device__ inline bool pcg_finished(int k, const PcgState* __restrict__ st, const double* __restrict__ partV,
                                     int nblkV, double tol2, int min_iters, double& gamma, double& zeta) {
   const PcgState& s = st[k & 1];
-  const double* pv = partV + (size_t)(k & 1) * 2 * nblkV;
+  const double2* pv = (const double2*)(partV + (size_t)(k & 1) * 2 * nblkV);
   double g = 0, z = 0;
-  for (int b = 0; b < nblkV; ++b) { g += pv[2 * b]; z += pv[2 * b + 1]; }
+  for (int b = threadIdx.x & 63; b < nblkV; b += 64) { const double2 t = pv[b]; g += t.x; z += t.y; }
+  g = wave_total_dpp(g);
+  z = wave_total_dpp(z);
   gamma = g; zeta = z;
   if (s.done) return true;
   const double g0 = (k == 0) ? g : s.gamma0;
@@ -785,7 +798,7 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
             double* __restrict__ s, double* __restrict__ z, double* __restrict__ vtil,
             double* __restrict__ partV, PcgState* __restrict__ st) {
   __shared__ double sm[2];
-  const int c = blockIdx.x * VEC_BLOCK + threadIdx.x;
+  const int c = vec_camera(n_cams);
   double acc[2] = {0, 0};
   if (c < n_cams) {
     const double* M = cs + CS * c + 12;
@@ -883,7 +896,7 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) publish_flag(host_flag, flag_base + k + 1, 0);   // verdict: keep going
   const double alpha = gamma / denom;
-  const int c = blockIdx.x * VEC_BLOCK + threadIdx.x;
+  const int c = vec_camera(n_cams);
   double acc[2] = {0, 0};
   if (c < n_cams && c != fixed_cam) {
     const double* M = cs + CS * c + 12;
@@ -933,7 +946,7 @@ k_cam_update(const double* __restrict__ cams, const double* __restrict__ dc, con
              const double* __restrict__ Hcc, const double* __restrict__ bc, const double* __restrict__ cs,
              int n_cams, int fixed_cam, double* __restrict__ cams_trial, double* __restrict__ cs_trial,
              double* __restrict__ vtil, double* __restrict__ camA_trial, double* __restrict__ partC) {
-  const int c = blockIdx.x * VEC_BLOCK + threadIdx.x;
+  const int c = vec_camera(n_cams);
   double acc[5] = {0, 0, 0, 0, 0};
   if (c < n_cams) {
     double d[6];
@@ -994,12 +1007,14 @@ k_scalars(const double* __restrict__ partR, int nR, const double* __restrict__ p
     const int slot = threadIdx.x < 2 ? S_SSE + threadIdx.x : (threadIdx.x < 6 ? S_PT_GD + (threadIdx.x - 2) : S_CAM_GD + (threadIdx.x - 6));
     res[slot] = t;
   }
-  if (threadIdx.x == 64 && st) {
+  if (wv == 1 && st) {                       // whole wave: pcg_finished sums across its lanes
     double g, z;
     const bool fin = pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z);
-    const PcgState& s = st[kit & 1];
-    res[S_PCG_FIN] = fin ? 1.0 : 0.0;
-    res[S_PCG_ITERS] = s.done ? (double)s.iters : (double)kit;
+    if (lane == 0) {
+      const PcgState& s = st[kit & 1];
+      res[S_PCG_FIN] = fin ? 1.0 : 0.0;
+      res[S_PCG_ITERS] = s.done ? (double)s.iters : (double)kit;
+    }
   }
   __syncthreads();
   if (threadIdx.x < S_COUNT) {

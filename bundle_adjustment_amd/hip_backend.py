@@ -14,7 +14,7 @@ import numpy as np
 from .problem import BAProblem
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libba_hip.so")
+LIB_PATH = os.environ.get("BA_HIP_LIB") or os.path.join(_HERE, "libba_hip.so")   # BA_HIP_LIB: another build of the same ABI
 
 LOSS = {"linear": 0, "huber": 1}
 PRECOND = {"jacobi": 0, "schur_jacobi": 1}
