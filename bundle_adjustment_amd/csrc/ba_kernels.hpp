@@ -256,10 +256,22 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
             double fx, double fy, int n_cams, int fixed_cam, double* __restrict__ part6,
             int kit, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2,
             int min_iters, const double* __restrict__ partA, int nblkA, double* __restrict__ uy) {
+  // segment bounds and camera state are fetched before the PCG verdict is known: one round trip
+  // less on the way to the first gather (an early-exit launch wastes a few loads)
+  const bool extra = PCG && blockIdx.x == gridDim.x - 1;   // extra workgroup: folds the point pass's u.y partials
+  Seg s;
+  s.c = 0; s.k = 0; s.beg = 0; s.end = 0; s.lane = threadIdx.x & 63;
+  const bool live = !extra && cam_segment(offk, n_cams, s);
+  JT cam[12];                                  // Jacobian blocks in JT (double, or float for config 5)
+  if (live) {
+    const double* camd = cs + CS * s.c;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) cam[q] = (JT)camd[q];
+  }
   if (PCG) {
     double g, z;
     if (pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z)) return;
-    if (blockIdx.x == gridDim.x - 1) {      // extra workgroup: u.y = sum of the point pass's block partials
+    if (extra) {
       __shared__ double smu[WPB];
       double a = 0.0;
       for (int b = threadIdx.x; b < nblkA; b += 64 * WPB) a += partA[b];
@@ -270,12 +282,7 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
       return;
     }
   }
-  Seg s;
-  if (!cam_segment(offk, n_cams, s)) return;
-  const double* camd = cs + CS * s.c;
-  JT cam[12];                                  // Jacobian blocks in JT (double, or float for config 5)
-#pragma unroll
-  for (int q = 0; q < 12; ++q) cam[q] = (JT)camd[q];
+  if (!live) return;
   const JT fxj = (JT)fx, fyj = (JT)fy;
   double acc[6] = {0, 0, 0, 0, 0, 0};          // sums always in fp64
   if (s.c != fixed_cam) {
@@ -668,6 +675,18 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
            long long* __restrict__ host_flag, long long flag_base) {
   extern __shared__ double tab[];
   __shared__ double sm[4 * (PT_THREADS / 64)];
+  // the workgroup's window and the first round's track bounds are fetched before the PCG verdict
+  // is known: one round trip less on the way to the first camera row
+  const int rb = pt_range_of_block(blockIdx.x, gridDim.x, wk.xcd_ranges);
+  const int2 win = blk_win[wk.blk_base + rb];
+  const int send = min(wk.n_slots, (rb + 1) * wk.slots_per_block);
+  const int sb0 = rb * wk.slots_per_block;
+  int p0 = -1, beg0 = 0, end0 = 0;
+  if (sb0 + (int)(threadIdx.x / LANES) < send) {
+    p0 = wk.plist ? wk.plist[sb0 + threadIdx.x / LANES] : sb0 + (int)(threadIdx.x / LANES);
+    beg0 = pt_off[p0];
+    end0 = pt_off[p0 + 1];
+  }
   if (MODE == 0) {
     double g, z;
     const bool fin = pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z);
@@ -679,14 +698,11 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
     }
     if (fin) return;
   }
-  const int rb = pt_range_of_block(blockIdx.x, gridDim.x, wk.xcd_ranges);
-  const int2 win = blk_win[wk.blk_base + rb];
   const bool use_lds = ALL_LDS || (size_t)win.y * TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
   const int sub = threadIdx.x % LANES;
   double acc[4] = {0, 0, 0, 0};
-  const int send = min(wk.n_slots, (rb + 1) * wk.slots_per_block);
   bool table_ready = !use_lds;
-  for (int sb = rb * wk.slots_per_block; sb < send; sb += PT_THREADS / LANES) {
+  for (int sb = sb0; sb < send; sb += PT_THREADS / LANES) {
     const int sl = sb + threadIdx.x / LANES;
     int p = -1, j = 0, end = 0, c = 0, cn = 0;   // ROBUST: p_cam is the flagged copy
     double u[3] = {0, 0, 0};
@@ -694,9 +710,13 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
     double hi[6] = {0, 0, 0, 0, 0, 0};
     double2 w = make_double2(1.0, 1.0);
     if (sl < send) {                     // first loads of the index stream go out before the table fill
-      p = wk.plist ? wk.plist[sl] : sl;
-      const int beg = pt_off[p];
-      end = pt_off[p + 1];
+      int beg;
+      if (sb == sb0) { p = p0; beg = beg0; end = end0; }
+      else {
+        p = wk.plist ? wk.plist[sl] : sl;
+        beg = pt_off[p];
+        end = pt_off[p + 1];
+      }
       if (end - beg > wk.skip_thr) { p = -1; end = 0; }     // long track: list-mode launch
       else {
         X = *(const double4*)(ptab + PT * (size_t)p);
@@ -868,6 +888,22 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
            double* __restrict__ x, double* __restrict__ r, double* __restrict__ p, double* __restrict__ s,
            double* __restrict__ z, double* __restrict__ vtil, double* __restrict__ partV, int nblkV,
            PcgState* __restrict__ st, long long* __restrict__ host_flag, long long flag_base) {
+  // every operand is fetched before the verdict is known (one round trip for the whole kernel; an
+  // early-exit launch wastes the loads)
+  const int c = vec_camera(n_cams);
+  const bool live = c < n_cams && c != fixed_cam;
+  double h[21], mi[21], zz[6], wy[6], pp[6], ss[6], rr[6], xx[6];
+  const double uy = uy_src[0];
+  if (live) {
+    const double* M = cs + CS * c + 12;
+#pragma unroll
+    for (int q = 0; q < 21; ++q) { h[q] = Hccd[21 * c + q]; mi[q] = Minv[21 * c + q]; }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      zz[q] = z[6 * c + q]; pp[q] = p[6 * c + q]; ss[q] = s[6 * c + q]; rr[q] = r[6 * c + q]; xx[q] = x[6 * c + q];
+    }
+    combine_wy(part6, nparts, n_cams, c, M, wy);
+  }
   double gamma, zeta;
   const bool fin = pcg_finished(k, st, partV, nblkV, tol2, min_iters, gamma, zeta);
   const PcgState sin = st[k & 1];
@@ -881,7 +917,6 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
     }
     return;
   }
-  const double uy = uy_src[0];
   const double delta = zeta - uy;
   const double beta = (k == 0) ? 0.0 : gamma / sin.gamma_prev;
   const double denom = (k == 0) ? delta : delta - beta * gamma / sin.alpha_prev;
@@ -896,25 +931,23 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) publish_flag(host_flag, flag_base + k + 1, 0);   // verdict: keep going
   const double alpha = gamma / denom;
-  const int c = vec_camera(n_cams);
   double acc[2] = {0, 0};
-  if (c < n_cams && c != fixed_cam) {
+  if (live) {
     const double* M = cs + CS * c + 12;
-    double zz[6], w[6], wy[6], pp[6], ss[6], rr[6], hz[6], h[21];
-    for (int q = 0; q < 21; ++q) h[q] = Hccd[21 * c + q];
-    for (int q = 0; q < 6; ++q) zz[q] = z[6 * c + q];
+    double w[6], hz[6];
     sym6_mul(h, zz, w);
-    combine_wy(part6, nparts, n_cams, c, M, wy);
+#pragma unroll
     for (int q = 0; q < 6; ++q) {
       w[q] -= wy[q];
-      pp[q] = zz[q] + beta * p[6 * c + q];
-      ss[q] = w[q] + beta * s[6 * c + q];
-      x[6 * c + q] += alpha * pp[q];
-      rr[q] = r[6 * c + q] - alpha * ss[q];
+      pp[q] = zz[q] + beta * pp[q];
+      ss[q] = w[q] + beta * ss[q];
+      x[6 * c + q] = xx[q] + alpha * pp[q];
+      rr[q] -= alpha * ss[q];
       p[6 * c + q] = pp[q]; s[6 * c + q] = ss[q]; r[6 * c + q] = rr[q];
     }
-    sym6_mul(Minv + 21 * c, rr, zz);
+    sym6_mul(mi, rr, zz);
     sym6_mul(h, zz, hz);
+#pragma unroll
     for (int q = 0; q < 6; ++q) {
       z[6 * c + q] = zz[q];
       acc[0] += rr[q] * zz[q];
