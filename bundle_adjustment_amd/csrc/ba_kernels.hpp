@@ -1013,6 +1013,16 @@ k_scalars(const double* __restrict__ partR, int nR, const double* __restrict__ p
           const double* __restrict__ partV, int nblkV, double tol2, int min_iters,
           double* __restrict__ scal, double* __restrict__ scal_host, long long* __restrict__ host_flag, long long seq) {
   __shared__ double sm[11 * 16];
+  // PCG verdict first (wave 1, whole wave: pcg_finished sums across its lanes): its loads are in
+  // flight while the partial sums below are read
+  bool pcg_fin = false;
+  double pcg_iters = 0.0;
+  if ((threadIdx.x >> 6) == 1 && st) {
+    double g, z;
+    pcg_fin = pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z);
+    const PcgState& s = st[kit & 1];
+    pcg_iters = s.done ? (double)s.iters : (double)kit;
+  }
   double a[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int i = threadIdx.x; i < nR; i += 1024) { const double2 t = ((const double2*)partR)[i]; a[0] += t.x; a[1] += t.y; }
   for (int i = threadIdx.x; i < nB; i += 1024) {
@@ -1040,14 +1050,9 @@ k_scalars(const double* __restrict__ partR, int nR, const double* __restrict__ p
     const int slot = threadIdx.x < 2 ? S_SSE + threadIdx.x : (threadIdx.x < 6 ? S_PT_GD + (threadIdx.x - 2) : S_CAM_GD + (threadIdx.x - 6));
     res[slot] = t;
   }
-  if (wv == 1 && st) {                       // whole wave: pcg_finished sums across its lanes
-    double g, z;
-    const bool fin = pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z);
-    if (lane == 0) {
-      const PcgState& s = st[kit & 1];
-      res[S_PCG_FIN] = fin ? 1.0 : 0.0;
-      res[S_PCG_ITERS] = s.done ? (double)s.iters : (double)kit;
-    }
+  if (wv == 1 && st && lane == 0) {
+    res[S_PCG_FIN] = pcg_fin ? 1.0 : 0.0;
+    res[S_PCG_ITERS] = pcg_iters;
   }
   __syncthreads();
   if (threadIdx.x < S_COUNT) {
