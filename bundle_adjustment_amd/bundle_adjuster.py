@@ -122,11 +122,13 @@ class BundleAdjuster:
         if rotations is None:
             from .rotations import rvecs_to_matrices
             rotations = rvecs_to_matrices(rvecs)
+        keyframes, map_points = gmap.keyframes, gmap.map_points
         for i, kf_id in enumerate(adjustable_kf_ids):
-            gmap.keyframes[kf_id].R = np.array(rotations[i], dtype=np.float64).reshape(3, 3)
-            gmap.keyframes[kf_id].t = tvecs[i].reshape(3, 1).copy()
-        for i, mp_id in enumerate(local_map_point_ids):
-            gmap.map_points[mp_id].position = pts[i].reshape(3, 1).copy()
+            keyframes[kf_id].R = np.array(rotations[i], dtype=np.float64).reshape(3, 3)
+            keyframes[kf_id].t = tvecs[i].reshape(3, 1).copy()
+        # like the reference (:239-240) every position is a (3,1) view into the one result array
+        for mp_id, pos in zip(local_map_point_ids, pts.reshape(-1, 3, 1)):
+            map_points[mp_id].position = pos
 
     # -- the solve step -------------------------------------------------------------------
     def run(self, gmap: Map):
