@@ -217,7 +217,9 @@ def main():
     roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     algorithmic_bytes_per_launch=ab[dom], mean_launch_us=round(dom_us, 3),
-                    launches=prof[dom]["working_launches"], early_exit_launches=prof[dom]["launches"] - prof[dom]["working_launches"])
+                    launches=prof[dom]["working_launches"], early_exit_launches=prof[dom]["launches"] - prof[dom]["working_launches"],
+                    # what rocprofv3 --stats averages: every launch of the kernel, early exits included
+                    mean_launch_us_all_launches=round(prof[dom]["mean_us"], 3))
 
     line = None
     if rank == 0:
