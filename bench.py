@@ -220,6 +220,12 @@ def main():
                     launches=prof[dom]["working_launches"], early_exit_launches=prof[dom]["launches"] - prof[dom]["working_launches"],
                     # what rocprofv3 --stats averages: every launch of the kernel, early exits included
                     mean_launch_us_all_launches=round(prof[dom]["mean_us"], 3))
+    # SURVEY.md 8(d)'s whole-iteration figure: B_iter = B_lin + K_pcg B_pcg + B_back + B_eval over the timed wall time
+    k_pcg = out["pcg_iterations"] / max(steps_done, 1)
+    b_iter = ab["lin"] + k_pcg * ab["pcg_iter"] + ab["back"] + ab["evalc"]
+    iter_gbs = b_iter / (dt / max(steps_done, 1)) / 1e9
+    roofline["lm_iteration"] = dict(algorithmic_bytes=round(b_iter), achieved=round(iter_gbs, 1),
+                                    frac=round(iter_gbs / HBM_PEAK_GBS, 4))
 
     line = None
     if rank == 0:
