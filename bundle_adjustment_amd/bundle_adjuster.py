@@ -15,7 +15,12 @@ Differences, by design:
 * the intermediate ``.pcd`` snapshot (``:187-193``) is written as a plain ASCII PCD, only
   when the ``DEBUG_DIRS['lba_steps']`` directory exists (no open3d dependency);
 * extra keyword arguments select solver options; their defaults are the reference's
-  literals (``loss='huber'``, ``xtol = ftol = 1e-5``, at most 50 evaluations).
+  literals (``loss='huber'``, ``xtol = ftol = 1e-5``, at most 50 evaluations);
+* ``comm=(rank, world, unique_id)`` makes ``run`` SPMD over ``world`` processes, one GPU each
+  (SURVEY.md section 8e): every rank calls ``run`` with an identical map, solves its landmark shard
+  (the library all-reduces the reduced camera system), gathers all points and writes the whole map
+  back, so the ranks' maps stay identical.  ``unique_id`` = ``hip_backend.comm_unique_id()`` of
+  rank 0, shipped by the caller (any transport).
 """
 from __future__ import annotations
 
@@ -26,20 +31,21 @@ import numpy as np
 from . import hip_backend
 from .map_structures import Map
 from .parameters import DEBUG_DIRS
-from .problem import BAProblem, flatten_map_window, gather_window
+from .problem import BAProblem, extract_shard, flatten_map_window, gather_window, shard_by_landmark
 from .rotations import matrices_to_rvecs
 
 
 class BundleAdjuster:
     def __init__(self, camera_matrix, window_size=5, *, device_id=0, loss='huber', f_scale=1.0, ftol=1e-5,
                  xtol=1e-5, gtol=1e-8, max_iters=50, pcg_tol=0.1, pcg_max_iters=200, preconditioner='schur_jacobi',
-                 sparsity_plot_hook=None, verbose=0):
+                 jacobian='f64', comm=None, sparsity_plot_hook=None, verbose=0):
         self.camera_matrix = camera_matrix
         self.window_size = window_size
         self.device_id = device_id
         self.solver_options = dict(loss=loss, f_scale=f_scale, ftol=ftol, xtol=xtol, gtol=gtol, max_iters=max_iters,
                                    pcg_tol=pcg_tol, pcg_max_iters=pcg_max_iters, preconditioner=preconditioner,
-                                   verbose=verbose)
+                                   jacobian_precision={'f64': 0, 'f32': 1}[jacobian], verbose=verbose)
+        self.comm = comm                       # None, or (rank, world, unique_id bytes)
         self.sparsity_plot_hook = sparsity_plot_hook
         self.last_summary = None
         self._solver = None
@@ -48,6 +54,9 @@ class BundleAdjuster:
     def _get_solver(self):
         if self._solver is None:
             self._solver = hip_backend.Solver(self.device_id)
+            if self.comm is not None and self.comm[1] > 1:
+                rank, world, unique_id = self.comm
+                self._solver.comm_init(rank, world, unique_id)
         return self._solver
 
     def close(self):
@@ -156,8 +165,14 @@ class BundleAdjuster:
                                                                   adjustable_kf_ids, local_map_point_ids, observations),
                                     fixed_kf_id, local_kf_ids[-1])
         solver = self._get_solver()
-        solver.set_problem(prob)
-        summary = solver.solve(**self.solver_options)
+        world = self.comm[1] if self.comm is not None else 1
+        if world > 1:                          # this rank's landmark block; all cameras
+            p_begin, p_end = shard_by_landmark(prob, world)[self.comm[0]]
+            shard, _ = extract_shard(prob, p_begin, p_end)
+            solver.set_problem(shard)
+        else:
+            solver.set_problem(prob)
+        summary = solver.solve(**self.solver_options)          # costs / verdicts are global on every rank
         self.last_summary = summary
         initial_cost, final_cost = summary["initial_sse"], summary["final_sse"]     # plain SSE (:165, :176)
         if final_cost >= initial_cost:
@@ -165,6 +180,8 @@ class BundleAdjuster:
             return
 
         cams, pts = solver.get_params()
+        if world > 1:
+            pts = solver.allgather_points(p_begin, prob.n_pts)
         R = solver.get_rotations()
         x = np.concatenate([cams[1:, :3].ravel(), cams[1:, 3:].ravel(), pts.ravel()])
         self._update_map(gmap, x, adjustable_kf_ids, local_map_point_ids, rotations=R[1:])

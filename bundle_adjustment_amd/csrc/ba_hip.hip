@@ -134,7 +134,7 @@ struct ba_handle {
   int lb = 0;                  // which c_w / partL buffer holds the current linearisation
   hipEvent_t ev_decide = nullptr;
   // PCG vectors, comm buffers (multi-rank), scalars
-  DBuf<double> gvec, x, r, p, s, z, vin, scal, rbuf;
+  DBuf<double> gvec, x, r, p, s, z, vin, scal, rbuf, gather;
   DBuf<PcgState> st;
   int nblkP = 1, ppb = 1, nblkV = 1;
   size_t lds_bytes = 0;
@@ -232,7 +232,7 @@ extern "C" int ba_destroy(ba_handle* h) {
   DBuf<double>* db[] = {&h->cams[0], &h->cams[1], &h->cs[0], &h->cs[1], &h->ptab[0], &h->ptab[1], &h->stage,
                         &h->camA[0], &h->camA[1], &h->HccBc, &h->Hpp, &h->bp, &h->Hppinv, &h->y0, &h->Hccd, &h->Minv,
                         &h->partR, &h->partL[0], &h->partL[1], &h->part6, &h->partE, &h->partA, &h->partB, &h->partC, &h->partV,
-                        &h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin, &h->scal, &h->rbuf};
+                        &h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin, &h->scal, &h->rbuf, &h->gather};
   for (auto b : db) b->release();
   h->st.release();
   if (h->h_scal) (void)hipHostFree(h->h_scal);
@@ -649,6 +649,27 @@ extern "C" int ba_get_params(ba_handle* h, double* cams, double* pts) {
     hipLaunchKernelGGL(k_unpack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->ptab[h->cur].p, h->slot.p, h->Np, h->stage.p);
     HIPCHECK(hipMemcpyAsync(pts, h->stage.p, 3 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   }
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return BA_OK;
+}
+
+// multi-rank: every rank ends up with the points of all shards (its own at [p_begin, p_begin + Np)):
+// zero-filled buffer + own slice, summed over the ranks with the solver's all-reduce
+extern "C" int ba_allgather_points(ba_handle* h, int64_t p_begin, int64_t n_total, double* pts_all) {
+  if (!h || !pts_all) return fail(BA_ERR_INVALID, "null argument");
+  if (!h->have_params) return fail(BA_ERR_STATE, "no parameters set");
+  if (p_begin < 0 || n_total < 0 || p_begin + (int64_t)h->Np > n_total)
+    return fail(BA_ERR_INVALID, "shard [%lld, %lld) does not fit in %lld points", (long long)p_begin,
+                (long long)(p_begin + h->Np), (long long)n_total);
+  if (n_total == 0) return BA_OK;
+  if (set_device(h)) return BA_ERR_HIP;
+  HIPCHECK(h->gather.alloc(3 * (size_t)n_total));
+  HIPCHECK(hipMemsetAsync(h->gather.p, 0, 3 * (size_t)n_total * sizeof(double), h->stream));
+  if (h->Np > 0)
+    hipLaunchKernelGGL(k_unpack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->ptab[h->cur].p, h->slot.p, h->Np,
+                       h->gather.p + 3 * (size_t)p_begin);
+  if (int rc = allreduce(h, h->gather.p, 3 * (size_t)n_total)) return rc;
+  HIPCHECK(hipMemcpyAsync(pts_all, h->gather.p, 3 * (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
   return BA_OK;
 }

@@ -71,6 +71,7 @@ SYMBOLS = {
     "ba_set_params": (C.c_int, [C.c_void_p, _DP, _DP]),
     "ba_get_params": (C.c_int, [C.c_void_p, _DP, _DP]),
     "ba_get_rotations": (C.c_int, [C.c_void_p, _DP]),
+    "ba_allgather_points": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _DP]),
     "ba_residuals": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _DP, _DP, _DP]),
     "ba_linearize": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _DP, _DP, _DP, _DP]),
     "ba_schur_rhs": (C.c_int, [C.c_void_p, C.c_double, _DP]),
@@ -176,6 +177,12 @@ class Solver:
         pts = np.empty((self.n_pts, 3))
         _check(self._lib.ba_get_params(self._h, _dp(cams), _dp(pts)))
         return cams, pts
+
+    def allgather_points(self, p_begin, n_total):
+        """Multi-rank: the points of every shard, on every rank (collective)."""
+        pts = np.empty((int(n_total), 3))
+        _check(self._lib.ba_allgather_points(self._h, int(p_begin), int(n_total), _dp(pts)))
+        return pts
 
     def get_rotations(self):
         R = np.empty((self.n_cams, 3, 3))

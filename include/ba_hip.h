@@ -123,6 +123,13 @@ int ba_get_params(ba_handle* h, double* cams, double* pts);
  * cv2.Rodrigues(rvec) of _update_map (:235-236). */
 int ba_get_rotations(ba_handle* h, double* R);
 
+/* Multi-rank write-back: after ba_solve every rank holds its own shard's points; this fills
+ * pts_all double[n_total][3] with the points of ALL shards on every rank (the calling rank's
+ * shard sits at [p_begin, p_begin + n_pts)); a collective, call it on every rank.  With one rank
+ * it is ba_get_params' point copy.  Lets an SPMD BundleAdjuster.run finish _update_map (:239-240)
+ * on every rank. */
+int ba_allgather_points(ba_handle* h, int64_t p_begin, int64_t n_total, double* pts_all);
+
 /* K1: residual vector in the caller's observation order == _cost_function (:24-72).
  * r may be NULL.  sse = sum r^2 (":165"), cost = 0.5 sum rho(r^2) for `loss`. */
 int ba_residuals(ba_handle* h, int32_t loss, double f_scale, double* r, double* sse, double* cost);

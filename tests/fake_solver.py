@@ -42,3 +42,39 @@ class OracleSolver:
 
     def get_rotations(self):
         return o.rodrigues_batch(self.cams[:, :3])
+
+
+class GlooOracleSolver(OracleSolver):
+    """Multi-rank double (one process per rank, torch.distributed gloo already initialised): what the
+    library's collectives do is restated with gloo -- the shards are gathered, every rank solves the
+    reassembled problem with the oracle (identical arithmetic on every rank, like the replicated
+    camera side of the real solver), keeps its own landmark block, and allgather_points exchanges
+    the blocks."""
+
+    def comm_init(self, rank, world, unique_id):
+        self.rank, self.world = rank, world
+
+    def solve(self, **kw):
+        import torch.distributed as dist
+        from bundle_adjustment_amd.problem import BAProblem
+        mine = self.prob
+        parts = [None] * self.world
+        dist.all_gather_object(parts, (mine.pts, mine.cam_idx, mine.pt_idx, mine.uv))
+        offs = np.cumsum([0] + [q[0].shape[0] for q in parts])
+        full = BAProblem(mine.cams.copy(), np.concatenate([q[0] for q in parts]), np.concatenate([q[1] for q in parts]),
+                         np.concatenate([q[2] + offs[i] for i, q in enumerate(parts)]).astype(np.int32),
+                         np.concatenate([q[3] for q in parts]), mine.K4, mine.fixed_cam)
+        self.prob, self.cams, self.pts = full, full.cams.copy(), full.pts.copy()
+        out = super().solve(**kw)
+        b, e = offs[self.rank], offs[self.rank + 1]
+        self.prob, self.pts = mine, self.pts[b:e].copy()
+        return out
+
+    def allgather_points(self, p_begin, n_total):
+        import torch.distributed as dist
+        parts = [None] * self.world
+        dist.all_gather_object(parts, (int(p_begin), self.pts))
+        full = np.zeros((int(n_total), 3))
+        for b, pts in parts:
+            full[b:b + pts.shape[0]] = pts
+        return full

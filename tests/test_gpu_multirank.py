@@ -71,3 +71,66 @@ def test_two_ranks_on_one_gpu_match_single_rank(tmp_path):
     pts = np.concatenate([np.load(tmp_path / f"pts_{k}.npy") for k in range(2)])
     assert pts.shape == pts_ref.shape and ranges[1][1] == p.n_pts
     assert np.abs(pts - pts_ref).max() <= 1e-5
+
+
+RUN_WORKER = r"""
+import io, os, sys
+from contextlib import redirect_stdout
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from bundle_adjustment_amd import BundleAdjuster, hip_backend
+from bundle_adjustment_amd.synthetic import make_problem, problem_to_map
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo")
+p = make_problem(12, 1200, 5, seed=17)
+gmap = problem_to_map(p)
+K = np.array([[p.K4[0], 0, p.K4[2]], [0, p.K4[1], p.K4[3]], [0, 0, 1.0]])
+uid = [hip_backend.comm_unique_id() if rank == 0 else None]
+dist.broadcast_object_list(uid, src=0)
+ba = BundleAdjuster(K, window_size=p.n_cams, comm=(rank, world, uid[0]), ftol=1e-12, xtol=1e-12, pcg_tol=1e-3)
+buf = io.StringIO()
+with redirect_stdout(buf):
+    ba.run(gmap)
+ids = sorted(gmap.map_points)
+np.save(os.path.join(%(out)r, f"run_pts_{rank}.npy"), np.array([gmap.map_points[i].position.ravel() for i in ids]))
+np.save(os.path.join(%(out)r, f"run_R_{rank}.npy"), np.array([gmap.keyframes[k].R for k in sorted(gmap.keyframes)]))
+open(os.path.join(%(out)r, f"run_log_{rank}.txt"), "w").write(buf.getvalue())
+ba.close()
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_spmd_run_on_two_ranks_leaves_the_same_map_everywhere(tmp_path):
+    """BundleAdjuster.run with comm=(rank, world, id): each rank solves its landmark block, the points
+    of all blocks are gathered (ba_allgather_points) and both ranks write back the same map as a
+    single-rank run (to the rounding of the re-ordered sums)."""
+    import io
+    from contextlib import redirect_stdout
+    from bundle_adjustment_amd import BundleAdjuster
+    from bundle_adjustment_amd.synthetic import make_problem, problem_to_map
+    script = tmp_path / "run_worker.py"
+    script.write_text(RUN_WORKER % dict(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, BA_COMM="shm")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29537", str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    p = make_problem(12, 1200, 5, seed=17)
+    gmap = problem_to_map(p)
+    K = np.array([[p.K4[0], 0, p.K4[2]], [0, p.K4[1], p.K4[3]], [0, 0, 1.0]])
+    ba = BundleAdjuster(K, window_size=p.n_cams, ftol=1e-12, xtol=1e-12, pcg_tol=1e-3)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        ba.run(gmap)
+    ba.close()
+    assert "LBA Complete" in buf.getvalue()
+    ids = sorted(gmap.map_points)
+    pts = np.array([gmap.map_points[i].position.ravel() for i in ids])
+    Rs = np.array([gmap.keyframes[k].R for k in sorted(gmap.keyframes)])
+    got = [(np.load(tmp_path / f"run_pts_{k}.npy"), np.load(tmp_path / f"run_R_{k}.npy"),
+            open(tmp_path / f"run_log_{k}.txt").read()) for k in range(2)]
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1]) and got[0][2] == got[1][2]
+    assert got[0][2] == buf.getvalue()                       # same log line: costs agree to the printed cents
+    assert np.abs(got[0][0] - pts).max() <= 1e-5 and np.abs(got[0][1] - Rs).max() <= 1e-7
