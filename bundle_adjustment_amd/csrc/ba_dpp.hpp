@@ -1,4 +1,4 @@
-// Wave-level (64-lane) sums and segmented scans built on DPP row operations instead of
+// Wave-level (64-lane) and row-level (16-lane) sums built on DPP row operations instead of
 // ds_bpermute shuffles (measured on MI355X: a 3-value segmented scan by shuffles costs
 // ~8 us over 1M observations, the dominant term of the point pass).
 #pragma once
@@ -10,10 +10,6 @@ namespace ba {
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
 constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
 
-template <int CTRL, int ROW_MASK>
-__device__ inline int dpp_int(int old, int src) {
-  return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
-}
 template <int CTRL, int ROW_MASK>
 __device__ inline double dpp_f64(double src) {   // lanes without a source read 0.0
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), CTRL, ROW_MASK, 0xf, false);
@@ -37,29 +33,6 @@ __device__ inline double wave_total_dpp(double x) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
   return __hiloint2double(hi, lo);
-}
-
-// Segmented inclusive scan of v[0..N) over lanes with equal `key` (keys are sorted along
-// the lanes, so equal keys are contiguous; key >= 0 for live lanes, any negative value
-// for idle ones).  After the call the LAST lane of each segment holds the segment sum.
-template <int N>
-__device__ inline void seg_scan_dpp(const int key, double (&v)[N]) {
-#define BA_SEG_STEP(CTRL, MASK)                                         \
-  {                                                                     \
-    const int kk = dpp_int<CTRL, MASK>(-1, key);                        \
-    const bool take = (kk == key);                                      \
-    _Pragma("unroll") for (int q = 0; q < N; ++q) {                     \
-      const double t = dpp_f64<CTRL, MASK>(v[q]);                       \
-      v[q] += take ? t : 0.0;                                           \
-    }                                                                   \
-  }
-  BA_SEG_STEP(DPP_ROW_SHR1, 0xf)
-  BA_SEG_STEP(DPP_ROW_SHR2, 0xf)
-  BA_SEG_STEP(DPP_ROW_SHR4, 0xf)
-  BA_SEG_STEP(DPP_ROW_SHR8, 0xf)
-  BA_SEG_STEP(DPP_ROW_BCAST15, 0xa)
-  BA_SEG_STEP(DPP_ROW_BCAST31, 0xc)
-#undef BA_SEG_STEP
 }
 
 }  // namespace ba

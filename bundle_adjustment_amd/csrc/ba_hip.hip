@@ -956,7 +956,7 @@ extern "C" int ba_default_options(ba_options* o) {
   o->pcg_min_iters = 1;
   o->preconditioner = BA_PRECOND_SCHUR_JACOBI;
   o->jacobian_precision = 0;
-  o->pcg_check_every = 2;
+  o->reserved0 = 0;
   o->profile = 0;
   o->verbose = 0;
   return BA_OK;

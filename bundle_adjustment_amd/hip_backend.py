@@ -31,7 +31,7 @@ class BAOptions(C.Structure):
     _fields_ = [("loss", C.c_int32), ("max_iters", C.c_int32), ("f_scale", C.c_double), ("ftol", C.c_double),
                 ("xtol", C.c_double), ("gtol", C.c_double), ("initial_lambda", C.c_double), ("pcg_tol", C.c_double),
                 ("pcg_max_iters", C.c_int32), ("pcg_min_iters", C.c_int32), ("preconditioner", C.c_int32),
-                ("jacobian_precision", C.c_int32), ("pcg_check_every", C.c_int32), ("profile", C.c_int32),
+                ("jacobian_precision", C.c_int32), ("reserved0", C.c_int32), ("profile", C.c_int32),
                 ("verbose", C.c_int32), ("reserved", C.c_int32)]
 
 

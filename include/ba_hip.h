@@ -58,7 +58,7 @@ typedef struct ba_options {
   int32_t pcg_min_iters;
   int32_t preconditioner;  /* ba_precond */
   int32_t jacobian_precision; /* 0 = f64 (default); 1 = f32 Jacobian blocks in the PCG passes, f64 accumulation / solve */
-  int32_t pcg_check_every; /* unused (kept for ABI stability): the host polls device-published PCG verdicts */
+  int32_t reserved0;       /* must be 0 */
   int32_t profile;         /* 1 = bracket every kernel with HIP events (see ba_get_profile) */
   int32_t verbose;
   int32_t reserved;

@@ -173,7 +173,7 @@ def test_solve_matches_cpu_mirror(solver, loss, precond):
     p = make_problem(12, 800, 5, seed=4, outlier_frac=0.02 if loss == "huber" else 0.0)
     solver.set_problem(p)
     kw = dict(max_iters=40, ftol=1e-13, xtol=1e-13, gtol=0.0, pcg_tol=1e-4, pcg_max_iters=400)
-    out = solver.solve(loss=loss, preconditioner=precond, pcg_check_every=1, **kw)
+    out = solver.solve(loss=loss, preconditioner=precond, **kw)
     ref = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, 0, loss, precond=precond, **kw)
     assert abs(out["final_cost"] - ref["cost"]) <= 1e-9 * ref["cost"]
     cams, pts = solver.get_params()
