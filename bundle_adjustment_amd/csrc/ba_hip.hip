@@ -721,7 +721,7 @@ static int wait_flag(ba_handle* h, int idx, long long target) {
 static void launch_lin_cam(ba_handle* h, int which, int buf, bool robust, double fscale) {
   Scope sc(h, BA_K_LINEARIZE_CAM);
   auto kern = robust ? k_camrow_linearize<true> : k_camrow_linearize<false>;
-  hipLaunchKernelGGL(kern, dim3(row_grid(h)), dim3(16 * ROWS), 0, h->stream, h->cs[which].p, h->ptab[which].p, h->offk.p,
+  hipLaunchKernelGGL(kern, dim3(row_grid(h)), dim3(ROW_LANES * ROWS), 0, h->stream, h->cs[which].p, h->ptab[which].p, h->offk.p,
                      h->c_pt.p, h->c_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, h->c_w[buf].p,
                      h->c_ptf[buf].p, h->partL[buf].p);
 }
@@ -769,7 +769,7 @@ static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int
   const dim3 g(cam_grid(h) + (pcg ? 1 : 0)), b(64 * WPB);
   if (diag) {
     auto kern = robust ? k_camrow_schur_diag<true> : k_camrow_schur_diag<false>;
-    hipLaunchKernelGGL(kern, dim3(row_grid(h)), dim3(16 * ROWS), 0, h->stream, h->cs[w].p, h->ptab[w].p, h->offk.p,
+    hipLaunchKernelGGL(kern, dim3(row_grid(h)), dim3(ROW_LANES * ROWS), 0, h->stream, h->cs[w].p, h->ptab[w].p, h->offk.p,
                        (robust ? h->c_ptf[h->lb].p : h->c_pt.p), h->c_w[h->lb].p, h->Hppinv.p, h->K4[0], h->K4[1], h->Nc,
                        h->fixed, h->part6.p, h->partE.p);
   } else if (pcg) {

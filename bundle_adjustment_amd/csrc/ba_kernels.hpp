@@ -320,21 +320,27 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
 // With 27 running sums the 64-lane reduction of the wave-per-segment mapping costs as much as
 // the arithmetic of a ~125-observation segment; a row walks the segment in 8 steps and only
 // needs the 4 in-row shifts.  Workgroup = 16 consecutive cameras of one partition.
-constexpr int ROWS = 16;     // rows (= cameras) per 256-thread workgroup
-struct RowSeg { int c, k, beg, end, l16; bool live; };
+#ifndef BA_ROW_LANES
+#define BA_ROW_LANES 16
+#endif
+constexpr int ROW_LANES = BA_ROW_LANES;          // lanes per (camera, partition) segment: 16 (one DPP row) or 32 (two)
+constexpr int ROWS = 256 / ROW_LANES;           // segments (= cameras) per 256-thread workgroup
+static_assert(ROW_LANES == 8 || ROW_LANES == 16 || ROW_LANES == 32, "row-form kernels: 8, 16 or 32 lanes per segment");
+struct RowSeg { int c, k, beg, end, l16; bool live; };   // l16: lane inside the segment
 __device__ inline void row_segment(const int* __restrict__ offk, int n_cams, RowSeg& s) {
   s.k = blockIdx.x % NPART;
-  s.c = (int)(blockIdx.x / NPART) * ROWS + (int)(threadIdx.x >> 4);
-  s.l16 = threadIdx.x & 15;
+  s.c = (int)(blockIdx.x / NPART) * ROWS + (int)(threadIdx.x / ROW_LANES);
+  s.l16 = threadIdx.x % ROW_LANES;
   s.live = s.c < n_cams;
   s.beg = s.live ? offk[s.c * (NPART + 1) + s.k] : 0;
   s.end = s.live ? offk[s.c * (NPART + 1) + s.k + 1] : 0;
 }
-__device__ inline double row_sum_dpp(double x) {     // lane 15 of every row ends with the row total
+__device__ inline double row_sum_dpp(double x) {     // the last lane of every segment ends with the segment total
   x += dpp_f64<DPP_ROW_SHR1, 0xf>(x);
   x += dpp_f64<DPP_ROW_SHR2, 0xf>(x);
   x += dpp_f64<DPP_ROW_SHR4, 0xf>(x);
-  x += dpp_f64<DPP_ROW_SHR8, 0xf>(x);
+  if (ROW_LANES >= 16) x += dpp_f64<DPP_ROW_SHR8, 0xf>(x);
+  if (ROW_LANES == 32) x += dpp_f64<DPP_ROW_BCAST15, 0xa>(x);     // odd rows add the total of the row before
   return x;
 }
 __device__ inline void load_cam12(const double* __restrict__ cs, int c, double (&cam)[12]) {
@@ -345,7 +351,7 @@ __device__ inline void load_cam12(const double* __restrict__ cs, int c, double (
 
 // K2a (row form): same outputs as k_cam_linearize
 template <bool ROBUST>
-__global__ void __launch_bounds__(16 * ROWS)
+__global__ void __launch_bounds__(ROW_LANES * ROWS)
 k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
                    const int* __restrict__ c_pt, const double2* __restrict__ c_uv,
                    double fx, double fy, double cx, double cy, double hub_c, int n_cams,
@@ -362,7 +368,7 @@ k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ pta
     int p = (i < s.end) ? c_pt[i] : 0;
     double2 uv = (i < s.end) ? c_uv[i] : make_double2(0, 0);
     while (i < s.end) {
-      const int in = i + 16;
+      const int in = i + ROW_LANES;
       const int pn = (in < s.end) ? c_pt[in] : 0;
       const double2 uvn = (in < s.end) ? c_uv[in] : make_double2(0, 0);
       const double4 X = *(const double4*)(ptab + PT * (size_t)p);
@@ -393,7 +399,7 @@ k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ pta
   }
 #pragma unroll
   for (int q = 0; q < 27; ++q) acc[q] = row_sum_dpp(acc[q]);
-  if (s.live && s.l16 == 15) {
+  if (s.live && s.l16 == ROW_LANES - 1) {
     double* o = partL + ((size_t)s.k * n_cams + s.c) * 27;
 #pragma unroll
     for (int q = 0; q < 27; ++q) o[q] = acc[q];
@@ -402,7 +408,7 @@ k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ pta
 
 // right-hand side + Schur-Jacobi blocks (row form of k_cam_schur<.., DIAG = true, PCG = false>)
 template <bool ROBUST>
-__global__ void __launch_bounds__(16 * ROWS)
+__global__ void __launch_bounds__(ROW_LANES * ROWS)
 k_camrow_schur_diag(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
                     const int* __restrict__ c_pt, const double2* __restrict__ c_w, const double* __restrict__ Hppinv,
                     double fx, double fy, int n_cams, int fixed_cam, double* __restrict__ part6, double* __restrict__ partE) {
@@ -419,7 +425,7 @@ k_camrow_schur_diag(const double* __restrict__ cs, const double* __restrict__ pt
     double2 w = make_double2(1.0, 1.0);
     if (ROBUST && pf < 0) w = c_w[i];
     while (i < s.end) {
-      const int in = i + 16;
+      const int in = i + ROW_LANES;
       const int pn = (in < s.end) ? c_pt[in] : 0;
       const int p = ROBUST ? (pf & IDX_MASK) : pf;
       const double4 X = *(const double4*)(ptab + PT * (size_t)p);
@@ -460,7 +466,7 @@ k_camrow_schur_diag(const double* __restrict__ cs, const double* __restrict__ pt
   }
 #pragma unroll
   for (int q = 0; q < 27; ++q) acc[q] = row_sum_dpp(acc[q]);
-  if (s.live && s.l16 == 15) {
+  if (s.live && s.l16 == ROW_LANES - 1) {
     double* o6 = part6 + ((size_t)s.k * n_cams + s.c) * 6;
 #pragma unroll
     for (int q = 0; q < 6; ++q) o6[q] = acc[q];
