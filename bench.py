@@ -221,7 +221,7 @@ def main():
     achieved = ab[dom] / (dom_us * 1e-6) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if world == 1 and args.config == "C3" and os.path.exists(tpath):     # the PMC passes were run on this workload only
         try:
             traffic = json.load(open(tpath)).get(dom)
         except Exception:
