@@ -198,9 +198,9 @@ extern "C" int ba_create(int device_id, ba_handle** out) {
   memset(h->h_flags, 0, 8 * sizeof(long long));
   HIPCHECK(hipHostGetDevicePointer((void**)&h->d_flags, h->h_flags, 0));
 #define BA_BIG_LDS(K) HIPCHECK(allow_big_lds(K))
-#define BA_BIG_LDS_LIN(R, L) BA_BIG_LDS((k_pt_linearize<R, L, LPP>)); BA_BIG_LDS((k_pt_linearize<R, L, LPP_LONG>))
-#define BA_BIG_LDS_SCH(R, M, L) BA_BIG_LDS((k_pt_schur<R, M, L, LPP, double>)); BA_BIG_LDS((k_pt_schur<R, M, L, LPP_LONG, double>)); \
-  BA_BIG_LDS((k_pt_schur<R, M, L, LPP, float>)); BA_BIG_LDS((k_pt_schur<R, M, L, LPP_LONG, float>))
+#define BA_BIG_LDS_LIN(R, L) BA_BIG_LDS((k_pt_linearize<R, L, LPP>)); BA_BIG_LDS((k_pt_linearize_both<R, L>))
+#define BA_BIG_LDS_SCH(R, M, L) BA_BIG_LDS((k_pt_schur<R, M, L, LPP, double>)); BA_BIG_LDS((k_pt_schur<R, M, L, LPP, float>)); \
+  BA_BIG_LDS((k_pt_schur_both<R, M, L, double>)); BA_BIG_LDS((k_pt_schur_both<R, M, L, float>))
   BA_BIG_LDS_LIN(true, true); BA_BIG_LDS_LIN(true, false); BA_BIG_LDS_LIN(false, true); BA_BIG_LDS_LIN(false, false);
   BA_BIG_LDS_SCH(true, 0, true); BA_BIG_LDS_SCH(true, 0, false); BA_BIG_LDS_SCH(false, 0, true); BA_BIG_LDS_SCH(false, 0, false);
   BA_BIG_LDS_SCH(true, 1, true); BA_BIG_LDS_SCH(true, 1, false); BA_BIG_LDS_SCH(false, 1, true); BA_BIG_LDS_SCH(false, 1, false);
@@ -739,18 +739,23 @@ static void launch_lin_pt(ba_handle* h, bool robust, double fscale, double lambd
   if (h->Np == 0) return;
   Scope sc(h, BA_K_LINEARIZE_PT);
   const int w = h->cur;
-#define LP_ARGS(WK) h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_uv.p, h->blk_win.p, WK, h->K4[0], h->K4[1],    \
-                    h->K4[2], h->K4[3], fscale, lambda, h->Hpp.p, h->bp.p, h->p_w.p, h->p_camf.p, h->Hppinv.p, h->y0.p
-#define LP_LAUNCH(R, L, LN, G, WK) hipLaunchKernelGGL((k_pt_linearize<R, L, LN>), dim3(G), dim3(PT_THREADS), h->lds_bytes, h->stream, LP_ARGS(WK))
+#define LP_HEAD h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_uv.p, h->blk_win.p
+#define LP_TAIL h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, lambda, h->Hpp.p, h->bp.p, h->p_w.p, h->p_camf.p, h->Hppinv.p, h->y0.p
+#define LP_LAUNCH(R, L, LN, G, WK) hipLaunchKernelGGL((k_pt_linearize<R, L, LN>), dim3(G), dim3(PT_THREADS), h->lds_bytes, h->stream, LP_HEAD, WK, LP_TAIL)
+#define LP_BOTH(R, L) hipLaunchKernelGGL((k_pt_linearize_both<R, L>), dim3(h->nblkP + h->nblkL), dim3(PT_THREADS), h->lds_bytes, h->stream, \
+                                         LP_HEAD, wk, h->nblkP, wl, LP_TAIL)
   const PtWork wk = pt_work(h), wl = pt_work_long(h);
-  if (h->all_lds) { if (robust) LP_LAUNCH(true, true, LPP, h->nblkP, wk); else LP_LAUNCH(false, true, LPP, h->nblkP, wk); }
-  else            { if (robust) LP_LAUNCH(true, false, LPP, h->nblkP, wk); else LP_LAUNCH(false, false, LPP, h->nblkP, wk); }
-  if (h->nblkL) {
-    if (h->all_lds) { if (robust) LP_LAUNCH(true, true, LPP_LONG, h->nblkL, wl); else LP_LAUNCH(false, true, LPP_LONG, h->nblkL, wl); }
-    else            { if (robust) LP_LAUNCH(true, false, LPP_LONG, h->nblkL, wl); else LP_LAUNCH(false, false, LPP_LONG, h->nblkL, wl); }
+  if (h->nblkL) {          // short and long tracks in one launch
+    if (h->all_lds) { if (robust) LP_BOTH(true, true); else LP_BOTH(false, true); }
+    else            { if (robust) LP_BOTH(true, false); else LP_BOTH(false, false); }
+  } else {
+    if (h->all_lds) { if (robust) LP_LAUNCH(true, true, LPP, h->nblkP, wk); else LP_LAUNCH(false, true, LPP, h->nblkP, wk); }
+    else            { if (robust) LP_LAUNCH(true, false, LPP, h->nblkP, wk); else LP_LAUNCH(false, false, LPP, h->nblkP, wk); }
   }
+#undef LP_BOTH
 #undef LP_LAUNCH
-#undef LP_ARGS
+#undef LP_HEAD
+#undef LP_TAIL
 }
 static void launch_point_invert(ba_handle* h, double lambda) {
   if (h->Np == 0) return;
@@ -791,33 +796,33 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
   if (h->Np == 0) return;
   Scope sc(h, mode == 0 ? BA_K_SCHUR_PT : BA_K_BACKSUB);
   const int w = h->cur;
-#define PS_ARGS(WK, FLAG) h->camA[w].p, h->ptab[w].p, h->pt_off.p, (robust ? h->p_camf.p : h->p_cam.p), h->p_w.p, h->Hppinv.p, h->blk_win.p, WK, h->K4[0],  \
-                h->K4[1], h->fixed, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0.p, h->Hpp.p, h->bp.p,  \
-                h->ptab[1 - w].p, h->partB.p, FLAG, flag_base
+#define PS_HEAD h->camA[w].p, h->ptab[w].p, h->pt_off.p, (robust ? h->p_camf.p : h->p_cam.p), h->p_w.p, h->Hppinv.p, h->blk_win.p
+#define PS_TAIL h->K4[0], h->K4[1], h->fixed, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0.p, h->Hpp.p,  \
+                h->bp.p, h->ptab[1 - w].p, h->partB.p, flag, flag_base
   const size_t lds = h->lds_bytes;
   long long* flag = (mode == 0 && flag_base > 0) ? h->d_flags : (long long*)nullptr;
-  long long* noflag = nullptr;
-#define PS_LAUNCH(R, M, L, LN, JT, G, WK, FLAG) \
-  hipLaunchKernelGGL((k_pt_schur<R, M, L, LN, JT>), dim3(G), dim3(PT_THREADS), lds, h->stream, PS_ARGS(WK, FLAG))
-#define PS_BOTH(R, M, L, JT)                                                          \
-  do {                                                                                \
-    PS_LAUNCH(R, M, L, LPP, JT, h->nblkP, wk, flag);                                  \
-    if (h->nblkL) PS_LAUNCH(R, M, L, LPP_LONG, JT, h->nblkL, wl, noflag);             \
+  // data with long tracks: short and long tracks in one launch (workgroup 0 publishes the verdict)
+#define PS_LAUNCH(R, M, L, JT)                                                                                              \
+  do {                                                                                                                      \
+    if (h->nblkL) hipLaunchKernelGGL((k_pt_schur_both<R, M, L, JT>), dim3(h->nblkP + h->nblkL), dim3(PT_THREADS), lds,      \
+                                     h->stream, PS_HEAD, wk, h->nblkP, wl, PS_TAIL);                                        \
+    else hipLaunchKernelGGL((k_pt_schur<R, M, L, LPP, JT>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, PS_HEAD, wk,  \
+                            PS_TAIL);                                                                                       \
   } while (0)
 #define PS_MODE(R, L)                                                                 \
   do {                                                                                \
-    if (mode != 0) PS_BOTH(R, 1, L, double);                                          \
-    else if (f32) PS_BOTH(R, 0, L, float);                                            \
-    else PS_BOTH(R, 0, L, double);                                                    \
+    if (mode != 0) PS_LAUNCH(R, 1, L, double);                                        \
+    else if (f32) PS_LAUNCH(R, 0, L, float);                                          \
+    else PS_LAUNCH(R, 0, L, double);                                                  \
   } while (0)
   const PtWork wk = pt_work(h), wl = pt_work_long(h);
   const bool f32 = h->jac_f32 && flag_base > 0;       // only inside the PCG loop of ba_solve
   if (h->all_lds) { if (robust) PS_MODE(true, true); else PS_MODE(false, true); }
   else            { if (robust) PS_MODE(true, false); else PS_MODE(false, false); }
 #undef PS_MODE
-#undef PS_BOTH
 #undef PS_LAUNCH
-#undef PS_ARGS
+#undef PS_HEAD
+#undef PS_TAIL
 }
 
 // multi-rank: the per-partition partial sums themselves are all-reduced (part6 with the u.y word

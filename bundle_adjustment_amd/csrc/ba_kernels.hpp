@@ -560,15 +560,16 @@ __device__ inline double lanes_sum(double x) {      // last lane of every LANES-
 
 // K2b: point half of the normal equations.  Hpp[p] (6) = sum P^T w P, bp[p] (3) = -sum P^T w r,
 // IRLS weights of point-ordered observations (p_w) when ROBUST; K3 fused: damped inverse and y0.
+// Body for workgroup `bid` of `nblk`: LANES lanes per point (LPP short tracks, LPP_LONG long ones).
 template <bool ROBUST, bool ALL_LDS, int LANES>
-__global__ void __launch_bounds__(PT_THREADS)
-k_pt_linearize(const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,
-               const int* __restrict__ p_cam, const double2* __restrict__ p_uv, const int2* __restrict__ blk_win,
-               PtWork wk, double fx, double fy, double cx, double cy, double hub_c,
-               double lambda, double* __restrict__ Hpp, double* __restrict__ bp, double2* __restrict__ p_w,
-               int* __restrict__ p_camf, double* __restrict__ Hppinv, double* __restrict__ y0) {
+__device__ __forceinline__ void
+pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,
+                  const int* __restrict__ p_cam, const double2* __restrict__ p_uv, const int2* __restrict__ blk_win,
+                  const PtWork& wk, int bid, int nblk, double fx, double fy, double cx, double cy, double hub_c,
+                  double lambda, double* __restrict__ Hpp, double* __restrict__ bp, double2* __restrict__ p_w,
+                  int* __restrict__ p_camf, double* __restrict__ Hppinv, double* __restrict__ y0) {
   extern __shared__ double tab[];
-  const int rb = pt_range_of_block(blockIdx.x, gridDim.x, wk.xcd_ranges);
+  const int rb = pt_range_of_block(bid, nblk, wk.xcd_ranges);
   const int2 win = blk_win[wk.blk_base + rb];
   const bool use_lds = ALL_LDS || (size_t)win.y * TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
   if (use_lds) fill_cam_table<PT_THREADS>(tab, camA, win.x, win.y);
@@ -639,6 +640,35 @@ k_pt_linearize(const double* __restrict__ camA, double* __restrict__ ptab, const
   }
 }
 
+#define BA_LIN_PARAMS const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,               \
+                      const int* __restrict__ p_cam, const double2* __restrict__ p_uv, const int2* __restrict__ blk_win
+#define BA_LIN_TAIL double fx, double fy, double cx, double cy, double hub_c, double lambda, double* __restrict__ Hpp,          \
+                    double* __restrict__ bp, double2* __restrict__ p_w, int* __restrict__ p_camf, double* __restrict__ Hppinv, \
+                    double* __restrict__ y0
+// one kind of track per launch
+template <bool ROBUST, bool ALL_LDS, int LANES>
+__global__ void __launch_bounds__(PT_THREADS)
+k_pt_linearize(BA_LIN_PARAMS, PtWork wk, BA_LIN_TAIL) {
+  pt_linearize_body<ROBUST, ALL_LDS, LANES>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wk, blockIdx.x, gridDim.x, fx, fy, cx, cy,
+                                            hub_c, lambda, Hpp, bp, p_w, p_camf, Hppinv, y0);
+}
+// short and long tracks in one launch: workgroups [0, nblk_short) take the range list with LPP lanes
+// per point, the rest the long-track list with a DPP row per point (saves a launch per pass on data
+// with long tracks)
+template <bool ROBUST, bool ALL_LDS>
+__global__ void __launch_bounds__(PT_THREADS)
+k_pt_linearize_both(BA_LIN_PARAMS, PtWork wk, int nblk_short, PtWork wl, BA_LIN_TAIL) {
+  if ((int)blockIdx.x < nblk_short)
+    pt_linearize_body<ROBUST, ALL_LDS, LPP>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wk, blockIdx.x, nblk_short, fx, fy, cx, cy,
+                                            hub_c, lambda, Hpp, bp, p_w, p_camf, Hppinv, y0);
+  else
+    pt_linearize_body<ROBUST, ALL_LDS, LPP_LONG>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wl, blockIdx.x - nblk_short,
+                                                 gridDim.x - nblk_short, fx, fy, cx, cy, hub_c, lambda, Hpp, bp, p_w, p_camf,
+                                                 Hppinv, y0);
+}
+#undef BA_LIN_PARAMS
+#undef BA_LIN_TAIL
+
 // K3: damped 3x3 inverse per point and y0 = (Hpp + lam Dp)^-1 bp (also placed in the y
 // slot of the point table, where the right-hand-side camera pass reads it).
 __global__ void __launch_bounds__(256)
@@ -669,21 +699,21 @@ k_point_invert(const double* __restrict__ Hpp, const double* __restrict__ bp, do
 // MODE 1 (back substitution): dp = -(y0 + Hppinv u), trial point = X + dp, partB[block][4] =
 //         bp.dp, sum Dp dp^2, |dp|^2, |X|^2.
 template <bool ROBUST, int MODE, bool ALL_LDS, int LANES, typename JT>
-__global__ void __launch_bounds__(PT_THREADS)
-k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,
-           const int* __restrict__ p_cam, const double2* __restrict__ p_w, const double* __restrict__ Hppinv,
-           const int2* __restrict__ blk_win, PtWork wk,
-           double fx, double fy, int fixed_cam, double* __restrict__ partA,
-           int kit, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2,
-           int min_iters,
-           const double* __restrict__ y0, const double* __restrict__ Hpp, const double* __restrict__ bp,
-           double* __restrict__ ptab_trial, double* __restrict__ partB,
-           long long* __restrict__ host_flag, long long flag_base) {
+__device__ __forceinline__ void
+pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,
+              const int* __restrict__ p_cam, const double2* __restrict__ p_w, const double* __restrict__ Hppinv,
+              const int2* __restrict__ blk_win, const PtWork& wk, int bid, int nblk,
+              double fx, double fy, int fixed_cam, double* __restrict__ partA,
+              int kit, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2,
+              int min_iters,
+              const double* __restrict__ y0, const double* __restrict__ Hpp, const double* __restrict__ bp,
+              double* __restrict__ ptab_trial, double* __restrict__ partB,
+              long long* __restrict__ host_flag, long long flag_base) {
   extern __shared__ double tab[];
   __shared__ double sm[4 * (PT_THREADS / 64)];
   // the workgroup's window and the first round's track bounds are fetched before the PCG verdict
   // is known: one round trip less on the way to the first camera row
-  const int rb = pt_range_of_block(blockIdx.x, gridDim.x, wk.xcd_ranges);
+  const int rb = pt_range_of_block(bid, nblk, wk.xcd_ranges);
   const int2 win = blk_win[wk.blk_base + rb];
   const int send = min(wk.n_slots, (rb + 1) * wk.slots_per_block);
   const int sb0 = rb * wk.slots_per_block;
@@ -698,7 +728,7 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
     const bool fin = pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z);
     // first kernel of iteration kit: tell the host now whether this iteration runs (it then queues
     // the next one behind it) or PCG is over (it queues the step kernels instead)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {     // workgroup 0 of the launch, whichever kind of track it works on
       const PcgState& s = st[kit & 1];
       publish_flag(host_flag, flag_base + kit + 1, fin ? (long long)(s.done ? s.iters : kit) + 1 : 0);
     }
@@ -798,6 +828,36 @@ k_pt_schur(const double* __restrict__ camA, double* __restrict__ ptab, const int
     else { for (int q = 0; q < 4; ++q) partB[4 * (wk.blk_base + rb) + q] = acc[q]; }
   }
 }
+
+#define BA_SCH_PARAMS const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,               \
+                      const int* __restrict__ p_cam, const double2* __restrict__ p_w, const double* __restrict__ Hppinv,     \
+                      const int2* __restrict__ blk_win
+#define BA_SCH_TAIL double fx, double fy, int fixed_cam, double* __restrict__ partA, int kit, const PcgState* __restrict__ st, \
+                    const double* __restrict__ partV, int nblkV, double tol2, int min_iters, const double* __restrict__ y0,    \
+                    const double* __restrict__ Hpp, const double* __restrict__ bp, double* __restrict__ ptab_trial,            \
+                    double* __restrict__ partB, long long* __restrict__ host_flag, long long flag_base
+#define BA_SCH_TAIL_ARGS fx, fy, fixed_cam, partA, kit, st, partV, nblkV, tol2, min_iters, y0, Hpp, bp, ptab_trial, partB,       \
+                         host_flag, flag_base
+template <bool ROBUST, int MODE, bool ALL_LDS, int LANES, typename JT>
+__global__ void __launch_bounds__(PT_THREADS)
+k_pt_schur(BA_SCH_PARAMS, PtWork wk, BA_SCH_TAIL) {
+  pt_schur_body<ROBUST, MODE, ALL_LDS, LANES, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk, blockIdx.x, gridDim.x,
+                                                  BA_SCH_TAIL_ARGS);
+}
+// short and long tracks in one launch (see k_pt_linearize_both)
+template <bool ROBUST, int MODE, bool ALL_LDS, typename JT>
+__global__ void __launch_bounds__(PT_THREADS)
+k_pt_schur_both(BA_SCH_PARAMS, PtWork wk, int nblk_short, PtWork wl, BA_SCH_TAIL) {
+  if ((int)blockIdx.x < nblk_short)
+    pt_schur_body<ROBUST, MODE, ALL_LDS, LPP, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk, blockIdx.x, nblk_short,
+                                                  BA_SCH_TAIL_ARGS);
+  else
+    pt_schur_body<ROBUST, MODE, ALL_LDS, LPP_LONG, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wl,
+                                                       blockIdx.x - nblk_short, gridDim.x - nblk_short, BA_SCH_TAIL_ARGS);
+}
+#undef BA_SCH_PARAMS
+#undef BA_SCH_TAIL
+#undef BA_SCH_TAIL_ARGS
 
 // -------------------------------------------------------------------------------------
 // reduced-camera-system vector kernels (one thread per camera)
