@@ -110,6 +110,7 @@ struct ba_handle {
   int device = 0;
   int n_cu = 256;              // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int xcd_ranges = 1;          // point-pass ranges grouped per XCD (BA_XCD_RANGES=0 turns it off; speed only)
+  int cam_band = 0;            // camera passes: XCD x takes camera range x (1) or partition x of every camera (0); see group_of_block
   hipStream_t stream = nullptr;
   bool have_problem = false, have_params = false, linearized = false;
   int lin_robust = 0;
@@ -509,6 +510,25 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     const long long n = cam_off[c + 1] - cam_off[c];
     for (int k = 0; k <= NPART; ++k) offk[(size_t)c * (NPART + 1) + k] = cam_off[c] + (int)((n * k) / NPART);
   }
+  // which workgroup -> XCD assignment of the camera passes keeps an XCD on one slice of the point table
+  // (group_of_block): count the observations whose point lies in the slice of their partition, and in
+  // the slice of their camera's range
+  {
+    long long in_partition = 0, in_band = 0;
+    if (Np > 0) {
+      for (int c = 0; c < Nc; ++c) {
+        const int cam_slice = (int)(((long long)c * NPART) / Nc);
+        for (int k = 0; k < NPART; ++k)
+          for (int a = offk[(size_t)c * (NPART + 1) + k]; a < offk[(size_t)c * (NPART + 1) + k + 1]; ++a) {
+            const int pt_slice = (int)(((long long)c_pt[a] * NPART) / Np);
+            in_partition += pt_slice == k;
+            in_band += pt_slice == cam_slice;
+          }
+      }
+    }
+    h->cam_band = in_band > in_partition;
+    if (const char* e = getenv("BA_CAM_BAND")) h->cam_band = atoi(e) != 0;
+  }
   h->Nc = Nc; h->Np = Np; h->Nobs = No; h->fixed = fixed_cam;
   memcpy(h->K4, K4, sizeof h->K4);
   h->nblkV = (Nc + VEC_CAMS - 1) / VEC_CAMS;
@@ -689,7 +709,7 @@ static void launch_residual(ba_handle* h, int which, bool robust, double fscale,
   Scope sc(h, BA_K_RESIDUAL);
   auto kern = robust ? k_cam_residual<true> : k_cam_residual<false>;
   hipLaunchKernelGGL(kern, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[which].p, h->ptab[which].p, h->offk.p,
-                     h->c_pt.p, h->c_uv.p, h->c_orig.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, r_out,
+                     h->c_pt.p, h->c_uv.p, h->c_orig.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, h->cam_band, r_out,
                      h->partR.p);
 }
 // fold the partial arrays of a step into `scal` (residual always; point / camera parts optional)
@@ -722,7 +742,7 @@ static void launch_lin_cam(ba_handle* h, int which, int buf, bool robust, double
   Scope sc(h, BA_K_LINEARIZE_CAM);
   auto kern = robust ? k_camrow_linearize<true> : k_camrow_linearize<false>;
   hipLaunchKernelGGL(kern, dim3(row_grid(h)), dim3(ROW_LANES * ROWS), 0, h->stream, h->cs[which].p, h->ptab[which].p, h->offk.p,
-                     h->c_pt.p, h->c_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, h->c_w[buf].p,
+                     h->c_pt.p, h->c_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, h->cam_band, h->c_w[buf].p,
                      h->c_ptf[buf].p, h->partL[buf].p);
 }
 static void launch_lin_finalize(ba_handle* h) {
@@ -768,7 +788,7 @@ static void launch_point_invert(ba_handle* h, double lambda) {
 static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int k, double tol2, int min_iters) {
   Scope sc(h, diag ? BA_K_PRECOND : BA_K_SCHUR_CAM);
   const int w = h->cur;
-#define CS_ARGS h->cs[w].p, h->ptab[w].p, h->offk.p, (robust ? h->c_ptf[h->lb].p : h->c_pt.p), h->c_w[h->lb].p, h->K4[0], h->K4[1], h->Nc, h->fixed,        \
+#define CS_ARGS h->cs[w].p, h->ptab[w].p, h->offk.p, (robust ? h->c_ptf[h->lb].p : h->c_pt.p), h->c_w[h->lb].p, h->K4[0], h->K4[1], h->Nc, h->cam_band, h->fixed,        \
                 h->part6.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->partA.p,                                   \
                 (h->Np > 0 ? h->nblkP + h->nblkL : 0), uy_ptr(h)
   const dim3 g(cam_grid(h) + (pcg ? 1 : 0)), b(64 * WPB);
@@ -776,7 +796,7 @@ static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int
     auto kern = robust ? k_camrow_schur_diag<true> : k_camrow_schur_diag<false>;
     hipLaunchKernelGGL(kern, dim3(row_grid(h)), dim3(ROW_LANES * ROWS), 0, h->stream, h->cs[w].p, h->ptab[w].p, h->offk.p,
                        (robust ? h->c_ptf[h->lb].p : h->c_pt.p), h->c_w[h->lb].p, h->Hppinv.p, h->K4[0], h->K4[1], h->Nc,
-                       h->fixed, h->part6.p, h->partE.p);
+                       h->cam_band, h->fixed, h->part6.p, h->partE.p);
   } else if (pcg) {
     if (h->jac_f32) {
       if (robust) hipLaunchKernelGGL((k_cam_schur<true, true, float>), g, b, 0, h->stream, CS_ARGS);

@@ -107,9 +107,25 @@ __global__ void k_unpermute_rows(const double* __restrict__ src, const int* __re
 // camera passes: wave = (camera c, partition k)
 // -------------------------------------------------------------------------------------
 struct Seg { int c, k, beg, end, lane; };
-__device__ inline bool cam_segment(const int* __restrict__ offk, int n_cams, Seg& s) {
-  s.k = blockIdx.x % NPART;
-  s.c = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / NPART) * WPB + (int)(threadIdx.x >> 6));
+// Workgroup -> (camera group, partition).  Workgroups are dealt round-robin over the NPART XCDs.
+// band = 0: XCD x takes partition x of every camera -- right when a camera's k-th chunk lies in the
+// k-th eighth of the point table (observations spread over all points: C3).  band = 1: XCD x takes
+// all partitions of the x-th eighth of the cameras -- right when a camera's points sit in a band
+// around the camera's own position in the point numbering (sequential captures: C5).  Either way
+// an XCD keeps gathering from the same slice of the point table, the one its point-pass ranges
+// write; ba_set_problem counts which fits the data.  Speed only.
+__device__ inline void group_of_block(int n_groups, int band, int& group, int& k) {
+  if (band) {
+    const int q = (int)(blockIdx.x % NPART) * n_groups + (int)(blockIdx.x / NPART);
+    group = q / NPART; k = q % NPART;
+  } else {
+    group = blockIdx.x / NPART; k = blockIdx.x % NPART;
+  }
+}
+__device__ inline bool cam_segment(const int* __restrict__ offk, int n_cams, int band, Seg& s) {
+  int group;
+  group_of_block((n_cams + WPB - 1) / WPB, band, group, s.k);
+  s.c = __builtin_amdgcn_readfirstlane(group * WPB + (int)(threadIdx.x >> 6));
   s.lane = threadIdx.x & 63;
   if (s.c >= n_cams) return false;
   s.beg = offk[s.c * (NPART + 1) + s.k];
@@ -131,10 +147,10 @@ template <bool ROBUST>
 __global__ void __launch_bounds__(64 * WPB)
 k_cam_residual(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
                const int* __restrict__ c_pt, const double2* __restrict__ c_uv, const int* __restrict__ c_orig,
-               double fx, double fy, double cx, double cy, double hub_c, int n_cams,
+               double fx, double fy, double cx, double cy, double hub_c, int n_cams, int band,
                double* __restrict__ r_out, double* __restrict__ partR) {
   Seg s;
-  if (!cam_segment(offk, n_cams, s)) return;
+  if (!cam_segment(offk, n_cams, band, s)) return;
   const double* cam = cs + CS * s.c;
   double acc[2] = {0.0, 0.0};
   for (int i = s.beg + s.lane; i < s.end; i += 64) {
@@ -253,7 +269,7 @@ template <bool ROBUST, bool PCG, typename JT>
 __global__ void __launch_bounds__(64 * WPB)
 k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
             const int* __restrict__ c_pt, const double2* __restrict__ c_w,
-            double fx, double fy, int n_cams, int fixed_cam, double* __restrict__ part6,
+            double fx, double fy, int n_cams, int band, int fixed_cam, double* __restrict__ part6,
             int kit, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2,
             int min_iters, const double* __restrict__ partA, int nblkA, double* __restrict__ uy) {
   // segment bounds and camera state are fetched before the PCG verdict is known: one round trip
@@ -261,7 +277,7 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
   const bool extra = PCG && blockIdx.x == gridDim.x - 1;   // extra workgroup: folds the point pass's u.y partials
   Seg s;
   s.c = 0; s.k = 0; s.beg = 0; s.end = 0; s.lane = threadIdx.x & 63;
-  const bool live = !extra && cam_segment(offk, n_cams, s);
+  const bool live = !extra && cam_segment(offk, n_cams, band, s);
   JT cam[12];                                  // Jacobian blocks in JT (double, or float for config 5)
   if (live) {
     const double* camd = cs + CS * s.c;
@@ -327,9 +343,10 @@ constexpr int ROW_LANES = BA_ROW_LANES;          // lanes per (camera, partition
 constexpr int ROWS = 256 / ROW_LANES;           // segments (= cameras) per 256-thread workgroup
 static_assert(ROW_LANES == 8 || ROW_LANES == 16 || ROW_LANES == 32, "row-form kernels: 8, 16 or 32 lanes per segment");
 struct RowSeg { int c, k, beg, end, l16; bool live; };   // l16: lane inside the segment
-__device__ inline void row_segment(const int* __restrict__ offk, int n_cams, RowSeg& s) {
-  s.k = blockIdx.x % NPART;
-  s.c = (int)(blockIdx.x / NPART) * ROWS + (int)(threadIdx.x / ROW_LANES);
+__device__ inline void row_segment(const int* __restrict__ offk, int n_cams, int band, RowSeg& s) {
+  int group;
+  group_of_block((n_cams + ROWS - 1) / ROWS, band, group, s.k);
+  s.c = group * ROWS + (int)(threadIdx.x / ROW_LANES);
   s.l16 = threadIdx.x % ROW_LANES;
   s.live = s.c < n_cams;
   s.beg = s.live ? offk[s.c * (NPART + 1) + s.k] : 0;
@@ -354,10 +371,10 @@ template <bool ROBUST>
 __global__ void __launch_bounds__(ROW_LANES * ROWS)
 k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
                    const int* __restrict__ c_pt, const double2* __restrict__ c_uv,
-                   double fx, double fy, double cx, double cy, double hub_c, int n_cams,
+                   double fx, double fy, double cx, double cy, double hub_c, int n_cams, int band,
                    double2* __restrict__ c_w, int* __restrict__ c_ptf, double* __restrict__ partL) {
   RowSeg s;
-  row_segment(offk, n_cams, s);
+  row_segment(offk, n_cams, band, s);
   double acc[27];
 #pragma unroll
   for (int q = 0; q < 27; ++q) acc[q] = 0.0;
@@ -411,9 +428,10 @@ template <bool ROBUST>
 __global__ void __launch_bounds__(ROW_LANES * ROWS)
 k_camrow_schur_diag(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
                     const int* __restrict__ c_pt, const double2* __restrict__ c_w, const double* __restrict__ Hppinv,
-                    double fx, double fy, int n_cams, int fixed_cam, double* __restrict__ part6, double* __restrict__ partE) {
+                    double fx, double fy, int n_cams, int band, int fixed_cam, double* __restrict__ part6,
+                    double* __restrict__ partE) {
   RowSeg s;
-  row_segment(offk, n_cams, s);
+  row_segment(offk, n_cams, band, s);
   double acc[27];
 #pragma unroll
   for (int q = 0; q < 27; ++q) acc[q] = 0.0;
