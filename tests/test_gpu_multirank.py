@@ -13,6 +13,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return str(port)
+
 WORKER = r"""
 import json, os, sys
 import numpy as np
@@ -50,7 +59,7 @@ def test_two_ranks_on_one_gpu_match_single_rank(tmp_path):
     script.write_text(WORKER % dict(root=ROOT, out=str(tmp_path)))
     env = dict(os.environ, BA_COMM="shm")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", str(script)]
+           "--master-port", _free_port(), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     p = make_problem(14, 1500, 5, seed=11, outlier_frac=0.02)
@@ -114,7 +123,7 @@ def test_spmd_run_on_two_ranks_leaves_the_same_map_everywhere(tmp_path):
     script.write_text(RUN_WORKER % dict(root=ROOT, out=str(tmp_path)))
     env = dict(os.environ, BA_COMM="shm")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29537", str(script)]
+           "--master-port", _free_port(), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     p = make_problem(12, 1200, 5, seed=17)
