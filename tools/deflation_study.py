@@ -75,5 +75,44 @@ def main():
             print(f"   + deflation, {nseg} segments x 6 = {Wd.shape[1]} vectors: {it1} (to 0.1), {it2} (to 0.01)")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 2 and sys.argv[2] == "cluster"):
     main()
+
+
+def cluster_jacobi_study(n_cams=400):
+    """Same problem: PCG iterations with cluster-Jacobi preconditioners (diagonal blocks of m consecutive
+    cameras of the explicit Schur complement) instead of the per-camera Schur-Jacobi blocks."""
+    scale = n_cams / 1723.0
+    p = make_bal_like(n_cams=n_cams, n_pts=int(156502 * scale), n_obs_target=int(678718 * scale), seed=0)
+    out = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, 0, "huber", max_iters=6, ftol=0, xtol=0, gtol=0,
+                     pcg_tol=0.1, pcg_max_iters=400)
+    ne = o.normal_equations(out["cams"], out["pts"], p.cam_idx, p.pt_idx, p.uv, p.K4, 0, "huber")
+    for lam in (1e-4, 1e-6):
+        op = o.SchurOperator(ne, p.cam_idx, p.pt_idx, lam, 0)
+        S = np.stack([op.apply(np.eye(6 * p.n_cams)[j].reshape(p.n_cams, 6)).ravel() for j in range(6 * p.n_cams)], axis=1)
+        rhs = op.rhs().ravel()
+
+        def pcg_dense(Mi_apply, tol, max_iters=5000):
+            x = np.zeros_like(rhs); r = rhs.copy(); z = Mi_apply(r); pv = z.copy(); rz = r @ z; rz0 = rz; it = 0
+            while it < max_iters:
+                q = S @ pv; a = rz / (pv @ q); x += a * pv; r -= a * q; z = Mi_apply(r); rzn = r @ z; it += 1
+                if rzn <= tol * tol * rz0: break
+                pv = z + (rzn / rz) * pv; rz = rzn
+            return it
+        for m in (1, 2, 4, 8, 16, 32):
+            blocks = []
+            for c0 in range(0, p.n_cams, m):
+                sl = slice(6 * c0, 6 * min(p.n_cams, c0 + m))
+                blocks.append((sl, np.linalg.inv(S[sl, sl])))
+
+            def Mi(v):
+                out_ = np.empty_like(v)
+                for sl, B in blocks:
+                    out_[sl] = B @ v[sl]
+                return out_
+            print(f"lambda {lam:g}: cluster-Jacobi, {m:2d} cameras per block: {pcg_dense(Mi, 0.1)} iterations to 0.1, "
+                  f"{pcg_dense(Mi, 0.01)} to 0.01")
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "cluster":
+    cluster_jacobi_study(int(sys.argv[1]))
