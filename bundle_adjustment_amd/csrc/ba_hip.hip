@@ -442,6 +442,15 @@ static int allreduce(ba_handle* h, double* buf, size_t count, bool is_max = fals
 extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64_t n_obs, const int32_t* cam_idx,
                               const int32_t* pt_idx_in, const double* uv, const double K4[4], int32_t fixed_cam) {
   const int32_t* pt_idx = pt_idx_in;
+  // BA_TIME_SETUP=1: stage times of this call on stderr (host sorts are the bulk of it at C3)
+  const bool timed = getenv("BA_TIME_SETUP") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto stage = [&](const char* name) {
+    if (!timed) return;
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "ba_set_problem %-28s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
   if (!h) return fail(BA_ERR_INVALID, "null handle");
   if (n_cams <= 0 || n_pts < 0 || n_obs < 0 || n_obs > 0x7fffffffLL) return fail(BA_ERR_INVALID, "bad sizes");
   if (n_obs > 0 && (!cam_idx || !pt_idx || !uv)) return fail(BA_ERR_INVALID, "null observation arrays");
@@ -451,6 +460,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     if (cam_idx[i] < 0 || cam_idx[i] >= n_cams) return fail(BA_ERR_INVALID, "cam_idx[%lld]=%d out of range", (long long)i, cam_idx[i]);
     if (pt_idx[i] < 0 || pt_idx[i] >= n_pts) return fail(BA_ERR_INVALID, "pt_idx[%lld]=%d out of range", (long long)i, pt_idx[i]);
   }
+  stage("validate");
   if (set_device(h)) return BA_ERR_HIP;
   const int Nc = n_cams, Np = n_pts, No = (int)n_obs;
   // internal point numbering.  When the whole camera table fits in LDS nothing is gained by
@@ -473,34 +483,36 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   std::vector<int> pt_new(No);
   for (int i = 0; i < No; ++i) pt_new[i] = slot[pt_idx[i]];
   pt_idx = pt_new.data();
+  stage("point numbering");
   // point order: stable counting sort by point (keeps the caller's order inside a point)
   std::vector<int> pt_off(Np + 1, 0);
   for (int i = 0; i < No; ++i) pt_off[pt_idx[i] + 1]++;
   for (int p = 0; p < Np; ++p) pt_off[p + 1] += pt_off[p];
+  // (only the indices are permuted on the host; the pixels follow on the device, k_gather_uv)
   std::vector<int> p_cam(No), p_src(No);
-  std::vector<double2> p_uv(No);
   {
     std::vector<int> pc(pt_off.begin(), pt_off.end() - 1);
     for (int i = 0; i < No; ++i) {
       const int b = pc[pt_idx[i]]++;
-      p_cam[b] = cam_idx[i]; p_src[b] = i; p_uv[b] = make_double2(uv[2 * (size_t)i], uv[2 * (size_t)i + 1]);
+      p_cam[b] = cam_idx[i]; p_src[b] = i;
     }
   }
+  stage("sort by point");
   // camera order: stable counting sort of the POINT-ordered list by camera, so that every
   // camera's observations are ascending in point index (needed by the partition split)
   std::vector<int> cam_off(Nc + 1, 0);
   for (int i = 0; i < No; ++i) cam_off[cam_idx[i] + 1]++;
   for (int c = 0; c < Nc; ++c) cam_off[c + 1] += cam_off[c];
   std::vector<int> c_pt(No), c_orig(No);
-  std::vector<double2> c_uv(No);
   {
     std::vector<int> cc(cam_off.begin(), cam_off.end() - 1);
     for (int p = 0; p < Np; ++p)
       for (int j = pt_off[p]; j < pt_off[p + 1]; ++j) {
         const int a = cc[p_cam[j]]++;
-        c_pt[a] = p; c_orig[a] = p_src[j]; c_uv[a] = p_uv[j];
+        c_pt[a] = p; c_orig[a] = p_src[j];
       }
   }
+  stage("sort by camera");
   // partition split: every camera's (point-sorted) list is cut into NPART equal-count chunks.  For
   // uniformly spread observations chunk k covers about the k-th eighth of the point table (what
   // keeps it resident in XCD k's L2); for band-structured data the chunks stay balanced and are
@@ -516,11 +528,15 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   {
     long long in_partition = 0, in_band = 0;
     if (Np > 0) {
+      std::vector<unsigned char> slice_of(Np);           // p * NPART / Np without a division per observation
+      for (int k = 0; k < NPART; ++k)
+        for (long long q = ((long long)k * Np + NPART - 1) / NPART; q < ((long long)(k + 1) * Np + NPART - 1) / NPART; ++q)
+          slice_of[q] = (unsigned char)k;
       for (int c = 0; c < Nc; ++c) {
         const int cam_slice = (int)(((long long)c * NPART) / Nc);
         for (int k = 0; k < NPART; ++k)
           for (int a = offk[(size_t)c * (NPART + 1) + k]; a < offk[(size_t)c * (NPART + 1) + k + 1]; ++a) {
-            const int pt_slice = (int)(((long long)c_pt[a] * NPART) / Np);
+            const int pt_slice = slice_of[c_pt[a]];
             in_partition += pt_slice == k;
             in_band += pt_slice == cam_slice;
           }
@@ -529,6 +545,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     h->cam_band = in_band > in_partition;
     if (const char* e = getenv("BA_CAM_BAND")) h->cam_band = atoi(e) != 0;
   }
+  stage("partitions + XCD statistic");
   h->Nc = Nc; h->Np = Np; h->Nobs = No; h->fixed = fixed_cam;
   memcpy(h->K4, K4, sizeof h->K4);
   h->nblkV = (Nc + VEC_CAMS - 1) / VEC_CAMS;
@@ -586,6 +603,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     win[h->nblkP + b] = window_of(lo, hi);
   }
   h->lds_bytes = max_win;
+  stage("long tracks + windows");
   const size_t nobs1 = std::max(No, 1), np1 = std::max(Np, 1);
   HIPCHECK(h->offk.alloc((size_t)Nc * (NPART + 1))); HIPCHECK(h->pt_off.alloc(Np + 1));
   HIPCHECK(h->slot.alloc(np1));
@@ -622,16 +640,24 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(hipMemsetAsync(h->camA[0].p, 0, TA * (size_t)Nc * sizeof(double), h->stream));
   HIPCHECK(hipMemsetAsync(h->camA[1].p, 0, TA * (size_t)Nc * sizeof(double), h->stream));
   h->lb = 0;
+  stage("allocations");
   HIPCHECK(hipMemcpyAsync(h->offk.p, offk.data(), offk.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(hipMemcpyAsync(h->pt_off.p, pt_off.data(), (Np + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream));
   if (No > 0) {
     HIPCHECK(hipMemcpyAsync(h->c_pt.p, c_pt.data(), No * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipMemcpyAsync(h->c_orig.p, c_orig.data(), No * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipMemcpyAsync(h->p_cam.p, p_cam.data(), No * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(hipMemcpyAsync(h->c_uv.p, c_uv.data(), No * sizeof(double2), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(hipMemcpyAsync(h->p_uv.p, p_uv.data(), No * sizeof(double2), hipMemcpyHostToDevice, h->stream));
+    // pixels: uploaded once in the caller's order, permuted into both orderings on the device
+    // (staging: the residual buffer for the pixels, a flagged-index buffer for the point-order permutation)
+    HIPCHECK(h->rbuf.alloc(2 * (size_t)No));
+    HIPCHECK(hipMemcpyAsync(h->rbuf.p, uv, 2 * (size_t)No * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipMemcpyAsync(h->c_ptf[0].p, p_src.data(), No * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    const dim3 gg((No + 255) / 256), gb(256);
+    hipLaunchKernelGGL(k_gather_uv, gg, gb, 0, h->stream, (const double2*)h->rbuf.p, (const int*)h->c_ptf[0].p, No, h->p_uv.p);
+    hipLaunchKernelGGL(k_gather_uv, gg, gb, 0, h->stream, (const double2*)h->rbuf.p, (const int*)h->c_orig.p, No, h->c_uv.p);
   }
   HIPCHECK(hipStreamSynchronize(h->stream));   // host vectors go out of scope
+  stage("upload");
   h->have_problem = true;
   h->have_params = false;
   h->linearized = false;

@@ -78,6 +78,12 @@ __global__ void k_cam_prepare(const double* __restrict__ cams, double* __restric
   for (int q = 0; q < 12; ++q) camA[TA * c + q] = cs[CS * c + q];
 }
 
+// out[j] = uv[idx[j]]: the caller-order pixels into point order / camera order (ba_set_problem)
+__global__ void k_gather_uv(const double2* __restrict__ uv, const int* __restrict__ idx, int n, double2* __restrict__ out) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) out[j] = uv[idx[j]];
+}
+
 // pts (Np,3) -> X slots of the point table; table (Np,8) -> pts
 // `slot[p]` = internal (locality-sorted) index of the caller's point p
 __global__ void k_pack_points(const double* __restrict__ pts, const int* __restrict__ slot, int n_pts,
