@@ -1,26 +1,30 @@
 // HIP kernels of the bundle-adjustment solve step (gfx950).
 //
 // Data in HBM (built once per problem in ba_set_problem, see DESIGN.md "Layout"):
-//   points are renumbered internally by the first camera that sees them (slot[]), so that a run of
+//   points keep the caller's numbering when the whole camera table fits in LDS; otherwise they are
+//   renumbered internally (slot[]) by the mean index of the cameras that see them, so that a run of
 //   consecutive points is seen from a narrow window of cameras whenever the data has that locality
 //   ptab[2][Np][8]   point records {X0 X1 X2 - y0 y1 y2 -}: one 64-byte sector per point, so a
 //                    camera-ordered pass fetches everything it needs about a point with one
 //                    sector; [cur] = accepted points, [1-cur] = trial points; y = PCG scratch
 //   camera order:    observations of camera c are [cam_off[c], cam_off[c+1]), sorted by point;
 //                    offk[c][k] cuts them into NPART equal-count chunks ("partitions")
-//                    -> c_pt (int32), c_uv, c_w (double2), c_orig (caller's row)
-//   point order:     observations of point p are [pt_off[p], pt_off[p+1]) -> p_cam, p_uv, p_w
+//                    -> c_pt (int32), c_uv, c_w (double2), c_orig (caller's row), c_ptf (c_pt with
+//                    the "weights are not (1, 1)" flag, written by the linearisation)
+//   point order:     observations of point p are [pt_off[p], pt_off[p+1]) -> p_cam, p_uv, p_w, p_camf
 //   cs[2][Nc][24]    per-camera state R t M (camera_state), camA[2][Nc][18] = R t | vtil, the
 //                    packed table the point passes stage in LDS (vtil = camera vector of the pass)
 //
-// Camera passes (k_cam_*): one WAVE per (camera, point partition); the workgroup index is
-// laid out so that blockIdx % NPART is the partition.  Workgroups are dealt round-robin
-// over the 8 XCDs, so each XCD only ever touches 1/8 of the point table and keeps it in
-// its own 4 MB L2 (speed only: results do not depend on the placement).  Per-(partition,
-// camera) partial sums are combined, in fixed order, by the consuming kernel.
+// Camera passes (k_cam_*: a WAVE, k_camrow_*: a 16-lane row, per (camera, partition) segment).
+// Workgroups are dealt round-robin over the 8 XCDs; group_of_block maps a workgroup to its segment
+// so that an XCD keeps gathering from one eighth of the point table (partition x of every camera, or
+// all partitions of the x-th eighth of the cameras for band-structured data) and holds it in its
+// own 4 MB L2.  Speed only: results do not depend on the placement.  Per-(partition, camera)
+// partial sums are combined, in fixed order, by the consuming kernel.
 //
-// Point passes (k_pt_*): LPP lanes per point walk its observations (software-prefetched
-// index stream), the per-camera table sits in LDS, lanes are combined with DPP row shifts.
+// Point passes (k_pt_*): LPP lanes per point (a 16-lane row for long tracks) walk its observations
+// (software-prefetched index stream), the per-camera table sits in LDS, lanes are combined with
+// DPP row shifts; workgroup ranges are grouped per XCD like the camera passes' slices.
 //
 // Every sum has a fixed order: results are bitwise reproducible run to run.
 #pragma once
