@@ -212,7 +212,7 @@ __device__ inline void m_congruence(const double* __restrict__ M, double (&A)[6]
   }
 }
 
-// Combine the NPART partial sums of k_cam_linearize (fixed order), apply M:
+// Combine the NPART partial sums of k_camrow_linearize (fixed order), apply M:
 //   Hcc[c] (21) = Jc^T w Jc,  bc[c] (6) = Jc^T w r  (zero for the fixed camera).
 __device__ inline void lin_finalize_camera(const double* __restrict__ partL, const double* __restrict__ cam, int n_cams,
                                            int c, int fixed_cam, double* __restrict__ H, double* __restrict__ b) {
@@ -376,7 +376,8 @@ __device__ inline void load_cam12(const double* __restrict__ cs, int c, double (
   for (int q = 0; q < 6; ++q) { const double2 t = cp[q]; cam[2 * q] = t.x; cam[2 * q + 1] = t.y; }
 }
 
-// K2a (row form): same outputs as k_cam_linearize
+// K2a: camera half of the normal equations, pre-M: partL[(k*Nc + c)*27 ..] = 21 sums of Jc^T w Jc (upper triangle), 6 of Jc^T w r;
+// IRLS weights and flagged indices of camera-ordered observations when ROBUST
 template <bool ROBUST>
 __global__ void __launch_bounds__(ROW_LANES * ROWS)
 k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,

@@ -441,7 +441,7 @@ def lm_solve(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam=-1, loss='linear',
              max_iters=50, ftol=1e-10, xtol=1e-10, gtol=1e-10, lam0=1e-4,
              pcg_tol=1e-1, pcg_max_iters=200, precond='schur_jacobi', verbose=False):
     """CPU mirror of the device LM / Schur / PCG loop (same formulas, same update
-    rules, same stopping tests) -- see bundle_adjustment_amd/csrc/ba_solver.hip.
+    rules, same stopping tests) -- see ba_solve in bundle_adjustment_amd/csrc/ba_hip.hip.
     Returns dict(cams, pts, iterations, accepted, sse0, sse, cost0, cost, pcg_iters,
     history)."""
     cams = np.array(cams, dtype=np.float64).reshape(-1, 6)
