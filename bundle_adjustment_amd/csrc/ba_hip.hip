@@ -665,7 +665,10 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
 }
 
 static double* bc_ptr(ba_handle* h) { return h->HccBc.p + 21 * (size_t)h->Nc; }
-static double* uy_ptr(ba_handle* h) { return h->part6.p + 6 * (size_t)NPART * h->Nc; }
+// part6 buffer: [u.y word, pad | NPART x Nc x 6 partial sums]; the u.y word sits in FRONT of partition 0 so that a
+// multi-rank job all-reduces it together with the folded partition (one contiguous message)
+static double* uy_ptr(ba_handle* h) { return h->part6.p; }
+static double* p6_ptr(ba_handle* h) { return h->part6.p + 2; }
 static int cam_grid(ba_handle* h) { return ((h->Nc + WPB - 1) / WPB) * NPART; }
 static int row_grid(ba_handle* h) { return ((h->Nc + ROWS - 1) / ROWS) * NPART; }
 
@@ -815,14 +818,14 @@ static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int
   Scope sc(h, diag ? BA_K_PRECOND : BA_K_SCHUR_CAM);
   const int w = h->cur;
 #define CS_ARGS h->cs[w].p, h->ptab[w].p, h->offk.p, (robust ? h->c_ptf[h->lb].p : h->c_pt.p), h->c_w[h->lb].p, h->K4[0], h->K4[1], h->Nc, h->cam_band, h->fixed,        \
-                h->part6.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->partA.p,                                   \
+                p6_ptr(h), k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->partA.p,                                   \
                 (h->Np > 0 ? h->nblkP + h->nblkL : 0), uy_ptr(h)
   const dim3 g(cam_grid(h) + (pcg ? 1 : 0)), b(64 * WPB);
   if (diag) {
     auto kern = robust ? k_camrow_schur_diag<true> : k_camrow_schur_diag<false>;
     hipLaunchKernelGGL(kern, dim3(row_grid(h)), dim3(ROW_LANES * ROWS), 0, h->stream, h->cs[w].p, h->ptab[w].p, h->offk.p,
                        (robust ? h->c_ptf[h->lb].p : h->c_pt.p), h->c_w[h->lb].p, h->Hppinv.p, h->K4[0], h->K4[1], h->Nc,
-                       h->cam_band, h->fixed, h->part6.p, h->partE.p);
+                       h->cam_band, h->fixed, p6_ptr(h), h->partE.p);
   } else if (pcg) {
     if (h->jac_f32) {
       if (robust) hipLaunchKernelGGL((k_cam_schur<true, true, float>), g, b, 0, h->stream, CS_ARGS);
@@ -871,19 +874,32 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
 #undef PS_TAIL
 }
 
-// multi-rank: the per-partition partial sums themselves are all-reduced (part6 with the u.y word
-// behind it; partE with the right-hand side pass), so every consumer kernel is the same as on one
-// rank and sums the NPART partitions afterwards.  Single rank: nothing.
+// multi-rank: a buffer of NPART per-partition partial sums is folded in place (partition 0 <- the sum
+// in partition order, the others <- 0) and only partition 0 is all-reduced; the consumers, which add
+// the NPART partitions, then read "total + 0 + ... + 0" and stay the kernels they are on one rank.
+// An eighth of the bytes on the wire for two launch-floor kernels.  Single rank: nothing.
+static int fold_and_reduce(ba_handle* h, double* parts, size_t n_per_part, double* msg, size_t msg_count) {
+  if (h->world == 1) return BA_OK;
+  {
+    Scope sc(h, BA_K_MISC);
+    hipLaunchKernelGGL(k_fold_parts, dim3((unsigned)((n_per_part + 255) / 256)), dim3(256), 0, h->stream, parts, n_per_part, NPART);
+  }
+  return allreduce(h, msg, msg_count);
+}
+static int exchange_partL(ba_handle* h, int buf) {
+  return fold_and_reduce(h, h->partL[buf].p, 27 * (size_t)h->Nc, h->partL[buf].p, 27 * (size_t)h->Nc);
+}
 static int exchange_schur(ba_handle* h, bool with_diag) {
   if (h->world == 1) return BA_OK;
-  if (int rc = allreduce(h, h->part6.p, 6 * (size_t)NPART * h->Nc + 1)) return rc;
-  if (with_diag) return allreduce(h, h->partE.p, 21 * (size_t)NPART * h->Nc);
+  // the message starts at the u.y word in front of partition 0
+  if (int rc = fold_and_reduce(h, p6_ptr(h), 6 * (size_t)h->Nc, uy_ptr(h), 2 + 6 * (size_t)h->Nc)) return rc;
+  if (with_diag) return fold_and_reduce(h, h->partE.p, 21 * (size_t)h->Nc, h->partE.p, 21 * (size_t)h->Nc);
   return BA_OK;
 }
 // finalize = true: fold the fresh camera-half partials into Hcc | bc inside the same kernel
 static void launch_pcg_setup(ba_handle* h, double lambda, bool schur_diag, bool finalize) {
   Scope sc(h, BA_K_PCG_UPDATE);
-#define SU_ARGS h->partL[h->lb].p, h->HccBc.p, bc_ptr(h), h->part6.p, h->partE.p, NPART, h->cs[h->cur].p, lambda,           \
+#define SU_ARGS h->partL[h->lb].p, h->HccBc.p, bc_ptr(h), p6_ptr(h), h->partE.p, NPART, h->cs[h->cur].p, lambda,           \
                 schur_diag ? 1 : 0, h->Nc, h->fixed, h->Hccd.p, h->Minv.p, h->gvec.p, h->x.p, h->r.p, h->p.p, h->s.p,     \
                 h->z.p, h->camA[h->cur].p, h->partV.p, h->st.p
   if (finalize) hipLaunchKernelGGL((k_pcg_setup<true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);
@@ -922,7 +938,7 @@ extern "C" int ba_linearize(ba_handle* h, int32_t loss, double f_scale, double* 
   if (!(f_scale > 0)) return fail(BA_ERR_INVALID, "f_scale must be positive");
   if (set_device(h)) return BA_ERR_HIP;
   launch_lin_cam(h, h->cur, h->lb, loss == BA_LOSS_HUBER, f_scale);
-  if (int rc = allreduce(h, h->partL[h->lb].p, 27 * (size_t)NPART * h->Nc)) return rc;
+  if (int rc = exchange_partL(h, h->lb)) return rc;
   launch_lin_finalize(h);
   launch_lin_pt(h, loss == BA_LOSS_HUBER, f_scale, 1.0);
   h->linearized = true;
@@ -983,7 +999,7 @@ extern "C" int ba_schur_apply(ba_handle* h, double lambda, const double* v, doub
   if (int rc = exchange_schur(h, false)) return rc;
   {
     Scope sc(h, BA_K_MISC);
-    hipLaunchKernelGGL(k_schur_combine, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->Hccd.p, h->vin.p, h->part6.p,
+    hipLaunchKernelGGL(k_schur_combine, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->Hccd.p, h->vin.p, p6_ptr(h),
                        NPART, h->cs[h->cur].p, h->Nc, h->fixed, h->z.p);
   }
   HIPCHECK(hipMemcpyAsync(out, h->z.p, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1078,7 +1094,7 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       fresh = true;
       // multi-rank: the camera-half partials of a freshly launched (not speculated) pass still
       // have to be all-reduced; the speculated pass was reduced right behind its launch
-      if (cam_half_unreduced) { if (int rc = allreduce(h, h->partL[h->lb].p, 27 * (size_t)NPART * Nc)) return rc; }
+      if (cam_half_unreduced) { if (int rc = exchange_partL(h, h->lb)) return rc; }
     }
     // ---- damped system, right-hand side, preconditioner, first PCG vectors
     if (int rc = damped_system(h, lambda, schur_diag, !fresh, fresh)) return rc;
@@ -1114,7 +1130,7 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       launch_cam_schur(h, robust, false, true, kk, tol2, opts->pcg_min_iters);
       if (int rc = exchange_schur(h, false)) return rc;
       Scope sc(h, BA_K_PCG_UPDATE);
-      hipLaunchKernelGGL(k_pcg_step, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, kk, h->part6.p, NPART,
+      hipLaunchKernelGGL(k_pcg_step, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, kk, p6_ptr(h), NPART,
                          (const double*)uy_ptr(h), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc,
                          h->fixed, tol2, opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA[h->cur].p,
                          h->partV.p, h->nblkV, h->st.p, h->d_flags, base);
@@ -1155,7 +1171,7 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     const bool speculated = (it + 1 < opts->max_iters);
     if (speculated) {
       launch_lin_cam(h, 1 - h->cur, 1 - h->lb, robust, fs);
-      if (int rc = allreduce(h, h->partL[1 - h->lb].p, 27 * (size_t)NPART * Nc)) return rc;
+      if (int rc = exchange_partL(h, 1 - h->lb)) return rc;
     }
     if (h->world > 1) HIPCHECK(hipEventSynchronize(h->ev_decide));
     else if (int rc = wait_flag(h, 2, seq)) return rc;

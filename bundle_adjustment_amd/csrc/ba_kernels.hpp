@@ -82,6 +82,16 @@ __global__ void k_cam_prepare(const double* __restrict__ cams, double* __restric
   for (int q = 0; q < 12; ++q) camA[TA * c + q] = cs[CS * c + q];
 }
 
+// In-place fold of nparts per-partition partial-sum arrays of n values each (multi-rank jobs, ahead of
+// the all-reduce): partition 0 <- sum over the partitions in partition order, the others <- 0.
+__global__ void k_fold_parts(double* __restrict__ parts, size_t n, int nparts) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = parts[i];
+  for (int k = 1; k < nparts; ++k) { s += parts[(size_t)k * n + i]; parts[(size_t)k * n + i] = 0.0; }
+  parts[i] = s;
+}
+
 // out[j] = uv[idx[j]]: the caller-order pixels into point order / camera order (ba_set_problem)
 __global__ void k_gather_uv(const double2* __restrict__ uv, const int* __restrict__ idx, int n, double2* __restrict__ out) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
