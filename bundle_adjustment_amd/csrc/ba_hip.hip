@@ -110,6 +110,7 @@ struct ba_handle {
   int device = 0;
   int n_cu = 256;              // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int xcd_ranges = 1;          // point-pass ranges grouped per XCD (BA_XCD_RANGES=0 turns it off; speed only)
+  int lanes = LPP;             // lanes per point in the point passes: LPP, or LPP_LONG for every point of a small problem
   int cam_band = 0;            // camera passes: XCD x takes camera range x (1) or partition x of every camera (0); see group_of_block
   hipStream_t stream = nullptr;
   bool have_problem = false, have_params = false, linearized = false;
@@ -199,8 +200,10 @@ extern "C" int ba_create(int device_id, ba_handle** out) {
   memset(h->h_flags, 0, 8 * sizeof(long long));
   HIPCHECK(hipHostGetDevicePointer((void**)&h->d_flags, h->h_flags, 0));
 #define BA_BIG_LDS(K) HIPCHECK(allow_big_lds(K))
-#define BA_BIG_LDS_LIN(R, L) BA_BIG_LDS((k_pt_linearize<R, L, LPP>)); BA_BIG_LDS((k_pt_linearize_both<R, L>))
+#define BA_BIG_LDS_LIN(R, L) BA_BIG_LDS((k_pt_linearize<R, L, LPP>)); BA_BIG_LDS((k_pt_linearize<R, L, LPP_LONG>)); \
+  BA_BIG_LDS((k_pt_linearize_both<R, L>))
 #define BA_BIG_LDS_SCH(R, M, L) BA_BIG_LDS((k_pt_schur<R, M, L, LPP, double>)); BA_BIG_LDS((k_pt_schur<R, M, L, LPP, float>)); \
+  BA_BIG_LDS((k_pt_schur<R, M, L, LPP_LONG, double>)); BA_BIG_LDS((k_pt_schur<R, M, L, LPP_LONG, float>));                       \
   BA_BIG_LDS((k_pt_schur_both<R, M, L, double>)); BA_BIG_LDS((k_pt_schur_both<R, M, L, float>))
   BA_BIG_LDS_LIN(true, true); BA_BIG_LDS_LIN(true, false); BA_BIG_LDS_LIN(false, true); BA_BIG_LDS_LIN(false, false);
   BA_BIG_LDS_SCH(true, 0, true); BA_BIG_LDS_SCH(true, 0, false); BA_BIG_LDS_SCH(false, 0, true); BA_BIG_LDS_SCH(false, 0, false);
@@ -555,7 +558,12 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   // started than the chip holds at once -- each then walks several rounds with one table fill
   // (C3 x 10: Schur point pass 133 -> 93 us); with camera windows the ranges stay one round long
   // so that the windows stay narrow.  BA_PT_BLOCKS overrides (tuning only).
-  const int pts_per_pass = PT_THREADS / LPP;
+  // A small problem (fewer LPP-lane workgroups than a quarter of the CUs: a sliding window, a shard of
+  // a multi-GPU job) gives every point a 16-lane row instead: eight times the workgroups, and a lane
+  // walks one or two observations instead of five.  BA_PT_LANES overrides (tuning only).
+  h->lanes = ((Np + PT_THREADS / LPP - 1) / (PT_THREADS / LPP)) * 4 < h->n_cu ? LPP_LONG : LPP;
+  if (const char* e = getenv("BA_PT_LANES")) h->lanes = atoi(e) == LPP_LONG ? LPP_LONG : LPP;
+  const int pts_per_pass = PT_THREADS / h->lanes;
   const int want = std::max(1, (Np + pts_per_pass - 1) / pts_per_pass);
   h->nblkP = std::min(want, 4096);
   const size_t full_table = (size_t)Nc * TA * sizeof(double);
@@ -575,6 +583,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     if (Np > 0) { std::nth_element(len.begin(), len.begin() + Np / 2, len.end()); med = len[Np / 2]; }
     const char* e = getenv("BA_LONG_TRACK");
     h->long_thr = e ? std::max(1, atoi(e)) : std::max(8, 2 * med);
+    if (h->lanes == LPP_LONG) h->long_thr = 0x7fffffff;       // every point already has a row
   }
   for (int p = 0; p < Np; ++p) if (pt_off[p + 1] - pt_off[p] > h->long_thr) long_pts.push_back(p);
   h->n_long = (int)long_pts.size();
@@ -798,8 +807,10 @@ static void launch_lin_pt(ba_handle* h, bool robust, double fscale, double lambd
     if (h->all_lds) { if (robust) LP_BOTH(true, true); else LP_BOTH(false, true); }
     else            { if (robust) LP_BOTH(true, false); else LP_BOTH(false, false); }
   } else {
-    if (h->all_lds) { if (robust) LP_LAUNCH(true, true, LPP, h->nblkP, wk); else LP_LAUNCH(false, true, LPP, h->nblkP, wk); }
-    else            { if (robust) LP_LAUNCH(true, false, LPP, h->nblkP, wk); else LP_LAUNCH(false, false, LPP, h->nblkP, wk); }
+#define LP_ONE(R, L) do { if (h->lanes == LPP) LP_LAUNCH(R, L, LPP, h->nblkP, wk); else LP_LAUNCH(R, L, LPP_LONG, h->nblkP, wk); } while (0)
+    if (h->all_lds) { if (robust) LP_ONE(true, true); else LP_ONE(false, true); }
+    else            { if (robust) LP_ONE(true, false); else LP_ONE(false, false); }
+#undef LP_ONE
   }
 #undef LP_BOTH
 #undef LP_LAUNCH
@@ -855,8 +866,12 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
   do {                                                                                                                      \
     if (h->nblkL) hipLaunchKernelGGL((k_pt_schur_both<R, M, L, JT>), dim3(h->nblkP + h->nblkL), dim3(PT_THREADS), lds,      \
                                      h->stream, PS_HEAD, wk, h->nblkP, wl, PS_TAIL);                                        \
-    else hipLaunchKernelGGL((k_pt_schur<R, M, L, LPP, JT>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, PS_HEAD, wk,  \
-                            PS_TAIL);                                                                                       \
+    else if (h->lanes == LPP)                                                                                               \
+      hipLaunchKernelGGL((k_pt_schur<R, M, L, LPP, JT>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, PS_HEAD, wk,     \
+                         PS_TAIL);                                                                                          \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((k_pt_schur<R, M, L, LPP_LONG, JT>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, PS_HEAD,    \
+                         wk, PS_TAIL);                                                                                      \
   } while (0)
 #define PS_MODE(R, L)                                                                 \
   do {                                                                                \
