@@ -558,19 +558,19 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   // started than the chip holds at once -- each then walks several rounds with one table fill
   // (C3 x 10: Schur point pass 133 -> 93 us); with camera windows the ranges stay one round long
   // so that the windows stay narrow.  BA_PT_BLOCKS overrides (tuning only).
-  // A small problem (fewer LPP-lane workgroups than a quarter of the CUs: a sliding window, a shard of
-  // a multi-GPU job) gives every point a 16-lane row instead: eight times the workgroups, and a lane
-  // walks one or two observations instead of five.  BA_PT_LANES overrides (tuning only).
-  h->lanes = ((Np + PT_THREADS / LPP - 1) / (PT_THREADS / LPP)) * 4 < h->n_cu ? LPP_LONG : LPP;
+  // A small problem (a sliding window, a shard of a multi-GPU job) gives every point a 16-lane row
+  // instead -- eight times the workgroups, a lane walks one or two observations instead of five -- as
+  // long as those workgroups are all resident at once.  BA_PT_LANES overrides (tuning only).
+  const size_t full_table = (size_t)Nc * TA * sizeof(double);
+  const bool table_fits = full_table <= (size_t)LDS_TAB_BYTES;
+  const int per_cu = !table_fits ? 1 : (int)std::max<size_t>(1, std::min<size_t>(2048 / PT_THREADS, (size_t)(160 * 1024) / (full_table + 1024)));
+  const int row_blocks = (Np + PT_THREADS / LPP_LONG - 1) / (PT_THREADS / LPP_LONG);
+  h->lanes = row_blocks <= h->n_cu * per_cu ? LPP_LONG : LPP;
   if (const char* e = getenv("BA_PT_LANES")) h->lanes = atoi(e) == LPP_LONG ? LPP_LONG : LPP;
   const int pts_per_pass = PT_THREADS / h->lanes;
   const int want = std::max(1, (Np + pts_per_pass - 1) / pts_per_pass);
   h->nblkP = std::min(want, 4096);
-  const size_t full_table = (size_t)Nc * TA * sizeof(double);
-  if (full_table <= (size_t)LDS_TAB_BYTES) {
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2048 / PT_THREADS, (size_t)(160 * 1024) / std::max<size_t>(full_table + 1024, 1)));
-    h->nblkP = std::min(h->nblkP, h->n_cu * per_cu);
-  }
+  if (table_fits) h->nblkP = std::min(h->nblkP, h->n_cu * per_cu);
   if (const char* e = getenv("BA_PT_BLOCKS")) h->nblkP = std::max(1, std::min(want, atoi(e)));
   if (const char* e = getenv("BA_XCD_RANGES")) h->xcd_ranges = atoi(e) != 0;
   h->ppb = std::max(1, (Np + h->nblkP - 1) / h->nblkP);
