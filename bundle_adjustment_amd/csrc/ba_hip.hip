@@ -676,6 +676,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
 static double* bc_ptr(ba_handle* h) { return h->HccBc.p + 21 * (size_t)h->Nc; }
 // part6 buffer: [u.y word, pad | NPART x Nc x 6 partial sums]; the u.y word sits in FRONT of partition 0 so that a
 // multi-rank job all-reduces it together with the folded partition (one contiguous message)
+constexpr int GMAX_HOST_SLOT = 40;   // word of the host-mapped scalar block that k_absmax2 writes (k_scalars uses [0, S_COUNT))
 static double* uy_ptr(ba_handle* h) { return h->part6.p; }
 static double* p6_ptr(ba_handle* h) { return h->part6.p + 2; }
 static int cam_grid(ba_handle* h) { return ((h->Nc + WPB - 1) / WPB) * NPART; }
@@ -1113,23 +1114,30 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     }
     // ---- damped system, right-hand side, preconditioner, first PCG vectors
     if (int rc = damped_system(h, lambda, schur_diag, !fresh, fresh)) return rc;
+    bool gtol_pending = false;     // single rank: max |gradient| lands in host-mapped memory, read at the first PCG verdict
     if (fresh && opts->gtol > 0) {
-      {
+      if (h->world == 1) {
         Scope sc(h, BA_K_MISC);
-        hipLaunchKernelGGL(k_absmax, dim3(1), dim3(256), 0, h->stream, bc_ptr(h), 6 * (size_t)Nc, h->scal.p + S_GMAX_C);
-        hipLaunchKernelGGL(k_absmax, dim3(1), dim3(256), 0, h->stream, h->bp.p, 3 * (size_t)h->Np, h->scal.p + S_GMAX_P);
-      }
-      HIPCHECK(hipMemcpyAsync(h->h_gmax, h->scal.p + S_GMAX_C, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      HIPCHECK(hipStreamSynchronize(h->stream));
-      double gmax = std::max(h->h_gmax[0], h->h_gmax[1]);
-      if (h->world > 1) {   // bc is all-reduced (identical on every rank); bp is shard-local -> max over ranks
+        hipLaunchKernelGGL(k_absmax2, dim3(1), dim3(1024), 0, h->stream, (const double*)bc_ptr(h), 6 * (size_t)Nc,
+                           (const double*)h->bp.p, 3 * (size_t)h->Np, h->d_scal_host + GMAX_HOST_SLOT);
+        gtol_pending = true;
+      } else {
+        {
+          Scope sc(h, BA_K_MISC);
+          hipLaunchKernelGGL(k_absmax, dim3(1), dim3(256), 0, h->stream, bc_ptr(h), 6 * (size_t)Nc, h->scal.p + S_GMAX_C);
+          hipLaunchKernelGGL(k_absmax, dim3(1), dim3(256), 0, h->stream, h->bp.p, 3 * (size_t)h->Np, h->scal.p + S_GMAX_P);
+        }
+        HIPCHECK(hipMemcpyAsync(h->h_gmax, h->scal.p + S_GMAX_C, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(hipStreamSynchronize(h->stream));
+        double gmax = std::max(h->h_gmax[0], h->h_gmax[1]);
+        // bc is all-reduced (identical on every rank); bp is shard-local -> max over ranks
         HIPCHECK(hipMemcpyAsync(h->scal.p + 18, &gmax, sizeof(double), hipMemcpyHostToDevice, h->stream));
         if (int rc = allreduce(h, h->scal.p + 18, 1, true)) return rc;
         HIPCHECK(hipMemcpyAsync(h->h_gmax, h->scal.p + 18, sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(hipStreamSynchronize(h->stream));
         gmax = h->h_gmax[0];
+        if (gmax <= opts->gtol) { status = 3; break; }
       }
-      if (gmax <= opts->gtol) { status = 3; break; }
     }
     double t1 = now_s();
     sum->seconds_linearize += t1 - t0;
@@ -1138,6 +1146,7 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     // of iteration j-1 says "go on".  The
     // rule only depends on the (deterministic, rank-identical) verdicts, never on timing.
     int k = 0, pcg_done_iters = -1;
+    bool gtol_stop = false;
     const long long base = h->flag_base;
     h->flag_base += opts->pcg_max_iters + 8;
     auto launch_point_pass = [&](int kk) { launch_pt_schur(h, robust, 0, kk, tol2, opts->pcg_min_iters, base); };
@@ -1158,6 +1167,11 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     launch_point_pass(0);
     while (true) {
       if (int rc = wait_flag(h, 0, base + k + 1)) return rc;
+      // the gradient maximum was written by a kernel ahead of this probe: visible now
+      if (gtol_pending) {
+        gtol_pending = false;
+        if (h->h_scal[GMAX_HOST_SLOT] <= opts->gtol) { gtol_stop = true; break; }
+      }
       const long long payload = h->h_flags[1];
       if (payload > 0) { pcg_done_iters = (int)payload - 1; break; }
       if (int rc = launch_rest(k)) return rc;
@@ -1165,6 +1179,7 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       if (k >= opts->pcg_max_iters) break;
       launch_point_pass(k);
     }
+    if (gtol_stop) { status = 3; break; }      // converged by gradient: no step (the queued probe exits on its own)
     // ---- step, trial point, gain-ratio scalars
     {
       Scope sc(h, BA_K_MISC);

@@ -1184,6 +1184,24 @@ k_absmax(const double* __restrict__ v, size_t n, double* __restrict__ out) {
   if (threadIdx.x == 0) out[0] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
 }
 
+// out_host[0] = max(max |a|, max |b|) (single workgroup; a host-mapped word the host reads after a later
+// kernel of the stream has published its flag -- the gtol test costs no copy and no stream sync)
+__global__ void __launch_bounds__(1024)
+k_absmax2(const double* __restrict__ a, size_t na, const double* __restrict__ b, size_t nb, double* __restrict__ out_host) {
+  __shared__ double sm[16];
+  double m = 0.0;
+  for (size_t i = threadIdx.x; i < na; i += 1024) m = fmax(m, fabs(a[i]));
+  for (size_t i = threadIdx.x; i < nb; i += 1024) m = fmax(m, fabs(b[i]));
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = sm[0];
+    for (int w = 1; w < 16; ++w) t = fmax(t, sm[w]);
+    out_host[0] = t;
+  }
+}
+
 // Not-converged PCG state for the test / bench hooks that run one pass in isolation.
 __global__ void k_pcg_reset(PcgState* __restrict__ st, double* __restrict__ partV, int nblkV) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
