@@ -110,7 +110,7 @@ struct ba_handle {
   int device = 0;
   int n_cu = 256;              // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int xcd_ranges = 1;          // point-pass ranges grouped per XCD (BA_XCD_RANGES=0 turns it off; speed only)
-  int lanes = LPP;             // lanes per point in the point passes: LPP, or LPP_LONG for every point of a small problem
+  int lanes = LPP;             // lanes per point in the point passes: 2, or 4 / 8 / 16 for every point of a smaller problem
   int cam_band = 0;            // camera passes: XCD x takes camera range x (1) or partition x of every camera (0); see group_of_block
   hipStream_t stream = nullptr;
   bool have_problem = false, have_params = false, linearized = false;
@@ -200,15 +200,16 @@ extern "C" int ba_create(int device_id, ba_handle** out) {
   memset(h->h_flags, 0, 8 * sizeof(long long));
   HIPCHECK(hipHostGetDevicePointer((void**)&h->d_flags, h->h_flags, 0));
 #define BA_BIG_LDS(K) HIPCHECK(allow_big_lds(K))
-#define BA_BIG_LDS_LIN(R, L) BA_BIG_LDS((k_pt_linearize<R, L, LPP>)); BA_BIG_LDS((k_pt_linearize<R, L, LPP_LONG>)); \
-  BA_BIG_LDS((k_pt_linearize_both<R, L>))
-#define BA_BIG_LDS_SCH(R, M, L) BA_BIG_LDS((k_pt_schur<R, M, L, LPP, double>)); BA_BIG_LDS((k_pt_schur<R, M, L, LPP, float>)); \
-  BA_BIG_LDS((k_pt_schur<R, M, L, LPP_LONG, double>)); BA_BIG_LDS((k_pt_schur<R, M, L, LPP_LONG, float>));                       \
-  BA_BIG_LDS((k_pt_schur_both<R, M, L, double>)); BA_BIG_LDS((k_pt_schur_both<R, M, L, float>))
+#define BA_BIG_LDS_LIN(R, L) BA_BIG_LDS((k_pt_linearize<R, L, 2>)); BA_BIG_LDS((k_pt_linearize<R, L, 4>));        \
+  BA_BIG_LDS((k_pt_linearize<R, L, 8>)); BA_BIG_LDS((k_pt_linearize<R, L, 16>)); BA_BIG_LDS((k_pt_linearize_both<R, L>))
+#define BA_BIG_LDS_SCH1(R, M, L, LN) BA_BIG_LDS((k_pt_schur<R, M, L, LN, double>)); BA_BIG_LDS((k_pt_schur<R, M, L, LN, float>))
+#define BA_BIG_LDS_SCH(R, M, L) BA_BIG_LDS_SCH1(R, M, L, 2); BA_BIG_LDS_SCH1(R, M, L, 4); BA_BIG_LDS_SCH1(R, M, L, 8);     \
+  BA_BIG_LDS_SCH1(R, M, L, 16); BA_BIG_LDS((k_pt_schur_both<R, M, L, double>)); BA_BIG_LDS((k_pt_schur_both<R, M, L, float>))
   BA_BIG_LDS_LIN(true, true); BA_BIG_LDS_LIN(true, false); BA_BIG_LDS_LIN(false, true); BA_BIG_LDS_LIN(false, false);
   BA_BIG_LDS_SCH(true, 0, true); BA_BIG_LDS_SCH(true, 0, false); BA_BIG_LDS_SCH(false, 0, true); BA_BIG_LDS_SCH(false, 0, false);
   BA_BIG_LDS_SCH(true, 1, true); BA_BIG_LDS_SCH(true, 1, false); BA_BIG_LDS_SCH(false, 1, true); BA_BIG_LDS_SCH(false, 1, false);
 #undef BA_BIG_LDS_SCH
+#undef BA_BIG_LDS_SCH1
 #undef BA_BIG_LDS_LIN
 #undef BA_BIG_LDS
   *out = h;
@@ -558,15 +559,16 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   // started than the chip holds at once -- each then walks several rounds with one table fill
   // (C3 x 10: Schur point pass 133 -> 93 us); with camera windows the ranges stay one round long
   // so that the windows stay narrow.  BA_PT_BLOCKS overrides (tuning only).
-  // A small problem (a sliding window, a shard of a multi-GPU job) gives every point a 16-lane row
-  // instead -- eight times the workgroups, a lane walks one or two observations instead of five -- as
-  // long as those workgroups are all resident at once.  BA_PT_LANES overrides (tuning only).
+  // A smaller problem (a sliding window, a shard of a multi-GPU job) gives every point 4, 8 or 16 lanes
+  // instead of 2 -- more workgroups, fewer observations per lane -- the most for which the
+  // workgroups are still all resident at once.  BA_PT_LANES overrides (tuning only).
   const size_t full_table = (size_t)Nc * TA * sizeof(double);
   const bool table_fits = full_table <= (size_t)LDS_TAB_BYTES;
   const int per_cu = !table_fits ? 1 : (int)std::max<size_t>(1, std::min<size_t>(2048 / PT_THREADS, (size_t)(160 * 1024) / (full_table + 1024)));
-  const int row_blocks = (Np + PT_THREADS / LPP_LONG - 1) / (PT_THREADS / LPP_LONG);
-  h->lanes = row_blocks <= h->n_cu * per_cu ? LPP_LONG : LPP;
-  if (const char* e = getenv("BA_PT_LANES")) h->lanes = atoi(e) == LPP_LONG ? LPP_LONG : LPP;
+  h->lanes = LPP;
+  for (int ln = 16; ln > LPP; ln >>= 1)
+    if ((Np + PT_THREADS / ln - 1) / (PT_THREADS / ln) <= h->n_cu * per_cu) { h->lanes = ln; break; }
+  if (const char* e = getenv("BA_PT_LANES")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) h->lanes = v; }
   const int pts_per_pass = PT_THREADS / h->lanes;
   const int want = std::max(1, (Np + pts_per_pass - 1) / pts_per_pass);
   h->nblkP = std::min(want, 4096);
@@ -583,7 +585,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     if (Np > 0) { std::nth_element(len.begin(), len.begin() + Np / 2, len.end()); med = len[Np / 2]; }
     const char* e = getenv("BA_LONG_TRACK");
     h->long_thr = e ? std::max(1, atoi(e)) : std::max(8, 2 * med);
-    if (h->lanes == LPP_LONG) h->long_thr = 0x7fffffff;       // every point already has a row
+    if (h->lanes != LPP) h->long_thr = 0x7fffffff;           // more lanes per point already: no separate long-track rows
   }
   for (int p = 0; p < Np; ++p) if (pt_off[p + 1] - pt_off[p] > h->long_thr) long_pts.push_back(p);
   h->n_long = (int)long_pts.size();
@@ -808,7 +810,15 @@ static void launch_lin_pt(ba_handle* h, bool robust, double fscale, double lambd
     if (h->all_lds) { if (robust) LP_BOTH(true, true); else LP_BOTH(false, true); }
     else            { if (robust) LP_BOTH(true, false); else LP_BOTH(false, false); }
   } else {
-#define LP_ONE(R, L) do { if (h->lanes == LPP) LP_LAUNCH(R, L, LPP, h->nblkP, wk); else LP_LAUNCH(R, L, LPP_LONG, h->nblkP, wk); } while (0)
+#define LP_ONE(R, L)                                             \
+  do {                                                           \
+    switch (h->lanes) {                                          \
+      case 4: LP_LAUNCH(R, L, 4, h->nblkP, wk); break;           \
+      case 8: LP_LAUNCH(R, L, 8, h->nblkP, wk); break;           \
+      case 16: LP_LAUNCH(R, L, 16, h->nblkP, wk); break;         \
+      default: LP_LAUNCH(R, L, 2, h->nblkP, wk); break;          \
+    }                                                            \
+  } while (0)
     if (h->all_lds) { if (robust) LP_ONE(true, true); else LP_ONE(false, true); }
     else            { if (robust) LP_ONE(true, false); else LP_ONE(false, false); }
 #undef LP_ONE
@@ -863,16 +873,20 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
   const size_t lds = h->lds_bytes;
   long long* flag = (mode == 0 && flag_base > 0) ? h->d_flags : (long long*)nullptr;
   // data with long tracks: short and long tracks in one launch (workgroup 0 publishes the verdict)
+#define PS_ONE(R, M, L, LN, JT) \
+  hipLaunchKernelGGL((k_pt_schur<R, M, L, LN, JT>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, PS_HEAD, wk, PS_TAIL)
 #define PS_LAUNCH(R, M, L, JT)                                                                                              \
   do {                                                                                                                      \
     if (h->nblkL) hipLaunchKernelGGL((k_pt_schur_both<R, M, L, JT>), dim3(h->nblkP + h->nblkL), dim3(PT_THREADS), lds,      \
                                      h->stream, PS_HEAD, wk, h->nblkP, wl, PS_TAIL);                                        \
-    else if (h->lanes == LPP)                                                                                               \
-      hipLaunchKernelGGL((k_pt_schur<R, M, L, LPP, JT>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, PS_HEAD, wk,     \
-                         PS_TAIL);                                                                                          \
-    else                                                                                                                    \
-      hipLaunchKernelGGL((k_pt_schur<R, M, L, LPP_LONG, JT>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, PS_HEAD,    \
-                         wk, PS_TAIL);                                                                                      \
+    else {                                                                                                                  \
+      switch (h->lanes) {                                                                                                   \
+        case 4: PS_ONE(R, M, L, 4, JT); break;                                                                              \
+        case 8: PS_ONE(R, M, L, 8, JT); break;                                                                              \
+        case 16: PS_ONE(R, M, L, 16, JT); break;                                                                            \
+        default: PS_ONE(R, M, L, 2, JT); break;                                                                             \
+      }                                                                                                                     \
+    }                                                                                                                       \
   } while (0)
 #define PS_MODE(R, L)                                                                 \
   do {                                                                                \
@@ -886,6 +900,7 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
   else            { if (robust) PS_MODE(true, false); else PS_MODE(false, false); }
 #undef PS_MODE
 #undef PS_LAUNCH
+#undef PS_ONE
 #undef PS_HEAD
 #undef PS_TAIL
 }
