@@ -314,3 +314,25 @@ def test_multi_round_point_ranges(solver, monkeypatch):
     assert _rel(got[4], ref[4]) <= 1e-12 and _rel(got[5], ref[5]) <= 1e-12
     assert abs(got[6]["final_cost"] - ref[6]["final_cost"]) <= 1e-10 * ref[6]["final_cost"]
     assert np.abs(got[7][0] - ref[7][0]).max() <= 1e-8 and np.abs(got[7][1] - ref[7][1]).max() <= 1e-7
+
+
+@pytest.mark.parametrize("lanes", [2, 4, 8, 16])
+def test_lanes_per_point_variants(solver, monkeypatch, lanes):
+    """ba_set_problem picks 2, 4, 8 or 16 lanes per point from the problem size; every choice must give
+    the same per-point blocks (to the rounding of the re-grouped sums) and the same solve."""
+    p = make_problem(30, 4000, 7, seed=6, outlier_frac=0.01)
+    v = np.random.default_rng(1).normal(size=(p.n_cams, 6))
+    kw = dict(loss="huber", max_iters=12, ftol=1e-12, xtol=1e-12, gtol=0.0, pcg_tol=1e-2)
+    ne = o.normal_equations(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, 0, "huber")
+    monkeypatch.setenv("BA_PT_LANES", str(lanes))
+    solver.set_problem(p)
+    Hcc, bc, Hpp, bp = solver.linearize("huber")
+    assert _rel(Hpp, o.sym3_pack(ne["Hpp"])) <= 1e-9 and _rel(bp, ne["bp"]) <= 1e-9
+    op = o.SchurOperator(ne, p.cam_idx, p.pt_idx, 1e-3, 0)
+    assert _rel(solver.schur_rhs(1e-3), op.rhs()) <= 1e-9
+    vv = v.copy(); vv[0] = 0
+    assert _rel(solver.schur_apply(1e-3, vv), op.apply(vv)) <= 1e-9
+    out = solver.solve(**kw)
+    ref = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, 0, "huber", max_iters=12, ftol=1e-12, xtol=1e-12,
+                     gtol=0.0, pcg_tol=1e-2)
+    assert abs(out["final_cost"] - ref["cost"]) <= 1e-8 * ref["cost"]
