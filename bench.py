@@ -245,7 +245,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline_port(prob)
         line = {
-            "metric": "LM iterations/sec (final reprojection RMSE in config.final_rmse_px), 1k cams / 100k pts",
+            "metric": "LM iterations/sec + final reprojection RMSE, 1k cams / 100k pts",   # BASELINE.json; RMSE: config.final_rmse_px
             "value": round(steps_done / dt, 3), "unit": "LM iterations/s", "n_gpus": world, "steps": steps_done,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / max(steps_done, 1), 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
