@@ -1,5 +1,6 @@
 """GPU: the drop-in BundleAdjuster end to end on maps rebuilt from the reference's goldens."""
 import io
+import os
 import re
 from contextlib import redirect_stdout
 
@@ -12,6 +13,7 @@ from oracle import ba_oracle as o
 from tests.helpers import golden_cost_case, load_golden, rebuild_map
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LOG_RE = re.compile(r"^    -> LBA Complete\. Initial Cost: (\d+\.\d\d), Final Cost: (\d+\.\d\d), Improvement: (-?\d+\.\d\d)%$")
 
 
@@ -71,3 +73,39 @@ def test_run_on_synthetic_c2_map():
     m = LOG_RE.match(log.splitlines()[1])
     assert m and float(m.group(3)) > 90.0
     ba.close()
+
+
+def test_integration_md_binding_runs():
+    """The ctypes binding printed in INTEGRATION.md (what a reference maintainer would paste) is
+    executed as written -- only the library path and the cv2.Rodrigues call are bound to local names --
+    and must reproduce the Solver class's result."""
+    import re
+    import types
+    from bundle_adjustment_amd import hip_backend
+    from bundle_adjustment_amd.rotations import matrices_to_rvecs, rvecs_to_matrices
+    from bundle_adjustment_amd.synthetic import make_problem
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.findall(r"```python\n(.*?)```", text, re.S)[1]
+    assert 'C.CDLL("libba_hip.so")' in code
+    code = code.replace('C.CDLL("libba_hip.so")', f"C.CDLL({hip_backend.LIB_PATH!r})")
+    cv2 = types.SimpleNamespace(Rodrigues=lambda R: (matrices_to_rvecs(np.asarray(R, dtype=np.float64)[None])[0].reshape(3, 1), None))
+    ns = {"cv2": cv2}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    p = make_problem(6, 300, 4, seed=2)
+    observations = [(int(c), int(m)) for c, m in zip(p.cam_idx, p.pt_idx)]
+    kp = {o: tuple(uv) for o, uv in zip(observations, p.uv)}
+    K = np.array([[p.K4[0], 0, p.K4[2]], [0, p.K4[1], p.K4[3]], [0, 0, 1.0]])
+    R0 = rvecs_to_matrices(p.cams[:1, :3])[0]
+    rv, tv, pts, summ = ns["solve_window"](K, R0, p.cams[0, 3:], p.cams[1:, :3], p.cams[1:, 3:], p.pts, observations, kp,
+                                           {i: i for i in range(p.n_cams)}, {i: i for i in range(p.n_pts)})
+    with hip_backend.Solver(0) as s:
+        s.set_problem(p)
+        ref = s.solve()
+        cams_ref, pts_ref = s.get_params()
+    # (the fixed camera goes matrix -> rotation vector here, so the start differs in the last bits and
+    # the ftol stop may fall one iteration earlier or later)
+    assert abs(summ.iterations - ref["iterations"]) <= 1 and abs(summ.final_sse - ref["final_sse"]) <= 1e-5 * ref["final_sse"]
+    assert summ.final_sse < 0.05 * summ.initial_sse
+    # default tolerances stop far from the last digit, and scale is a weak direction: loose on the parameters
+    np.testing.assert_allclose(rv, cams_ref[1:, :3], atol=2e-3)
+    np.testing.assert_allclose(pts, pts_ref, rtol=1e-2, atol=1e-2)
