@@ -1,6 +1,8 @@
 """GPU property tests (hypothesis): random small problems through the C ABI against the oracle
 and against size-independent invariants -- observation permutation, duplicated observations,
 points seen by a single camera, rigid change of the world frame."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings
@@ -12,7 +14,8 @@ from bundle_adjustment_amd.synthetic import make_problem
 from oracle import ba_oracle as o
 
 pytestmark = pytest.mark.gpu
-COMMON = dict(deadline=None, max_examples=12, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+# BA_HYPOTHESIS_EXAMPLES raises the example count for a stress run (default: a quick 12 per property)
+COMMON = dict(deadline=None, max_examples=int(os.environ.get("BA_HYPOTHESIS_EXAMPLES", "12")), suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 
 
 @pytest.fixture(scope="module")
