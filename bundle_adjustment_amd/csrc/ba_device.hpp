@@ -76,13 +76,28 @@ struct GeomT {
 };
 using Geom = GeomT<double>;
 
-template <typename T, typename CamT>
-__device__ inline void obs_geom(const CamT* __restrict__ cs, const T X0, const T X1, const T X2,
-                                const T fx, const T fy, GeomT<T>& g) {
+// 1 / z for the Schur-operator passes (PCG, right-hand side, back substitution): v_rcp + Newton steps, 5
+// instructions against the 14 of the IEEE division sequence; the last bit may differ from 1.0 / z.  The
+// residual and the linearisation (what parity with the reference is measured on) keep the exact division.
+__device__ inline double recip_fast(double z) {
+  double r = __builtin_amdgcn_rcp(z);
+  double e = fma(-z, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-z, r, 1.0);
+  return fma(r, e, r);
+}
+__device__ inline float recip_fast(float z) {
+  float r = __builtin_amdgcn_rcpf(z);
+  return fmaf(r, fmaf(-z, r, 1.0f), r);
+}
+
+template <bool FAST, typename T, typename CamT>
+__device__ inline void obs_geom_t(const CamT* __restrict__ cs, const T X0, const T X1, const T X2,
+                                  const T fx, const T fy, GeomT<T>& g) {
   const T Xc0 = cs[0] * X0 + cs[1] * X1 + cs[2] * X2 + cs[9];
   const T Xc1 = cs[3] * X0 + cs[4] * X1 + cs[5] * X2 + cs[10];
   const T Xc2 = cs[6] * X0 + cs[7] * X1 + cs[8] * X2 + cs[11];
-  const T iz = (Xc2 != T(0)) ? T(1) / Xc2 : T(1);   // cv2.projectPoints guards z == 0 as 1
+  const T iz = (Xc2 != T(0)) ? (FAST ? recip_fast(Xc2) : T(1) / Xc2) : T(1);   // cv2.projectPoints guards z == 0 as 1
   g.xh = Xc0 * iz;
   g.yh = Xc1 * iz;
   g.d00 = fx * iz;
@@ -95,6 +110,16 @@ __device__ inline void obs_geom(const CamT* __restrict__ cs, const T X0, const T
   g.P[3] = g.d11 * cs[3] + g.d12 * cs[6];
   g.P[4] = g.d11 * cs[4] + g.d12 * cs[7];
   g.P[5] = g.d11 * cs[5] + g.d12 * cs[8];
+}
+template <typename T, typename CamT>
+__device__ inline void obs_geom(const CamT* __restrict__ cs, const T X0, const T X1, const T X2,
+                                const T fx, const T fy, GeomT<T>& g) {
+  obs_geom_t<false, T, CamT>(cs, X0, X1, X2, fx, fy, g);
+}
+template <typename T, typename CamT>
+__device__ inline void obs_geom_fast(const CamT* __restrict__ cs, const T X0, const T X1, const T X2,
+                                     const T fx, const T fy, GeomT<T>& g) {
+  obs_geom_t<true, T, CamT>(cs, X0, X1, X2, fx, fy, g);
 }
 
 // projection only (trial-point cost and the residual entry point)

@@ -120,24 +120,29 @@ struct ba_handle {
   double K4[4] = {1, 1, 0, 0};
   // observation lists (camera order, point order)
   DBuf<int> offk, c_pt, c_orig, pt_off, p_cam, slot, long_pts;
-  DBuf<int> c_ptf[2], p_camf;  // index streams with the "weights are not (1, 1)" flag (robust loss; c_ptf pairs with c_w)
+  DBuf<int> c_ptf[2], p_camf[2];  // index streams with the "weights are not (1, 1)" flag (robust loss; c_ptf pairs with c_w, p_camf with p_w)
   int long_thr = 16;           // tracks longer than this get a DPP row each (set in ba_set_problem)
   int n_long = 0, nblkL = 0;   // points with more than LONG_TRACK observations: one DPP row each, own launch
   DBuf<int2> blk_win;          // per point-pass workgroup: first camera and number of cameras its points see
-  DBuf<double2> c_uv, p_uv, c_w[2], p_w;   // c_w / partL are double-buffered: the camera half of the next
-                                           // linearisation is computed speculatively at the trial point
+  DBuf<double2> c_uv, p_uv, c_w[2], p_w[2];   // both halves of the linearisation are double-buffered: the next one is
+                                              // computed speculatively at the trial point while the host decides
+                                              // (camera half: c_w, c_ptf, partL [lb]; point half: p_w, p_camf, Hpp, bp, Hppinv, y0 [pb])
   // parameters (current / trial): cameras, camera state, point table
   DBuf<double> cams[2], cs[2], ptab[2], stage;
   int cur = 0;
   // camera table of the point passes, normal equations
-  DBuf<double> camA[2], HccBc, Hpp, bp, Hppinv, y0, Hccd, Minv;
+  DBuf<double> camA[2], HccBc, Hpp[2], bp[2], Hppinv[2], y0[2], Hccd, Minv;
+  int pb = 0;                  // which point-half buffer set holds the current linearisation
   // partial sums
   DBuf<double> partR, partL[2], part6, partE, partA, partB, partC, partV;
+  DBuf<double> partG[2], partGc;   // per-workgroup max |bp| (point half, double-buffered like it) and max |bc| (k_pcg_setup): the gtol test
   int lb = 0;                  // which c_w / partL buffer holds the current linearisation
   hipEvent_t ev_decide = nullptr;
   // PCG vectors, comm buffers (multi-rank), scalars
   DBuf<double> gvec, x, r, p, s, z, vin, scal, rbuf, gather;
   DBuf<PcgState> st;
+  DBuf<double> verdict;        // PCG verdict words {gamma, zeta, finished, -} x 2 iteration parities (point pass -> camera pass, vector kernel)
+  int cam_segl = 64;           // lanes per (camera, partition) segment in the PCG camera pass (BA_CAM_SEGL, tuning)
   int nblkP = 1, ppb = 1, nblkV = 1;
   size_t lds_bytes = 0;
   bool jac_f32 = false;        // PCG passes recompute the Jacobian blocks in fp32 (ba_options.jacobian_precision = 1)
@@ -178,7 +183,7 @@ extern "C" int ba_device_count(int* n) {
 // the LDS-table point passes need more than the default 64 KB of dynamic LDS
 template <typename F>
 static hipError_t allow_big_lds(F* f) {
-  return hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+  return hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TAB_BYTES);   // the largest table a launch asks for
 }
 
 extern "C" int ba_create(int device_id, ba_handle** out) {
@@ -229,17 +234,20 @@ extern "C" int ba_destroy(ba_handle* h) {
   for (auto e : h->ev) (void)hipEventDestroy(e);
   if (h->ev_decide) (void)hipEventDestroy(h->ev_decide);
   DBuf<int>* ib[] = {&h->offk, &h->c_pt, &h->c_orig, &h->pt_off, &h->p_cam, &h->slot, &h->long_pts, &h->c_ptf[0], &h->c_ptf[1],
-                     &h->p_camf};
+                     &h->p_camf[0], &h->p_camf[1]};
   for (auto b : ib) b->release();
   h->blk_win.release();
-  DBuf<double2>* d2[] = {&h->c_uv, &h->p_uv, &h->c_w[0], &h->c_w[1], &h->p_w};
+  DBuf<double2>* d2[] = {&h->c_uv, &h->p_uv, &h->c_w[0], &h->c_w[1], &h->p_w[0], &h->p_w[1]};
   for (auto b : d2) b->release();
   DBuf<double>* db[] = {&h->cams[0], &h->cams[1], &h->cs[0], &h->cs[1], &h->ptab[0], &h->ptab[1], &h->stage,
-                        &h->camA[0], &h->camA[1], &h->HccBc, &h->Hpp, &h->bp, &h->Hppinv, &h->y0, &h->Hccd, &h->Minv,
+                        &h->camA[0], &h->camA[1], &h->HccBc, &h->Hpp[0], &h->Hpp[1], &h->bp[0], &h->bp[1],
+                        &h->Hppinv[0], &h->Hppinv[1], &h->y0[0], &h->y0[1], &h->Hccd, &h->Minv,
                         &h->partR, &h->partL[0], &h->partL[1], &h->part6, &h->partE, &h->partA, &h->partB, &h->partC, &h->partV,
+                        &h->partG[0], &h->partG[1], &h->partGc,
                         &h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin, &h->scal, &h->rbuf, &h->gather};
   for (auto b : db) b->release();
   h->st.release();
+  h->verdict.release();
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->h_gmax) (void)hipHostFree(h->h_gmax);
   if (h->h_flags) (void)hipHostFree(h->h_flags);
@@ -575,6 +583,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   if (table_fits) h->nblkP = std::min(h->nblkP, h->n_cu * per_cu);
   if (const char* e = getenv("BA_PT_BLOCKS")) h->nblkP = std::max(1, std::min(want, atoi(e)));
   if (const char* e = getenv("BA_XCD_RANGES")) h->xcd_ranges = atoi(e) != 0;
+  if (const char* e = getenv("BA_CAM_SEGL")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) h->cam_segl = v; }
   h->ppb = std::max(1, (Np + h->nblkP - 1) / h->nblkP);
   // long tracks: one DPP row (16 lanes) per point in a launch of their own
   std::vector<int> long_pts;
@@ -625,8 +634,8 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   if (h->n_long) HIPCHECK(hipMemcpyAsync(h->long_pts.p, long_pts.data(), h->n_long * sizeof(int), hipMemcpyHostToDevice, h->stream));
   HIPCHECK(h->c_pt.alloc(nobs1)); HIPCHECK(h->c_orig.alloc(nobs1)); HIPCHECK(h->p_cam.alloc(nobs1));
   HIPCHECK(h->c_uv.alloc(nobs1)); HIPCHECK(h->p_uv.alloc(nobs1));
-  HIPCHECK(h->c_w[0].alloc(nobs1)); HIPCHECK(h->c_w[1].alloc(nobs1)); HIPCHECK(h->p_w.alloc(nobs1));
-  HIPCHECK(h->c_ptf[0].alloc(nobs1)); HIPCHECK(h->c_ptf[1].alloc(nobs1)); HIPCHECK(h->p_camf.alloc(nobs1));
+  HIPCHECK(h->c_w[0].alloc(nobs1)); HIPCHECK(h->c_w[1].alloc(nobs1)); HIPCHECK(h->p_w[0].alloc(nobs1)); HIPCHECK(h->p_w[1].alloc(nobs1));
+  HIPCHECK(h->c_ptf[0].alloc(nobs1)); HIPCHECK(h->c_ptf[1].alloc(nobs1)); HIPCHECK(h->p_camf[0].alloc(nobs1)); HIPCHECK(h->p_camf[1].alloc(nobs1));
   for (int k = 0; k < 2; ++k) {
     HIPCHECK(h->cams[k].alloc(6 * (size_t)Nc)); HIPCHECK(h->cs[k].alloc(CS * (size_t)Nc));
     HIPCHECK(h->ptab[k].alloc(PT * np1));
@@ -635,8 +644,11 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(h->stage.alloc(3 * np1));
   HIPCHECK(h->camA[0].alloc(TA * (size_t)Nc)); HIPCHECK(h->camA[1].alloc(TA * (size_t)Nc));
   HIPCHECK(h->HccBc.alloc(27 * (size_t)Nc + 8));   // Hcc (21 Nc) | bc (6 Nc): one all-reduce
-  HIPCHECK(h->Hpp.alloc(6 * np1)); HIPCHECK(h->bp.alloc(3 * np1)); HIPCHECK(h->Hppinv.alloc(6 * np1));
-  HIPCHECK(h->y0.alloc(3 * np1));
+  for (int k = 0; k < 2; ++k) {
+    HIPCHECK(h->Hpp[k].alloc(6 * np1)); HIPCHECK(h->bp[k].alloc(3 * np1)); HIPCHECK(h->Hppinv[k].alloc(6 * np1));
+    HIPCHECK(h->y0[k].alloc(3 * np1));
+  }
+  h->pb = 0;
   HIPCHECK(h->Hccd.alloc(21 * (size_t)Nc)); HIPCHECK(h->Minv.alloc(21 * (size_t)Nc));
   HIPCHECK(h->partR.alloc(2 * (size_t)NPART * Nc));
   HIPCHECK(h->partL[0].alloc(27 * (size_t)NPART * Nc)); HIPCHECK(h->partL[1].alloc(27 * (size_t)NPART * Nc));
@@ -644,10 +656,13 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(h->partE.alloc(21 * (size_t)NPART * Nc));
   HIPCHECK(h->partA.alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partB.alloc(4 * (size_t)(h->nblkP + h->nblkL)));
   HIPCHECK(h->partC.alloc(5 * (size_t)h->nblkV)); HIPCHECK(h->partV.alloc(4 * (size_t)h->nblkV));
+  HIPCHECK(h->partG[0].alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partG[1].alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partGc.alloc(h->nblkV));
   DBuf<double>* v6[] = {&h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin};
   for (auto b : v6) HIPCHECK(b->alloc(6 * (size_t)Nc));
   HIPCHECK(h->scal.alloc(64));
   HIPCHECK(h->st.alloc(2));
+  HIPCHECK(h->verdict.alloc(8));
+  HIPCHECK(hipMemsetAsync(h->verdict.p, 0, 8 * sizeof(double), h->stream));
   HIPCHECK(hipMemsetAsync(h->camA[0].p, 0, TA * (size_t)Nc * sizeof(double), h->stream));
   HIPCHECK(hipMemsetAsync(h->camA[1].p, 0, TA * (size_t)Nc * sizeof(double), h->stream));
   h->lb = 0;
@@ -681,7 +696,7 @@ static double* bc_ptr(ba_handle* h) { return h->HccBc.p + 21 * (size_t)h->Nc; }
 constexpr int GMAX_HOST_SLOT = 40;   // word of the host-mapped scalar block that k_absmax2 writes (k_scalars uses [0, S_COUNT))
 static double* uy_ptr(ba_handle* h) { return h->part6.p; }
 static double* p6_ptr(ba_handle* h) { return h->part6.p + 2; }
-static int cam_grid(ba_handle* h) { return ((h->Nc + WPB - 1) / WPB) * NPART; }
+static int cam_grid(ba_handle* h, int segl = 64) { const int cpb = 64 * WPB / segl; return ((h->Nc + cpb - 1) / cpb) * NPART; }
 static int row_grid(ba_handle* h) { return ((h->Nc + ROWS - 1) / ROWS) * NPART; }
 
 extern "C" int ba_set_params(ba_handle* h, const double* cams, const double* pts) {
@@ -756,13 +771,16 @@ static void launch_residual(ba_handle* h, int which, bool robust, double fscale,
 // fold the partial arrays of a step into `scal` (residual always; point / camera parts optional)
 // with_step: also the step partials and the PCG verdict for iteration k; on a single rank the
 // results go straight to the host-mapped mirror (no copy kernel)
-static void launch_scalars(ba_handle* h, bool with_step, int k = 0, double tol2 = 0.0, int min_iters = 0, long long seq = 0) {
+// decide (single rank): the same kernel also computes the gain ratio and the next damping (lm_decide)
+static void launch_scalars(ba_handle* h, bool with_step, int k = 0, double tol2 = 0.0, int min_iters = 0, long long seq = 0,
+                           double cost_cur = 0.0, double lambda = 0.0) {
   Scope sc(h, BA_K_MISC);
   const bool direct = with_step && h->world == 1;     // results straight into host-mapped memory + sequence word
   hipLaunchKernelGGL(k_scalars, dim3(1), dim3(1024), 0, h->stream, h->partR.p, NPART * h->Nc, h->partB.p,
                      (with_step && h->Np > 0) ? h->nblkP + h->nblkL : 0, h->partC.p, with_step ? h->nblkV : 0, k,
                      with_step ? (const PcgState*)h->st.p : (const PcgState*)nullptr, h->partV.p, h->nblkV, tol2, min_iters,
-                     h->scal.p, direct ? h->d_scal_host : (double*)nullptr, direct ? h->d_flags + 2 : (long long*)nullptr, seq);
+                     h->scal.p, direct ? h->d_scal_host : (double*)nullptr, direct ? h->d_flags + 2 : (long long*)nullptr, seq,
+                     direct ? 1 : 0, cost_cur, lambda);
 }
 // spin on a host-mapped sequence word until it reaches `target` (the device publishes with a
 // system-scope release); a wall-clock limit turns a wedged GPU into an error instead of a hang
@@ -779,12 +797,14 @@ static int wait_flag(ba_handle* h, int idx, long long target) {
   return BA_OK;
 }
 // camera half of the linearisation at parameter set `which`, into buffer set `buf`
-static void launch_lin_cam(ba_handle* h, int which, int buf, bool robust, double fscale) {
+// cost: also the cost partials at that parameter set (partR) -- the pass then doubles as the trial-cost evaluation
+static void launch_lin_cam(ba_handle* h, int which, int buf, bool robust, double fscale, bool cost = false) {
   Scope sc(h, BA_K_LINEARIZE_CAM);
-  auto kern = robust ? k_camrow_linearize<true> : k_camrow_linearize<false>;
+  auto kern = robust ? (cost ? k_camrow_linearize<true, true> : k_camrow_linearize<true, false>)
+                     : (cost ? k_camrow_linearize<false, true> : k_camrow_linearize<false, false>);
   hipLaunchKernelGGL(kern, dim3(row_grid(h)), dim3(ROW_LANES * ROWS), 0, h->stream, h->cs[which].p, h->ptab[which].p, h->offk.p,
                      h->c_pt.p, h->c_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, h->cam_band, h->c_w[buf].p,
-                     h->c_ptf[buf].p, h->partL[buf].p);
+                     h->c_ptf[buf].p, h->partL[buf].p, h->partR.p);
 }
 static void launch_lin_finalize(ba_handle* h) {
   Scope sc(h, BA_K_MISC);
@@ -795,13 +815,14 @@ static PtWork pt_work(ba_handle* h) {        // every point; long tracks skipped
   return PtWork{nullptr, h->Np, h->nblkL ? h->long_thr : 0x7fffffff, 0, h->ppb, h->xcd_ranges};
 }
 static PtWork pt_work_long(ba_handle* h) { return PtWork{h->long_pts.p, h->n_long, 0x7fffffff, h->nblkP, PT_THREADS / LPP_LONG, 0}; }
-// point half at the current parameters, with the damped inverse / y0 at `lambda` fused in
-static void launch_lin_pt(ba_handle* h, bool robust, double fscale, double lambda) {
+// point half at parameter set `w` into point-buffer set `pbuf`, with the damped inverse / y0 at `lambda` fused in
+// (lam_dev != null: the damping is read from that device word instead -- a speculated pass, see ba_solve)
+static void launch_lin_pt(ba_handle* h, int w, int pbuf, bool robust, double fscale, double lambda, const double* lam_dev = nullptr) {
   if (h->Np == 0) return;
   Scope sc(h, BA_K_LINEARIZE_PT);
-  const int w = h->cur;
 #define LP_HEAD h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_uv.p, h->blk_win.p
-#define LP_TAIL h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, lambda, h->Hpp.p, h->bp.p, h->p_w.p, h->p_camf.p, h->Hppinv.p, h->y0.p
+#define LP_TAIL h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, lambda, lam_dev, h->Hpp[pbuf].p, h->bp[pbuf].p, h->p_w[pbuf].p,      \
+                h->p_camf[pbuf].p, h->Hppinv[pbuf].p, h->y0[pbuf].p, h->partG[pbuf].p
 #define LP_LAUNCH(R, L, LN, G, WK) hipLaunchKernelGGL((k_pt_linearize<R, L, LN>), dim3(G), dim3(PT_THREADS), h->lds_bytes, h->stream, LP_HEAD, WK, LP_TAIL)
 #define LP_BOTH(R, L) hipLaunchKernelGGL((k_pt_linearize_both<R, L>), dim3(h->nblkP + h->nblkL), dim3(PT_THREADS), h->lds_bytes, h->stream, \
                                          LP_HEAD, wk, h->nblkP, wl, LP_TAIL)
@@ -831,8 +852,8 @@ static void launch_lin_pt(ba_handle* h, bool robust, double fscale, double lambd
 static void launch_point_invert(ba_handle* h, double lambda) {
   if (h->Np == 0) return;
   Scope sc(h, BA_K_POINT_INVERT);
-  hipLaunchKernelGGL(k_point_invert, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp.p, h->bp.p, lambda,
-                     h->Np, h->Hppinv.p, h->y0.p, h->ptab[h->cur].p);
+  hipLaunchKernelGGL(k_point_invert, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp[h->pb].p, h->bp[h->pb].p, lambda,
+                     h->Np, h->Hppinv[h->pb].p, h->y0[h->pb].p, h->ptab[h->cur].p);
 }
 // camera pass of the Schur product on the y slot of the current point table
 //   diag: also the Schur-Jacobi blocks; pcg: iteration k with early exit
@@ -840,36 +861,43 @@ static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int
   Scope sc(h, diag ? BA_K_PRECOND : BA_K_SCHUR_CAM);
   const int w = h->cur;
 #define CS_ARGS h->cs[w].p, h->ptab[w].p, h->offk.p, (robust ? h->c_ptf[h->lb].p : h->c_pt.p), h->c_w[h->lb].p, h->K4[0], h->K4[1], h->Nc, h->cam_band, h->fixed,        \
-                p6_ptr(h), k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->partA.p,                                   \
-                (h->Np > 0 ? h->nblkP + h->nblkL : 0), uy_ptr(h)
-  const dim3 g(cam_grid(h) + (pcg ? 1 : 0)), b(64 * WPB);
+                p6_ptr(h), k, (const double*)h->verdict.p, h->partA.p, (h->Np > 0 ? h->nblkP + h->nblkL : 0), uy_ptr(h)
+  (void)tol2; (void)min_iters;
+  const int segl = pcg ? h->cam_segl : 64;
+  const dim3 g(cam_grid(h, segl) + (pcg ? 1 : 0)), b(64 * WPB);
+#define CS_PCG(R, JT)                                                                                       \
+  do {                                                                                                      \
+    if (segl == 16) hipLaunchKernelGGL((k_cam_schur<R, true, JT, 16>), g, b, 0, h->stream, CS_ARGS);        \
+    else if (segl == 32) hipLaunchKernelGGL((k_cam_schur<R, true, JT, 32>), g, b, 0, h->stream, CS_ARGS);   \
+    else hipLaunchKernelGGL((k_cam_schur<R, true, JT, 64>), g, b, 0, h->stream, CS_ARGS);                   \
+  } while (0)
   if (diag) {
     auto kern = robust ? k_camrow_schur_diag<true> : k_camrow_schur_diag<false>;
     hipLaunchKernelGGL(kern, dim3(row_grid(h)), dim3(ROW_LANES * ROWS), 0, h->stream, h->cs[w].p, h->ptab[w].p, h->offk.p,
-                       (robust ? h->c_ptf[h->lb].p : h->c_pt.p), h->c_w[h->lb].p, h->Hppinv.p, h->K4[0], h->K4[1], h->Nc,
+                       (robust ? h->c_ptf[h->lb].p : h->c_pt.p), h->c_w[h->lb].p, h->Hppinv[h->pb].p, h->K4[0], h->K4[1], h->Nc,
                        h->cam_band, h->fixed, p6_ptr(h), h->partE.p);
   } else if (pcg) {
-    if (h->jac_f32) {
-      if (robust) hipLaunchKernelGGL((k_cam_schur<true, true, float>), g, b, 0, h->stream, CS_ARGS);
-      else        hipLaunchKernelGGL((k_cam_schur<false, true, float>), g, b, 0, h->stream, CS_ARGS);
-    } else {
-      if (robust) hipLaunchKernelGGL((k_cam_schur<true, true, double>), g, b, 0, h->stream, CS_ARGS);
-      else        hipLaunchKernelGGL((k_cam_schur<false, true, double>), g, b, 0, h->stream, CS_ARGS);
-    }
+    if (h->jac_f32) { if (robust) CS_PCG(true, float); else CS_PCG(false, float); }
+    else            { if (robust) CS_PCG(true, double); else CS_PCG(false, double); }
   } else {
-    if (robust) hipLaunchKernelGGL((k_cam_schur<true, false, double>), g, b, 0, h->stream, CS_ARGS);
-    else        hipLaunchKernelGGL((k_cam_schur<false, false, double>), g, b, 0, h->stream, CS_ARGS);
+    if (robust) hipLaunchKernelGGL((k_cam_schur<true, false, double, 64>), g, b, 0, h->stream, CS_ARGS);
+    else        hipLaunchKernelGGL((k_cam_schur<false, false, double, 64>), g, b, 0, h->stream, CS_ARGS);
   }
+#undef CS_PCG
 #undef CS_ARGS
 }
 // point pass with the camera vector in vtil; mode 0 = PCG iteration k, mode 1 = back substitution
-static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double tol2, int min_iters, long long flag_base = 0) {
+// gmax_out (first PCG probe behind a fresh linearisation): host-mapped word that receives max |gradient|
+static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double tol2, int min_iters, long long flag_base = 0,
+                            double* gmax_out = nullptr) {
   if (h->Np == 0) return;
   Scope sc(h, mode == 0 ? BA_K_SCHUR_PT : BA_K_BACKSUB);
   const int w = h->cur;
-#define PS_HEAD h->camA[w].p, h->ptab[w].p, h->pt_off.p, (robust ? h->p_camf.p : h->p_cam.p), h->p_w.p, h->Hppinv.p, h->blk_win.p
-#define PS_TAIL h->K4[0], h->K4[1], h->fixed, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0.p, h->Hpp.p,  \
-                h->bp.p, h->ptab[1 - w].p, h->partB.p, flag, flag_base
+#define PS_HEAD h->camA[w].p, h->ptab[w].p, h->pt_off.p, (robust ? h->p_camf[h->pb].p : h->p_cam.p), h->p_w[h->pb].p,                 \
+                h->Hppinv[h->pb].p, h->blk_win.p
+#define PS_TAIL h->K4[0], h->K4[1], h->fixed, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0[h->pb].p,     \
+                h->Hpp[h->pb].p, h->bp[h->pb].p, h->ptab[1 - w].p, h->partB.p, flag, flag_base, h->verdict.p,                      \
+                (const double*)h->partG[h->pb].p, h->nblkP + h->nblkL, (const double*)h->partGc.p, h->nblkV, gmax_out
   const size_t lds = h->lds_bytes;
   long long* flag = (mode == 0 && flag_base > 0) ? h->d_flags : (long long*)nullptr;
   // data with long tracks: short and long tracks in one launch (workgroup 0 publishes the verdict)
@@ -932,7 +960,7 @@ static void launch_pcg_setup(ba_handle* h, double lambda, bool schur_diag, bool 
   Scope sc(h, BA_K_PCG_UPDATE);
 #define SU_ARGS h->partL[h->lb].p, h->HccBc.p, bc_ptr(h), p6_ptr(h), h->partE.p, NPART, h->cs[h->cur].p, lambda,           \
                 schur_diag ? 1 : 0, h->Nc, h->fixed, h->Hccd.p, h->Minv.p, h->gvec.p, h->x.p, h->r.p, h->p.p, h->s.p,     \
-                h->z.p, h->camA[h->cur].p, h->partV.p, h->st.p
+                h->z.p, h->camA[h->cur].p, h->partV.p, h->st.p, h->partGc.p
   if (finalize) hipLaunchKernelGGL((k_pcg_setup<true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);
   else          hipLaunchKernelGGL((k_pcg_setup<false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);
 #undef SU_ARGS
@@ -971,7 +999,7 @@ extern "C" int ba_linearize(ba_handle* h, int32_t loss, double f_scale, double* 
   launch_lin_cam(h, h->cur, h->lb, loss == BA_LOSS_HUBER, f_scale);
   if (int rc = exchange_partL(h, h->lb)) return rc;
   launch_lin_finalize(h);
-  launch_lin_pt(h, loss == BA_LOSS_HUBER, f_scale, 1.0);
+  launch_lin_pt(h, h->cur, h->pb, loss == BA_LOSS_HUBER, f_scale, 1.0);
   h->linearized = true;
   h->lin_robust = (loss == BA_LOSS_HUBER);
   h->lin_fscale = f_scale;
@@ -980,11 +1008,11 @@ extern "C" int ba_linearize(ba_handle* h, int32_t loss, double f_scale, double* 
   if ((Hpp || bp) && h->Np) {          // per-point blocks back in the caller's point order
     HIPCHECK(h->rbuf.alloc(6 * (size_t)h->Np));
     if (Hpp) {
-      hipLaunchKernelGGL(k_unpermute_rows, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp.p, h->slot.p, h->Np, 6, h->rbuf.p);
+      hipLaunchKernelGGL(k_unpermute_rows, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp[h->pb].p, h->slot.p, h->Np, 6, h->rbuf.p);
       HIPCHECK(hipMemcpyAsync(Hpp, h->rbuf.p, 6 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
     if (bp) {
-      hipLaunchKernelGGL(k_unpermute_rows, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->bp.p, h->slot.p, h->Np, 3, h->stage.p);
+      hipLaunchKernelGGL(k_unpermute_rows, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->bp[h->pb].p, h->slot.p, h->Np, 3, h->stage.p);
       HIPCHECK(hipMemcpyAsync(bp, h->stage.p, 3 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
   }
@@ -1108,63 +1136,64 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   }
   double lambda = opts->initial_lambda, nu = 2.0;
   int it = 0, status = 0;
-  bool need_linearize = true;      // point half (and, unless speculated, camera half) to be recomputed
-  bool have_cam_half = false;      // buffers [lb] already hold the camera half at the current parameters
+  bool need_linearize = true;      // a linearisation at the current parameters is needed before the next damped system
+  bool have_lin = false;           // ... and buffer sets [lb] / [pb] already hold it (speculated at the trial point that was accepted)
   h->linearized = false;
 
   while (it < opts->max_iters) {
     double t0 = now_s();
     bool fresh = false;
     if (need_linearize) {
-      const bool cam_half_unreduced = !have_cam_half;
-      if (!have_cam_half) launch_lin_cam(h, h->cur, h->lb, robust, fs);
-      launch_lin_pt(h, robust, fs, lambda);          // also Hpp^-1, y0 at this lambda
+      if (!have_lin) {
+        launch_lin_cam(h, h->cur, h->lb, robust, fs);
+        launch_lin_pt(h, h->cur, h->pb, robust, fs, lambda);          // also Hpp^-1, y0 at this lambda
+        // multi-rank: the camera-half partials of a pass launched here still have to be all-reduced
+        // (a speculated pass was reduced right behind its launch)
+        if (int rc = exchange_partL(h, h->lb)) return rc;
+      }
       h->lin_robust = robust; h->lin_fscale = fs;
       need_linearize = false;
-      have_cam_half = false;
+      have_lin = false;
       fresh = true;
-      // multi-rank: the camera-half partials of a freshly launched (not speculated) pass still
-      // have to be all-reduced; the speculated pass was reduced right behind its launch
-      if (cam_half_unreduced) { if (int rc = exchange_partL(h, h->lb)) return rc; }
     }
     // ---- damped system, right-hand side, preconditioner, first PCG vectors
     if (int rc = damped_system(h, lambda, schur_diag, !fresh, fresh)) return rc;
     bool gtol_pending = false;     // single rank: max |gradient| lands in host-mapped memory, read at the first PCG verdict
     if (fresh && opts->gtol > 0) {
+      // max |gradient| = max(|bc|, |bp|): per-workgroup maxima come out of the point half (partG) and of
+      // k_pcg_setup (partGc); single rank: the first PCG probe folds them into host-mapped memory
       if (h->world == 1) {
-        Scope sc(h, BA_K_MISC);
-        hipLaunchKernelGGL(k_absmax2, dim3(1), dim3(1024), 0, h->stream, (const double*)bc_ptr(h), 6 * (size_t)Nc,
-                           (const double*)h->bp.p, 3 * (size_t)h->Np, h->d_scal_host + GMAX_HOST_SLOT);
         gtol_pending = true;
       } else {
+        // bc is all-reduced (identical on every rank); bp is shard-local -> max over ranks
         {
           Scope sc(h, BA_K_MISC);
-          hipLaunchKernelGGL(k_absmax, dim3(1), dim3(256), 0, h->stream, bc_ptr(h), 6 * (size_t)Nc, h->scal.p + S_GMAX_C);
-          hipLaunchKernelGGL(k_absmax, dim3(1), dim3(256), 0, h->stream, h->bp.p, 3 * (size_t)h->Np, h->scal.p + S_GMAX_P);
+          hipLaunchKernelGGL(k_max_partials, dim3(1), dim3(64), 0, h->stream, (const double*)h->partG[h->pb].p,
+                             h->Np > 0 ? h->nblkP + h->nblkL : 0, (const double*)h->partGc.p, h->nblkV, h->scal.p + 18);
         }
-        HIPCHECK(hipMemcpyAsync(h->h_gmax, h->scal.p + S_GMAX_C, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(hipStreamSynchronize(h->stream));
-        double gmax = std::max(h->h_gmax[0], h->h_gmax[1]);
-        // bc is all-reduced (identical on every rank); bp is shard-local -> max over ranks
-        HIPCHECK(hipMemcpyAsync(h->scal.p + 18, &gmax, sizeof(double), hipMemcpyHostToDevice, h->stream));
         if (int rc = allreduce(h, h->scal.p + 18, 1, true)) return rc;
         HIPCHECK(hipMemcpyAsync(h->h_gmax, h->scal.p + 18, sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(hipStreamSynchronize(h->stream));
-        gmax = h->h_gmax[0];
+        const double gmax = h->h_gmax[0];
+        if (!std::isfinite(gmax)) return fail(BA_ERR_NUMERIC, "non-finite gradient at LM iteration %d", it);
         if (gmax <= opts->gtol) { status = 3; break; }
       }
     }
     double t1 = now_s();
     sum->seconds_linearize += t1 - t0;
-    // ---- PCG.  The vector kernel of iteration k publishes its verdict (go on / converged after
-    // n iterations) in host-mapped memory when it STARTS; iteration j is launched once the verdict
-    // of iteration j-1 says "go on".  The
-    // rule only depends on the (deterministic, rank-identical) verdicts, never on timing.
+    // ---- PCG.  The point pass of iteration k is the probe: it publishes the verdict for k (go on /
+    // converged after n iterations) in host-mapped memory when it STARTS.  Only after a "go on" are
+    // the camera pass and the vector kernel of k queued (the point pass is still running then),
+    // followed at once by the probe of k+1.  Convergence costs one early-exit point pass.  The rule
+    // only depends on the (deterministic, rank-identical) verdicts, never on timing.
     int k = 0, pcg_done_iters = -1;
     bool gtol_stop = false;
     const long long base = h->flag_base;
     h->flag_base += opts->pcg_max_iters + 8;
-    auto launch_point_pass = [&](int kk) { launch_pt_schur(h, robust, 0, kk, tol2, opts->pcg_min_iters, base); };
+    auto launch_point_pass = [&](int kk) {
+      launch_pt_schur(h, robust, 0, kk, tol2, opts->pcg_min_iters, base,
+                      (kk == 0 && gtol_pending) ? h->d_scal_host + GMAX_HOST_SLOT : (double*)nullptr);
+    };
     auto launch_rest = [&](int kk) -> int {
       launch_cam_schur(h, robust, false, true, kk, tol2, opts->pcg_min_iters);
       if (int rc = exchange_schur(h, false)) return rc;
@@ -1172,20 +1201,18 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       hipLaunchKernelGGL(k_pcg_step, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, kk, p6_ptr(h), NPART,
                          (const double*)uy_ptr(h), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc,
                          h->fixed, tol2, opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA[h->cur].p,
-                         h->partV.p, h->nblkV, h->st.p, h->d_flags, base);
+                         h->partV.p, h->nblkV, h->st.p, h->d_flags, base, (const double*)h->verdict.p);
       return BA_OK;
     };
-    // The point pass of iteration k is the probe: it publishes the verdict for k when it starts.
-    // Only after a "go on" are the camera pass and the vector kernel of k queued (the point pass
-    // is still running then), followed at once by the probe of k+1.  Convergence costs one
-    // early-exit point pass.
     launch_point_pass(0);
     while (true) {
       if (int rc = wait_flag(h, 0, base + k + 1)) return rc;
       // the gradient maximum was written by a kernel ahead of this probe: visible now
       if (gtol_pending) {
         gtol_pending = false;
-        if (h->h_scal[GMAX_HOST_SLOT] <= opts->gtol) { gtol_stop = true; break; }
+        const double gmax = h->h_scal[GMAX_HOST_SLOT];
+        if (!std::isfinite(gmax)) return fail(BA_ERR_NUMERIC, "non-finite gradient at LM iteration %d", it);
+        if (gmax <= opts->gtol) { gtol_stop = true; break; }
       }
       const long long payload = h->h_flags[1];
       if (payload > 0) { pcg_done_iters = (int)payload - 1; break; }
@@ -1203,21 +1230,30 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
                          h->camA[h->cur].p, h->camA[1 - h->cur].p, h->partC.p);
     }
     launch_pt_schur(h, robust, 1, 0, 0.0, 0);
-    launch_residual(h, 1 - h->cur, robust, fs, nullptr);
+    // Speculation: unless this is the last iteration, the cost at the trial point comes out of the camera half of
+    // the NEXT linearisation computed there (one pass instead of two), into the other c_w / partL buffers; the step's
+    // verdict (gain ratio, next damping) is computed on the device right behind it, and while the host reads it the
+    // GPU already runs the point half at the trial point with that damping, into the other point buffers.  An accepted
+    // step finds its linearisation done; a rejected one ignores both.
+    const bool speculated = (it + 1 < opts->max_iters);
+    if (speculated) {
+      launch_lin_cam(h, 1 - h->cur, 1 - h->lb, robust, fs, true);
+      if (int rc = exchange_partL(h, 1 - h->lb)) return rc;
+    } else {
+      launch_residual(h, 1 - h->cur, robust, fs, nullptr);
+    }
     const long long seq = ++h->step_seq;
-    launch_scalars(h, true, k, tol2, opts->pcg_min_iters, seq);
+    launch_scalars(h, true, k, tol2, opts->pcg_min_iters, seq, cost, lambda);
     if (h->world > 1) {
       if (int rc = allreduce(h, h->scal.p, 6)) return rc;
+      {
+        Scope sc(h, BA_K_MISC);
+        hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, h->stream, h->scal.p, cost, lambda);
+      }
       HIPCHECK(hipMemcpyAsync(h->h_scal, h->scal.p, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIPCHECK(hipEventRecord(h->ev_decide, h->stream));
     }
-    // speculation: while the host decides, the GPU already computes the camera half of the next
-    // linearisation at the trial point, into the other c_w / partL buffers
-    const bool speculated = (it + 1 < opts->max_iters);
-    if (speculated) {
-      launch_lin_cam(h, 1 - h->cur, 1 - h->lb, robust, fs);
-      if (int rc = exchange_partL(h, 1 - h->lb)) return rc;
-    }
+    if (speculated) launch_lin_pt(h, 1 - h->cur, 1 - h->pb, robust, fs, 0.0, h->scal.p + S_LAM_NEXT);
     if (h->world > 1) HIPCHECK(hipEventSynchronize(h->ev_decide));
     else if (int rc = wait_flag(h, 2, seq)) return rc;
     if (pcg_done_iters < 0) pcg_done_iters = (h->h_scal[S_PCG_FIN] != 0.0) ? (int)h->h_scal[S_PCG_ITERS] : k;
@@ -1226,10 +1262,8 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     sum->seconds_pcg += t2 - t1;
     const double* S = h->h_scal;
     const double sse_new = S[S_SSE], cost_new = 0.5 * S[S_RHO];
-    const double gTd = S[S_PT_GD] + S[S_CAM_GD], dDd = S[S_PT_DDD] + S[S_CAM_DDD], dcr = S[S_DC_R];
     const double step2 = S[S_PT_DD] + S[S_CAM_DD], x2 = S[S_PT_XX] + S[S_CAM_XX];
-    const double model = 0.5 * (lambda * dDd - gTd + dcr);
-    const double rho = (model > 0 && std::isfinite(cost_new)) ? (cost - cost_new) / model : -1.0;
+    const double rho = S[S_GAIN];               // gain ratio and next damping: decided on the device (lm_decide)
     ++it;
     if (opts->verbose)
       fprintf(stderr, "[ba] it %3d cost %.9e -> %.9e lambda %.3e rho %+.3f pcg %d |step| %.3e\n", it, cost, cost_new,
@@ -1238,11 +1272,11 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     if (rho > 0 && std::isfinite(cost_new)) {
       const double dcost = cost - cost_new;
       h->cur = 1 - h->cur;
-      if (speculated) { h->lb = 1 - h->lb; have_cam_half = true; }
+      if (speculated) { h->lb = 1 - h->lb; h->pb = 1 - h->pb; have_lin = true; }
       cost = cost_new;
       sse = sse_new;
       sum->accepted++;
-      lambda = std::max(lambda * std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3)), 1e-12);
+      lambda = S[S_LAM_NEXT];
       nu = 2.0;
       need_linearize = true;
       if (dcost <= opts->ftol * cost) { status = 1; stop = true; }
@@ -1277,7 +1311,7 @@ extern "C" int ba_time_kernel(ba_handle* h, int slot, int reps, double* mean_us)
   const bool robust = h->lin_robust;
   launch_lin_cam(h, h->cur, h->lb, robust, h->lin_fscale);
   launch_lin_finalize(h);
-  launch_lin_pt(h, robust, h->lin_fscale, 1e-4);
+  launch_lin_pt(h, h->cur, h->pb, robust, h->lin_fscale, 1e-4);
   h->linearized = true;
   if (int rc = damped_system(h, 1e-4, true)) return rc;
   hipLaunchKernelGGL(k_pcg_reset, dim3(1), dim3(64), 0, h->stream, h->st.p, h->partV.p, h->nblkV);
@@ -1288,7 +1322,7 @@ extern "C" int ba_time_kernel(ba_handle* h, int slot, int reps, double* mean_us)
     switch (slot) {
       case BA_K_RESIDUAL: launch_residual(h, h->cur, robust, h->lin_fscale, nullptr); break;
       case BA_K_LINEARIZE_CAM: launch_lin_cam(h, h->cur, h->lb, robust, h->lin_fscale); break;
-      case BA_K_LINEARIZE_PT: launch_lin_pt(h, robust, h->lin_fscale, 1e-4); break;
+      case BA_K_LINEARIZE_PT: launch_lin_pt(h, h->cur, h->pb, robust, h->lin_fscale, 1e-4); break;
       case BA_K_SCHUR_PT: launch_pt_schur(h, robust, 0, 0, -1.0, 1 << 30); break;
       case BA_K_SCHUR_CAM: launch_cam_schur(h, robust, false, false, 0, 0.0, 0); break;
       case BA_K_PRECOND: launch_cam_schur(h, robust, true, false, 0, 0.0, 0); break;
@@ -1309,3 +1343,16 @@ extern "C" int ba_time_kernel(ba_handle* h, int slot, int reps, double* mean_us)
   *mean_us = 1e3 * ms / reps;
   return BA_OK;
 }
+
+// --------------------------------------------------------------- diagnostic build only
+#ifdef BA_STAMPS
+// copy the stamps of the last launch of kind 0 (PCG point pass), 1 (PCG camera pass), 2 (k_pcg_step)
+extern "C" int ba_debug_stamps(ba_handle* h, int kind, unsigned long long* out, int n_blocks) {
+  if (!h || !out || kind < 0 || kind > 2 || n_blocks < 1 || n_blocks > STAMP_BLOCKS) return fail(BA_ERR_INVALID, "bad argument");
+  if (set_device(h)) return BA_ERR_HIP;
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)n_blocks * 8 * sizeof(unsigned long long),
+                               (size_t)kind * STAMP_BLOCKS * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return BA_OK;
+}
+#endif

@@ -33,6 +33,22 @@
 
 namespace ba {
 
+// Diagnostic build only (-DBA_STAMPS, tools/stamp_timeline.py): thread 0 of every workgroup records
+// where its time goes.  Slot 0 / 7: s_memrealtime (100 MHz) at entry / exit, slots 1..6: s_memtime
+// (shader clock) at the stages marked in the kernels.  The product build compiles none of it.
+#ifdef BA_STAMPS
+constexpr int STAMP_BLOCKS = 8192;
+__device__ unsigned long long g_stamps[3][STAMP_BLOCKS * 8];
+#define BA_STAMP(kind, slot)                                                                              \
+  do {                                                                                                    \
+    if (threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS)                                                    \
+      g_stamps[kind][blockIdx.x * 8 + (slot)] =                                                           \
+          ((slot) == 0 || (slot) == 7) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define BA_STAMP(kind, slot) do { } while (0)
+#endif
+
 constexpr int NPART = 8;         // point partitions (= XCDs)
 constexpr int WPB = 4;           // waves (= cameras) per workgroup in camera passes
 constexpr int PT = 8;            // doubles per point record
@@ -60,6 +76,13 @@ __device__ inline int vec_camera(int n_cams) {      // camera of this thread in 
   return (threadIdx.x < VEC_CAMS) ? (int)(blockIdx.x * VEC_CAMS + threadIdx.x) : n_cams;
 }
 
+// max that keeps a NaN (fmax drops it): a non-finite gradient must not read as "converged"
+__device__ inline double nanmax(double a, double b) { return (a != a) ? a : ((b != b) ? b : fmax(a, b)); }
+__device__ inline double wave_nanmax(double m) {
+  for (int o = 32; o > 0; o >>= 1) m = nanmax(m, __shfl_xor(m, o, 64));
+  return m;
+}
+
 // PCG device state, two copies indexed by iteration parity (see k_pcg_step)
 struct PcgState {
   double gamma_prev, alpha_prev, gamma0, pad0;
@@ -67,7 +90,7 @@ struct PcgState {
 };
 
 // scalar slots written by k_scalars (device `scal`)
-enum { S_SSE = 0, S_RHO = 1, S_PT_GD = 2, S_PT_DDD = 3, S_PT_DD = 4, S_PT_XX = 5,
+enum { S_SSE = 0, S_RHO = 1, S_PT_GD = 2, S_PT_DDD = 3, S_PT_DD = 4, S_PT_XX = 5, S_GAIN = 6, S_LAM_NEXT = 7,
        S_CAM_GD = 8, S_CAM_DDD = 9, S_DC_R = 10, S_CAM_DD = 11, S_CAM_XX = 12, S_GMAX_C = 16, S_GMAX_P = 17,
        S_PCG_FIN = 20, S_PCG_ITERS = 21, S_COUNT = 24 };
 
@@ -224,20 +247,14 @@ __device__ inline void m_congruence(const double* __restrict__ M, double (&A)[6]
 
 // Combine the NPART partial sums of k_camrow_linearize (fixed order), apply M:
 //   Hcc[c] (21) = Jc^T w Jc,  bc[c] (6) = Jc^T w r  (zero for the fixed camera).
-__device__ inline void lin_finalize_camera(const double* __restrict__ partL, const double* __restrict__ cam, int n_cams,
-                                           int c, int fixed_cam, double* __restrict__ H, double* __restrict__ b) {
-  if (c == fixed_cam) {
+// a[27] = the camera's pre-M sums (21 of Jc^T w Jc, upper triangle; 6 of Jc^T w r), M from its state
+__device__ inline void lin_finalize_sums(const double* __restrict__ a, const double* __restrict__ M, bool fixed,
+                                         double* __restrict__ H, double* __restrict__ b) {
+  if (fixed) {
     for (int q = 0; q < 21; ++q) H[q] = 0.0;
     for (int q = 0; q < 6; ++q) b[q] = 0.0;
     return;
   }
-  double a[27];
-  for (int q = 0; q < 27; ++q) a[q] = 0.0;
-  for (int k = 0; k < NPART; ++k) {
-    const double* src = partL + ((size_t)k * n_cams + c) * 27;
-    for (int q = 0; q < 27; ++q) a[q] += src[q];
-  }
-  const double* M = cam + 12;
   double A[6][6];
   for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) A[i][j] = a[S6(i, j)];
   m_congruence(M, A);
@@ -246,6 +263,18 @@ __device__ inline void lin_finalize_camera(const double* __restrict__ partL, con
   b[1] = M[1] * a[21] + M[4] * a[22] + M[7] * a[23];
   b[2] = M[2] * a[21] + M[5] * a[22] + M[8] * a[23];
   b[3] = a[24]; b[4] = a[25]; b[5] = a[26];
+}
+__device__ inline void lin_finalize_camera(const double* __restrict__ partL, const double* __restrict__ cam, int n_cams,
+                                           int c, int fixed_cam, double* __restrict__ H, double* __restrict__ b) {
+  double a[27];
+  for (int q = 0; q < 27; ++q) a[q] = 0.0;
+  if (c != fixed_cam) {
+    for (int k = 0; k < NPART; ++k) {
+      const double* src = partL + ((size_t)k * n_cams + c) * 27;
+      for (int q = 0; q < 27; ++q) a[q] += src[q];
+    }
+  }
+  lin_finalize_sums(a, cam + 12, c == fixed_cam, H, b);
 }
 // stand-alone form (multi-rank jobs all-reduce Hcc|bc between this and k_pcg_setup; test hook)
 __global__ void __launch_bounds__(VEC_BLOCK)
@@ -285,28 +314,63 @@ __device__ inline bool pcg_finished(int k, const PcgState* __restrict__ st, cons
   return (k >= min_iters && g <= tol2 * g0);
 }
 
-template <bool ROBUST, bool PCG, typename JT>
+// PCG verdict word of iteration k (vd = verdict + 4 * (k & 1)): {gamma, zeta, finished}.  Written once per
+// iteration by workgroup 0 of the point pass (the probe, first kernel of the iteration, which sums the vector
+// kernel's partials); the camera pass and the vector kernel of the same iteration read these three words
+// instead of re-reducing the partials in every wave (~9 % of the camera pass's vector instructions).
+__device__ inline bool pcg_verdict(const double* __restrict__ verdict, int k, double& gamma, double& zeta) {
+  const double* vd = verdict + 4 * (k & 1);
+  gamma = vd[0]; zeta = vd[1];
+  return vd[2] != 0.0;
+}
+
+// SEGL lanes per (camera, partition) segment: 64 (a wave), 32 or 16 (one DPP row).  Fewer lanes per segment =
+// fewer waves, so the per-wave prologue and the cross-lane reduction of the six sums are paid for 2 / 4
+// segments at once (the pass is vector-issue bound: SQ counters, profiles/), at the price of a longer chain
+// of dependent gathers per lane.  Workgroup = 256 / SEGL consecutive cameras of one partition.
+template <int SEGL>
+__device__ inline double seg_sum_dpp(double x) {    // the last lane of every SEGL-lane segment ends with the segment total
+  x += dpp_f64<DPP_ROW_SHR1, 0xf>(x);
+  x += dpp_f64<DPP_ROW_SHR2, 0xf>(x);
+  x += dpp_f64<DPP_ROW_SHR4, 0xf>(x);
+  x += dpp_f64<DPP_ROW_SHR8, 0xf>(x);
+  if (SEGL >= 32) x += dpp_f64<DPP_ROW_BCAST15, 0xa>(x);
+  if (SEGL == 64) x += dpp_f64<DPP_ROW_BCAST31, 0xc>(x);
+  return x;
+}
+template <bool ROBUST, bool PCG, typename JT, int SEGL>
 __global__ void __launch_bounds__(64 * WPB)
 k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
             const int* __restrict__ c_pt, const double2* __restrict__ c_w,
             double fx, double fy, int n_cams, int band, int fixed_cam, double* __restrict__ part6,
-            int kit, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2,
-            int min_iters, const double* __restrict__ partA, int nblkA, double* __restrict__ uy) {
+            int kit, const double* __restrict__ verdict, const double* __restrict__ partA, int nblkA,
+            double* __restrict__ uy) {
+  static_assert(SEGL == 16 || SEGL == 32 || SEGL == 64, "16, 32 or 64 lanes per segment");
+  constexpr int CPB = 64 * WPB / SEGL;         // cameras per workgroup
   // segment bounds and camera state are fetched before the PCG verdict is known: one round trip
   // less on the way to the first gather (an early-exit launch wastes a few loads)
   const bool extra = PCG && blockIdx.x == gridDim.x - 1;   // extra workgroup: folds the point pass's u.y partials
-  Seg s;
-  s.c = 0; s.k = 0; s.beg = 0; s.end = 0; s.lane = threadIdx.x & 63;
-  const bool live = !extra && cam_segment(offk, n_cams, band, s);
+  if (PCG) { BA_STAMP(1, 0); BA_STAMP(1, 1); }
+  int group, k;
+  group_of_block((n_cams + CPB - 1) / CPB, band, group, k);
+  int c = group * CPB + (int)(threadIdx.x / SEGL);
+  if (SEGL == 64) c = __builtin_amdgcn_readfirstlane(c);       // wave-uniform: camera state in scalar registers
+  const int lane = threadIdx.x % SEGL;
+  const bool live = !extra && c < n_cams;
+  int beg = 0, end = 0;
   JT cam[12];                                  // Jacobian blocks in JT (double, or float for config 5)
+#pragma unroll
+  for (int q = 0; q < 12; ++q) cam[q] = (JT)0;
   if (live) {
-    const double* camd = cs + CS * s.c;
+    beg = offk[c * (NPART + 1) + k];
+    end = offk[c * (NPART + 1) + k + 1];
+    const double* camd = cs + CS * c;
 #pragma unroll
     for (int q = 0; q < 12; ++q) cam[q] = (JT)camd[q];
   }
   if (PCG) {
     double g, z;
-    if (pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z)) return;
+    if (pcg_verdict(verdict, kit, g, z)) return;
     if (extra) {
       __shared__ double smu[WPB];
       double a = 0.0;
@@ -318,17 +382,18 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
       return;
     }
   }
-  if (!live) return;
+  if (SEGL == 64 && !live) return;             // (narrower segments: dead lanes idle through the reduction)
+  if (PCG) BA_STAMP(1, 2);
   const JT fxj = (JT)fx, fyj = (JT)fy;
   double acc[6] = {0, 0, 0, 0, 0, 0};          // sums always in fp64
-  if (s.c != fixed_cam) {
-    int i = s.beg + s.lane;
-    int pf = (i < s.end) ? c_pt[i] : 0;          // ROBUST: the flagged copy of c_pt
+  if (live && c != fixed_cam) {
+    int i = beg + lane;
+    int pf = (i < end) ? c_pt[i] : 0;          // ROBUST: the flagged copy of c_pt
     double2 w = make_double2(1.0, 1.0);
     if (ROBUST && pf < 0) w = c_w[i];
-    while (i < s.end) {
-      const int in = i + 64;
-      const int pn = (in < s.end) ? c_pt[in] : 0;          // prefetch the next index
+    while (i < end) {
+      const int in = i + SEGL;
+      const int pn = (in < end) ? c_pt[in] : 0;          // prefetch the next index
       const int p = ROBUST ? (pf & IDX_MASK) : pf;
       const double4 Xd = *(const double4*)(ptab + PT * (size_t)p);
       const double4 Yd = *(const double4*)(ptab + PT * (size_t)p + 4);
@@ -336,7 +401,7 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
       if (ROBUST && pn < 0) wn = c_w[in];
       const JT X0 = (JT)Xd.x, X1 = (JT)Xd.y, X2 = (JT)Xd.z, Y0 = (JT)Yd.x, Y1 = (JT)Yd.y, Y2 = (JT)Yd.z;
       GeomT<JT> g;
-      obs_geom<JT>(cam, X0, X1, X2, fxj, fyj, g);
+      obs_geom_fast<JT>(cam, X0, X1, X2, fxj, fyj, g);
       const JT s0 = -(g.P[0] * Y0 + g.P[1] * Y1 + g.P[2] * Y2) * (JT)w.x;
       const JT s1 = -(g.P[3] * Y0 + g.P[4] * Y1 + g.P[5] * Y2) * (JT)w.y;
       const JT e0 = g.P[0] * s0 + g.P[3] * s1, e1 = g.P[1] * s0 + g.P[4] * s1, e2 = g.P[2] * s0 + g.P[5] * s1;
@@ -349,7 +414,15 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
       i = in; pf = pn; w = wn;
     }
   }
-  wave_store_sums<6>(acc, s.lane, part6 + ((size_t)s.k * n_cams + s.c) * 6);
+  if (PCG) BA_STAMP(1, 3);
+#pragma unroll
+  for (int q = 0; q < 6; ++q) acc[q] = seg_sum_dpp<SEGL>(acc[q]);
+  if (live && lane == SEGL - 1) {
+    double* dst = part6 + ((size_t)k * n_cams + c) * 6;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) dst[q] = acc[q];
+  }
+  if (PCG) { BA_STAMP(1, 6); BA_STAMP(1, 7); }
 }
 
 // ---- 27-sum camera passes, one 16-lane DPP row per (camera, partition) segment ------------
@@ -388,17 +461,21 @@ __device__ inline void load_cam12(const double* __restrict__ cs, int c, double (
 
 // K2a: camera half of the normal equations, pre-M: partL[(k*Nc + c)*27 ..] = 21 sums of Jc^T w Jc (upper triangle), 6 of Jc^T w r;
 // IRLS weights and flagged indices of camera-ordered observations when ROBUST
-template <bool ROBUST>
+// COST: also the cost partials of K1 (partR[(k*Nc + c)*2 + {0,1}] = sum r^2, sum rho-term), so that the pass at a
+// TRIAL point is the trial-cost evaluation and the camera half of the next linearisation in one (ba_solve).
+template <bool ROBUST, bool COST>
 __global__ void __launch_bounds__(ROW_LANES * ROWS)
 k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
                    const int* __restrict__ c_pt, const double2* __restrict__ c_uv,
                    double fx, double fy, double cx, double cy, double hub_c, int n_cams, int band,
-                   double2* __restrict__ c_w, int* __restrict__ c_ptf, double* __restrict__ partL) {
+                   double2* __restrict__ c_w, int* __restrict__ c_ptf, double* __restrict__ partL,
+                   double* __restrict__ partR) {
   RowSeg s;
   row_segment(offk, n_cams, band, s);
-  double acc[27];
+  constexpr int NACC = COST ? 29 : 27;
+  double acc[NACC];
 #pragma unroll
-  for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+  for (int q = 0; q < NACC; ++q) acc[q] = 0.0;
   if (s.live) {
     double cam[12];
     load_cam12(cs, s.c, cam);
@@ -415,10 +492,12 @@ k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ pta
       const double ru = uv.x - (g.xh * fx + cx);
       const double rv = uv.y - (g.yh * fy + cy);
       double w0 = 1.0, w1 = 1.0;
+      if (COST) acc[27] += ru * ru + rv * rv;
       if (ROBUST) {
-        double t;
-        huber(ru, hub_c, t, w0);
-        huber(rv, hub_c, t, w1);
+        double t0, t1;
+        huber(ru, hub_c, t0, w0);
+        huber(rv, hub_c, t1, w1);
+        if (COST) acc[28] += t0 + t1;
         const int pfl = flagged_index(p, w0, w1);
         c_ptf[i] = pfl;
         if (pfl < 0) c_w[i] = make_double2(w0, w1);        // unflagged weights are never read
@@ -435,12 +514,17 @@ k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ pta
       i = in; p = pn; uv = uvn;
     }
   }
+  if (COST && !ROBUST) acc[28] = acc[27];
 #pragma unroll
-  for (int q = 0; q < 27; ++q) acc[q] = row_sum_dpp(acc[q]);
+  for (int q = 0; q < NACC; ++q) acc[q] = row_sum_dpp(acc[q]);
   if (s.live && s.l16 == ROW_LANES - 1) {
     double* o = partL + ((size_t)s.k * n_cams + s.c) * 27;
 #pragma unroll
     for (int q = 0; q < 27; ++q) o[q] = acc[q];
+    if (COST) {
+      double* r2 = partR + ((size_t)s.k * n_cams + s.c) * 2;
+      r2[0] = acc[27]; r2[1] = acc[28];
+    }
   }
 }
 
@@ -545,10 +629,27 @@ __device__ inline void load_cam_row(bool use_lds, const double* __restrict__ tab
 #pragma unroll
   for (int q = 0; q < ROWLEN / 2; ++q) { const double2 t = src[q]; row[2 * q] = t.x; row[2 * q + 1] = t.y; }
 }
+// All of a thread's loads go out before the first LDS store (batches of FILL_BATCH): a load -> wait -> store
+// loop pays one L2 round trip per 16 bytes (measured with in-kernel stamps at C3: 4.3 us for the 144 KB table,
+// 9 dependent round trips per thread).
+constexpr int FILL_BATCH = 9;
 template <int BLOCK>
 __device__ inline void fill_cam_table(double* __restrict__ tab, const double* __restrict__ camA, int lo, int n) {
   const double2* src = (const double2*)(camA + TA * (size_t)lo);
-  for (int i = threadIdx.x; i < n * TA / 2; i += BLOCK) ((double2*)tab)[i] = src[i];
+  const int total = n * TA / 2;
+  for (int base = threadIdx.x; base < total; base += BLOCK * FILL_BATCH) {
+    double2 v[FILL_BATCH];
+#pragma unroll
+    for (int u = 0; u < FILL_BATCH; ++u) {
+      const int i = base + u * BLOCK;
+      v[u] = (i < total) ? src[i] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int u = 0; u < FILL_BATCH; ++u) {
+      const int i = base + u * BLOCK;
+      if (i < total) ((double2*)tab)[i] = v[u];
+    }
+  }
   __syncthreads();
 }
 // deterministic workgroup sum of N values held by every wave's lane 0 -> thread 0
@@ -605,9 +706,14 @@ __device__ __forceinline__ void
 pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,
                   const int* __restrict__ p_cam, const double2* __restrict__ p_uv, const int2* __restrict__ blk_win,
                   const PtWork& wk, int bid, int nblk, double fx, double fy, double cx, double cy, double hub_c,
-                  double lambda, double* __restrict__ Hpp, double* __restrict__ bp, double2* __restrict__ p_w,
-                  int* __restrict__ p_camf, double* __restrict__ Hppinv, double* __restrict__ y0) {
-  extern __shared__ double tab[];
+                  double lambda_arg, const double* __restrict__ lam_dev, double* __restrict__ Hpp, double* __restrict__ bp,
+                  double2* __restrict__ p_w, int* __restrict__ p_camf, double* __restrict__ Hppinv, double* __restrict__ y0,
+                  double* __restrict__ partG) {
+  extern __shared__ __align__(16) double tab[];   // 16-byte aligned: the table is read and written with b128 LDS operations
+  __shared__ double smg[PT_THREADS / 64];
+  double gm = 0.0;                                 // max |bp| over this thread's points (the reference's gtol test, scipy trf.py:451-453)
+  // lam_dev: the damping of a SPECULATED linearisation is decided on the device (k_scalars) just ahead of this launch
+  const double lambda = lam_dev ? lam_dev[0] : lambda_arg;
   const int rb = pt_range_of_block(bid, nblk, wk.xcd_ranges);
   const int2 win = blk_win[wk.blk_base + rb];
   const bool use_lds = ALL_LDS || (size_t)win.y * TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
@@ -663,7 +769,7 @@ pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, co
 #pragma unroll
       for (int q = 0; q < 6; ++q) Hpp[6 * (size_t)p + q] = a[q];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) bp[3 * (size_t)p + q] = a[6 + q];
+      for (int q = 0; q < 3; ++q) { bp[3 * (size_t)p + q] = a[6 + q]; gm = nanmax(gm, fabs(a[6 + q])); }
       double h[6] = {a[0], a[1], a[2], a[3], a[4], a[5]}, inv[6], y[3];
       h[0] += lambda * fmax(h[0], DIAG_FLOOR);
       h[3] += lambda * fmax(h[3], DIAG_FLOOR);
@@ -677,19 +783,27 @@ pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, co
       o[0] = y[0]; o[1] = y[1]; o[2] = y[2];
     }
   }
+  gm = wave_nanmax(gm);
+  if ((threadIdx.x & 63) == 0) smg[threadIdx.x >> 6] = gm;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = smg[0];
+    for (int w = 1; w < PT_THREADS / 64; ++w) m = nanmax(m, smg[w]);
+    partG[wk.blk_base + rb] = m;
+  }
 }
 
 #define BA_LIN_PARAMS const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,               \
                       const int* __restrict__ p_cam, const double2* __restrict__ p_uv, const int2* __restrict__ blk_win
-#define BA_LIN_TAIL double fx, double fy, double cx, double cy, double hub_c, double lambda, double* __restrict__ Hpp,          \
-                    double* __restrict__ bp, double2* __restrict__ p_w, int* __restrict__ p_camf, double* __restrict__ Hppinv, \
-                    double* __restrict__ y0
+#define BA_LIN_TAIL double fx, double fy, double cx, double cy, double hub_c, double lambda, const double* __restrict__ lam_dev, \
+                    double* __restrict__ Hpp, double* __restrict__ bp, double2* __restrict__ p_w, int* __restrict__ p_camf,      \
+                    double* __restrict__ Hppinv, double* __restrict__ y0, double* __restrict__ partG
 // one kind of track per launch
 template <bool ROBUST, bool ALL_LDS, int LANES>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_linearize(BA_LIN_PARAMS, PtWork wk, BA_LIN_TAIL) {
   pt_linearize_body<ROBUST, ALL_LDS, LANES>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wk, blockIdx.x, gridDim.x, fx, fy, cx, cy,
-                                            hub_c, lambda, Hpp, bp, p_w, p_camf, Hppinv, y0);
+                                            hub_c, lambda, lam_dev, Hpp, bp, p_w, p_camf, Hppinv, y0, partG);
 }
 // short and long tracks in one launch: workgroups [0, nblk_short) take the range list with LPP lanes
 // per point, the rest the long-track list with a DPP row per point (saves a launch per pass on data
@@ -699,11 +813,11 @@ __global__ void __launch_bounds__(PT_THREADS)
 k_pt_linearize_both(BA_LIN_PARAMS, PtWork wk, int nblk_short, PtWork wl, BA_LIN_TAIL) {
   if ((int)blockIdx.x < nblk_short)
     pt_linearize_body<ROBUST, ALL_LDS, LPP>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wk, blockIdx.x, nblk_short, fx, fy, cx, cy,
-                                            hub_c, lambda, Hpp, bp, p_w, p_camf, Hppinv, y0);
+                                            hub_c, lambda, lam_dev, Hpp, bp, p_w, p_camf, Hppinv, y0, partG);
   else
     pt_linearize_body<ROBUST, ALL_LDS, LPP_LONG>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wl, blockIdx.x - nblk_short,
-                                                 gridDim.x - nblk_short, fx, fy, cx, cy, hub_c, lambda, Hpp, bp, p_w, p_camf,
-                                                 Hppinv, y0);
+                                                 gridDim.x - nblk_short, fx, fy, cx, cy, hub_c, lambda, lam_dev, Hpp, bp, p_w,
+                                                 p_camf, Hppinv, y0, partG);
 }
 #undef BA_LIN_PARAMS
 #undef BA_LIN_TAIL
@@ -747,9 +861,11 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
               int min_iters,
               const double* __restrict__ y0, const double* __restrict__ Hpp, const double* __restrict__ bp,
               double* __restrict__ ptab_trial, double* __restrict__ partB,
-              long long* __restrict__ host_flag, long long flag_base) {
-  extern __shared__ double tab[];
+              long long* __restrict__ host_flag, long long flag_base, double* __restrict__ verdict,
+              const double* __restrict__ partG, int nG, const double* __restrict__ partGc, int nGc, double* __restrict__ gmax_out) {
+  extern __shared__ __align__(16) double tab[];   // 16-byte aligned: the table is read and written with b128 LDS operations
   __shared__ double sm[4 * (PT_THREADS / 64)];
+  if (MODE == 0) { BA_STAMP(0, 0); BA_STAMP(0, 1); }
   // the workgroup's window and the first round's track bounds are fetched before the PCG verdict
   // is known: one round trip less on the way to the first camera row
   const int rb = pt_range_of_block(bid, nblk, wk.xcd_ranges);
@@ -763,15 +879,37 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
     end0 = pt_off[p0 + 1];
   }
   if (MODE == 0) {
-    double g, z;
-    const bool fin = pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z);
-    // first kernel of iteration kit: tell the host now whether this iteration runs (it then queues
-    // the next one behind it) or PCG is over (it queues the step kernels instead)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {     // workgroup 0 of the launch, whichever kind of track it works on
-      const PcgState& s = st[kit & 1];
-      publish_flag(host_flag, flag_base + kit + 1, fin ? (long long)(s.done ? s.iters : kit) + 1 : 0);
+    // wave 0 sums the vector kernel's partials and decides for the workgroup (the other waves would wait at
+    // the table-fill barrier anyway)
+    __shared__ int s_fin;
+    if (threadIdx.x < 64) {
+      double g, z;
+      const bool fin = pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z);
+      // first probe behind a fresh linearisation: max |gradient| from the partials of the point half (partG) and of
+      // k_pcg_setup (partGc), into host-mapped memory -- the reference's gtol test costs no kernel of its own
+      double gmx = 0.0;
+      if (gmax_out && blockIdx.x == 0) {
+        for (int b = threadIdx.x; b < nG; b += 64) gmx = nanmax(gmx, partG[b]);
+        for (int b = threadIdx.x; b < nGc; b += 64) gmx = nanmax(gmx, partGc[b]);
+        gmx = wave_nanmax(gmx);
+      }
+      if (threadIdx.x == 0) {
+        s_fin = fin ? 1 : 0;
+        // first kernel of iteration kit: workgroup 0 (whichever kind of track it works on) leaves the verdict
+        // word for the iteration's other kernels and tells the host now whether this iteration runs (it then
+        // queues the next one behind it) or PCG is over (it queues the step kernels instead)
+        if (blockIdx.x == 0) {
+          if (gmax_out) gmax_out[0] = gmx;      // ordered ahead of the sequence word by publish_flag's release
+          double* vd = verdict + 4 * (kit & 1);
+          vd[0] = g; vd[1] = z; vd[2] = fin ? 1.0 : 0.0;
+          const PcgState& s = st[kit & 1];
+          publish_flag(host_flag, flag_base + kit + 1, fin ? (long long)(s.done ? s.iters : kit) + 1 : 0);
+        }
+      }
     }
-    if (fin) return;
+    __syncthreads();
+    if (s_fin) return;
+    BA_STAMP(0, 2);
   }
   const bool use_lds = ALL_LDS || (size_t)win.y * TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
   const int sub = threadIdx.x % LANES;
@@ -807,6 +945,7 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
       }
     }
     if (!table_ready) { fill_cam_table<PT_THREADS>(tab, camA, win.x, win.y); table_ready = true; }
+    if (MODE == 0 && sb == sb0) BA_STAMP(0, 3);
     if (p >= 0) {
       while (j < end) {
         // index two observations ahead, weight (only where it is not (1, 1)) one ahead
@@ -824,7 +963,7 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
           const JT* v = row + 12;
           const JT X0 = (JT)X.x, X1 = (JT)X.y, X2 = (JT)X.z;
           GeomT<JT> g;
-          obs_geom<JT>(row, X0, X1, X2, (JT)fx, (JT)fy, g);
+          obs_geom_fast<JT>(row, X0, X1, X2, (JT)fx, (JT)fy, g);
           const JT q0 = X1 * v[2] - X2 * v[1], q1 = X2 * v[0] - X0 * v[2], q2 = X0 * v[1] - X1 * v[0];
           const JT s0 = (g.P[0] * q0 + g.P[1] * q1 + g.P[2] * q2 - (g.d00 * v[3] + g.d02 * v[5])) * (JT)w.x;
           const JT s1 = (g.P[3] * q0 + g.P[4] * q1 + g.P[5] * q2 - (g.d11 * v[4] + g.d12 * v[5])) * (JT)w.y;
@@ -835,6 +974,7 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
         j = jn; c = cn; cn = cnn; w = wn;
       }
     }
+    if (MODE == 0 && sb == sb0) BA_STAMP(0, 4);
 #pragma unroll
     for (int q = 0; q < 3; ++q) u[q] = lanes_sum<LANES>(u[q]);
     if (p >= 0 && sub == LANES - 1) {
@@ -859,6 +999,7 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
       }
     }
   }
+  if (MODE == 0) BA_STAMP(0, 5);
 #pragma unroll
   for (int q = 0; q < 4; ++q) acc[q] = wave_total_dpp(acc[q]);
   block_combine<4, PT_THREADS>(acc, sm);
@@ -866,6 +1007,7 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
     if (MODE == 0) partA[wk.blk_base + rb] = acc[0];
     else { for (int q = 0; q < 4; ++q) partB[4 * (wk.blk_base + rb) + q] = acc[q]; }
   }
+  if (MODE == 0) { BA_STAMP(0, 6); BA_STAMP(0, 7); }
 }
 
 #define BA_SCH_PARAMS const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,               \
@@ -874,9 +1016,11 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
 #define BA_SCH_TAIL double fx, double fy, int fixed_cam, double* __restrict__ partA, int kit, const PcgState* __restrict__ st, \
                     const double* __restrict__ partV, int nblkV, double tol2, int min_iters, const double* __restrict__ y0,    \
                     const double* __restrict__ Hpp, const double* __restrict__ bp, double* __restrict__ ptab_trial,            \
-                    double* __restrict__ partB, long long* __restrict__ host_flag, long long flag_base
+                    double* __restrict__ partB, long long* __restrict__ host_flag, long long flag_base,                     \
+                    double* __restrict__ verdict, const double* __restrict__ partG, int nG, const double* __restrict__ partGc, \
+                    int nGc, double* __restrict__ gmax_out
 #define BA_SCH_TAIL_ARGS fx, fy, fixed_cam, partA, kit, st, partV, nblkV, tol2, min_iters, y0, Hpp, bp, ptab_trial, partB,       \
-                         host_flag, flag_base
+                         host_flag, flag_base, verdict, partG, nG, partGc, nGc, gmax_out
 template <bool ROBUST, int MODE, bool ALL_LDS, int LANES, typename JT>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_schur(BA_SCH_PARAMS, PtWork wk, BA_SCH_TAIL) {
@@ -908,6 +1052,44 @@ __device__ inline void write_vtil(const double* __restrict__ M, const double (&v
   dst[3] = v[3]; dst[4] = v[4]; dst[5] = v[5];
 }
 
+// ---- cooperative staging for the camera-vector kernels ---------------------------------------------
+// A camera-vector workgroup (one wave) owns VEC_CAMS consecutive cameras, whose rows are CONTIGUOUS in every
+// per-camera array.  A thread per camera reading its own row issues one 8-byte load per word with 16 live
+// lanes, each lane on its own cache line (k_pcg_step: ~120 such loads, 3.7 of its 4.6 us by in-kernel
+// stamps).  Instead all 64 lanes copy the workgroup's slice of every array with 16-byte coalesced loads --
+// every load issued before the first LDS store -- and the per-camera arithmetic then reads LDS.
+struct VecSlice { const double* src; int len; };        // len doubles from src (16-byte aligned)
+template <int NL>
+__device__ inline void slice_load(const VecSlice& sl, double2 (&v)[NL]) {     // NL * 64 double2 cover the slice
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const int i = u * 64 + lane;
+    v[u] = make_double2(0.0, 0.0);
+    if (2 * i + 1 < sl.len) v[u] = ((const double2*)sl.src)[i];
+    else if (2 * i < sl.len) v[u].x = sl.src[2 * i];
+  }
+}
+template <int NL>
+__device__ inline void slice_store_lds(double* __restrict__ lds, int cap, const double2 (&v)[NL]) {   // cap: doubles reserved (even)
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const int i = u * 64 + lane;
+    if (2 * i < cap) ((double2*)lds)[i] = v[u];
+  }
+}
+// LDS -> global, len doubles (dst 16-byte aligned)
+__device__ inline void slice_write_back(double* __restrict__ dst, const double* __restrict__ lds, int len) {
+  const int lane = threadIdx.x & 63;
+  for (int i = lane; 2 * i < len; i += 64) {
+    if (2 * i + 1 < len) ((double2*)dst)[i] = ((const double2*)lds)[i];
+    else dst[2 * i] = lds[2 * i];
+  }
+}
+constexpr int VC = VEC_CAMS;
+static_assert(VEC_CAMS == 16, "the staging below is laid out for 16 cameras per camera-vector workgroup");
+
 // PCG setup at damping lambda: Hccd = Hcc + lam Dc (fixed camera: identity), Schur-Jacobi
 // or Jacobi preconditioner Minv = (Hccd - E)^-1, right-hand side g = -(bc - W y0), and the
 // (FINALIZE: first folds the fresh linearisation partials into Hcc | bc, single rank)
@@ -921,61 +1103,135 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
             int use_schur_diag, int n_cams, int fixed_cam, double* __restrict__ Hccd, double* __restrict__ Minv,
             double* __restrict__ gvec, double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
             double* __restrict__ s, double* __restrict__ z, double* __restrict__ vtil,
-            double* __restrict__ partV, PcgState* __restrict__ st) {
-  __shared__ double sm[2];
+            double* __restrict__ partV, PcgState* __restrict__ st, double* __restrict__ partGc) {
+  // LDS image of the workgroup's VC cameras.  Inputs: partition-folded sums (a: 27 of the linearisation when
+  // FINALIZE, e: 21 Schur-Jacobi, w6: 6 of W y0), Hcc | bc (when not FINALIZE), cs.  Outputs staged for a
+  // coalesced write-back: Hcc | bc (FINALIZE), Hccd, Minv, g = r, z (x = p = s = 0 written directly).
+  __shared__ double l_a[27 * VC], l_e[21 * VC], l_w6[6 * VC], l_cs[CS * VC], l_hcc[21 * VC], l_bc[6 * VC],
+      l_hd[21 * VC], l_mi[21 * VC], l_g[6 * VC], l_z[6 * VC];
+  const int c0 = blockIdx.x * VC;
+  const int nc = min(VC, n_cams - c0);
   const int c = vec_camera(n_cams);
+  const int lane = threadIdx.x;
+  // ---- cooperative loads: every word of the workgroup's slices, lane-strided and coalesced; the partition
+  // sums run k = 0, 1, ... in every element (the same fixed order as a thread-per-camera loop)
+  {
+    double2 vc[3], vh[3], vb[1];
+    slice_load(VecSlice{cs + CS * (size_t)c0, CS * nc}, vc);
+    if (!FINALIZE) {
+      slice_load(VecSlice{Hcc + 21 * (size_t)c0, 21 * nc}, vh);
+      slice_load(VecSlice{bc + 6 * (size_t)c0, 6 * nc}, vb);
+    }
+    constexpr int NA = (27 * VC + 63) / 64, NE = (21 * VC + 63) / 64, NW = (6 * VC + 63) / 64;
+    double sa[NA], se[NE], sw[NW];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) sa[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NE; ++j) se[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) sw[j] = 0.0;
+    const int la = 27 * nc, le = 21 * nc, lw = 6 * nc;
+#pragma unroll 2
+    for (int k = 0; k < NPART; ++k) {
+      double ta[NA], te[NE], tw[NW];
+      const double* pa = partL + ((size_t)k * n_cams + c0) * 27;
+      const double* pe = partE + ((size_t)k * n_cams + c0) * 21;
+      const double* pw = part6 + ((size_t)k * n_cams + c0) * 6;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) { const int i = j * 64 + lane; ta[j] = (FINALIZE && i < la) ? pa[i] : 0.0; }
+#pragma unroll
+      for (int j = 0; j < NE; ++j) { const int i = j * 64 + lane; te[j] = (use_schur_diag && k < nparts && i < le) ? pe[i] : 0.0; }
+#pragma unroll
+      for (int j = 0; j < NW; ++j) { const int i = j * 64 + lane; tw[j] = (k < nparts && i < lw) ? pw[i] : 0.0; }
+#pragma unroll
+      for (int j = 0; j < NA; ++j) sa[j] += ta[j];
+#pragma unroll
+      for (int j = 0; j < NE; ++j) se[j] += te[j];
+#pragma unroll
+      for (int j = 0; j < NW; ++j) sw[j] += tw[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NA; ++j) { const int i = j * 64 + lane; if (i < 27 * VC) l_a[i] = sa[j]; }
+#pragma unroll
+    for (int j = 0; j < NE; ++j) { const int i = j * 64 + lane; if (i < 21 * VC) l_e[i] = se[j]; }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) { const int i = j * 64 + lane; if (i < 6 * VC) l_w6[i] = sw[j]; }
+    slice_store_lds(l_cs, CS * VC, vc);
+    if (!FINALIZE) {
+      slice_store_lds(l_hcc, 21 * VC, vh);
+      slice_store_lds(l_bc, 6 * VC, vb);
+    }
+  }
+  __syncthreads();
   double acc[2] = {0, 0};
+  double gmc = 0.0;
+  const int t = threadIdx.x;
   if (c < n_cams) {
-    const double* M = cs + CS * c + 12;
-    if (FINALIZE) lin_finalize_camera(partL, cs + CS * c, n_cams, c, fixed_cam, Hcc + 21 * c, bc + 6 * c);
+    const double* M = l_cs + CS * t + 12;
+    const bool fixed = c == fixed_cam;
+    if (FINALIZE) lin_finalize_sums(l_a + 27 * t, M, fixed, l_hcc + 21 * t, l_bc + 6 * t);
     double h[21], m[21], inv[21];
-    for (int q = 0; q < 21; ++q) h[q] = Hcc[21 * c + q];
-    if (c == fixed_cam) {
+    for (int q = 0; q < 21; ++q) h[q] = l_hcc[21 * t + q];
+    if (fixed) {
       for (int q = 0; q < 21; ++q) h[q] = 0.0;
       for (int i = 0; i < 6; ++i) h[U6(i, i)] = 1.0;
     } else {
       for (int i = 0; i < 6; ++i) h[U6(i, i)] += lambda * fmax(h[U6(i, i)], DIAG_FLOOR);
     }
-    for (int q = 0; q < 21; ++q) { Hccd[21 * c + q] = h[q]; m[q] = h[q]; }
-    if (use_schur_diag && c != fixed_cam) {
-      double e[21];
-      for (int q = 0; q < 21; ++q) e[q] = 0.0;
-      for (int k = 0; k < nparts; ++k) {
-        const double* src = partE + ((size_t)k * n_cams + c) * 21;
-        for (int q = 0; q < 21; ++q) e[q] += src[q];
-      }
+    for (int q = 0; q < 21; ++q) { l_hd[21 * t + q] = h[q]; m[q] = h[q]; }
+    if (use_schur_diag && !fixed) {
       double A[6][6];
-      for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) A[i][j] = e[S6(i, j)];
+      for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) A[i][j] = l_e[21 * t + S6(i, j)];
       m_congruence(M, A);
       for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) m[U6(i, j)] -= A[i][j];
     }
     spd6_inverse(m, inv);
-    for (int q = 0; q < 21; ++q) Minv[21 * c + q] = inv[q];
+    for (int q = 0; q < 21; ++q) l_mi[21 * t + q] = inv[q];
     double wy[6], g[6], zz[6], hz[6];
-    combine_wy(part6, nparts, n_cams, c, M, wy);
-    for (int q = 0; q < 6; ++q) g[q] = (c == fixed_cam) ? 0.0 : -(bc[6 * c + q] - wy[q]);
+    {
+      const double* a = l_w6 + 6 * t;
+      wy[0] = M[0] * a[0] + M[3] * a[1] + M[6] * a[2];
+      wy[1] = M[1] * a[0] + M[4] * a[1] + M[7] * a[2];
+      wy[2] = M[2] * a[0] + M[5] * a[1] + M[8] * a[2];
+      wy[3] = a[3]; wy[4] = a[4]; wy[5] = a[5];
+    }
+    for (int q = 0; q < 6; ++q) g[q] = fixed ? 0.0 : -(l_bc[6 * t + q] - wy[q]);
+    for (int q = 0; q < 6; ++q) gmc = nanmax(gmc, fabs(l_bc[6 * t + q]));     // max |bc| (gtol test)
     sym6_mul(inv, g, zz);
     sym6_mul(h, zz, hz);
     for (int q = 0; q < 6; ++q) {
-      gvec[6 * c + q] = g[q]; r[6 * c + q] = g[q]; x[6 * c + q] = 0.0; p[6 * c + q] = 0.0; s[6 * c + q] = 0.0;
-      z[6 * c + q] = zz[q];
+      l_g[6 * t + q] = g[q];
+      l_z[6 * t + q] = zz[q];
       acc[0] += g[q] * zz[q];
       acc[1] += zz[q] * hz[q];
     }
     write_vtil(M, zz, vtil + TA * c + 12);
   }
+  __syncthreads();
+  // ---- coalesced write-back
+  if (FINALIZE) {
+    slice_write_back(Hcc + 21 * (size_t)c0, l_hcc, 21 * nc);
+    slice_write_back(bc + 6 * (size_t)c0, l_bc, 6 * nc);
+  }
+  slice_write_back(Hccd + 21 * (size_t)c0, l_hd, 21 * nc);
+  slice_write_back(Minv + 21 * (size_t)c0, l_mi, 21 * nc);
+  slice_write_back(gvec + 6 * (size_t)c0, l_g, 6 * nc);
+  slice_write_back(r + 6 * (size_t)c0, l_g, 6 * nc);
+  slice_write_back(z + 6 * (size_t)c0, l_z, 6 * nc);
+  for (int i = lane; i < 6 * nc; i += 64) { x[6 * (size_t)c0 + i] = 0.0; p[6 * (size_t)c0 + i] = 0.0; s[6 * (size_t)c0 + i] = 0.0; }
 #pragma unroll
   for (int q = 0; q < 2; ++q) acc[q] = wave_total_dpp(acc[q]);
+  gmc = wave_nanmax(gmc);
   if (threadIdx.x == 0) {
     partV[2 * blockIdx.x] = acc[0];
     partV[2 * blockIdx.x + 1] = acc[1];
+    partGc[blockIdx.x] = gmc;
     if (blockIdx.x == 0) {
       PcgState s0 = {0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0};
       st[0] = s0;
       st[1] = s0;
     }
   }
-  (void)sm;
 }
 
 // K5: one PCG iteration's vector work (Chronopoulos-Gear single-reduction CG).  With z the
@@ -992,25 +1248,39 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
            int n_cams, int fixed_cam, double tol2, int min_iters,
            double* __restrict__ x, double* __restrict__ r, double* __restrict__ p, double* __restrict__ s,
            double* __restrict__ z, double* __restrict__ vtil, double* __restrict__ partV, int nblkV,
-           PcgState* __restrict__ st, long long* __restrict__ host_flag, long long flag_base) {
-  // every operand is fetched before the verdict is known (one round trip for the whole kernel; an
-  // early-exit launch wastes the loads)
+           PcgState* __restrict__ st, long long* __restrict__ host_flag, long long flag_base,
+           const double* __restrict__ verdict) {
+  // LDS image of the workgroup's cameras: Hccd | Minv | z p s r x | part6[NPART] | cs
+  __shared__ double l_h[21 * VC], l_mi[21 * VC], l_v[5][6 * VC], l_p6[NPART][6 * VC], l_cs[CS * VC];
+  BA_STAMP(2, 0); BA_STAMP(2, 1);
+  const int c0 = blockIdx.x * VC;
+  const int nc = min(VC, n_cams - c0);                         // cameras of this workgroup (>= 1)
   const int c = vec_camera(n_cams);
   const bool live = c < n_cams && c != fixed_cam;
-  double h[21], mi[21], zz[6], wy[6], pp[6], ss[6], rr[6], xx[6];
+  // every operand is fetched before the verdict is known (one round trip for the whole kernel; an
+  // early-exit launch wastes the loads)
   const double uy = uy_src[0];
-  if (live) {
-    const double* M = cs + CS * c + 12;
+  {
+    double2 vh[3], vm[3], vv[5][1], vp[NPART][1], vc[3];     // 168 | 168 | 48 | 48 | 192 double2 per slice
+    slice_load(VecSlice{Hccd + 21 * (size_t)c0, 21 * nc}, vh);
+    slice_load(VecSlice{Minv + 21 * (size_t)c0, 21 * nc}, vm);
+    const double* vecs[5] = {z, p, s, r, x};
 #pragma unroll
-    for (int q = 0; q < 21; ++q) { h[q] = Hccd[21 * c + q]; mi[q] = Minv[21 * c + q]; }
+    for (int q = 0; q < 5; ++q) slice_load(VecSlice{vecs[q] + 6 * (size_t)c0, 6 * nc}, vv[q]);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      zz[q] = z[6 * c + q]; pp[q] = p[6 * c + q]; ss[q] = s[6 * c + q]; rr[q] = r[6 * c + q]; xx[q] = x[6 * c + q];
-    }
-    combine_wy(part6, nparts, n_cams, c, M, wy);
+    for (int kk = 0; kk < NPART; ++kk)
+      slice_load(VecSlice{part6 + ((size_t)kk * n_cams + c0) * 6, kk < nparts ? 6 * nc : 0}, vp[kk]);
+    slice_load(VecSlice{cs + CS * (size_t)c0, CS * nc}, vc);
+    slice_store_lds(l_h, 21 * VC, vh);
+    slice_store_lds(l_mi, 21 * VC, vm);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) slice_store_lds(l_v[q], 6 * VC, vv[q]);
+#pragma unroll
+    for (int kk = 0; kk < NPART; ++kk) slice_store_lds(l_p6[kk], 6 * VC, vp[kk]);
+    slice_store_lds(l_cs, CS * VC, vc);
   }
   double gamma, zeta;
-  const bool fin = pcg_finished(k, st, partV, nblkV, tol2, min_iters, gamma, zeta);
+  const bool fin = pcg_verdict(verdict, k, gamma, zeta);     // left by the point pass of this iteration
   const PcgState sin = st[k & 1];
   PcgState* sout = st + ((k + 1) & 1);
   if (fin) {
@@ -1022,6 +1292,7 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
     }
     return;
   }
+  BA_STAMP(2, 2);
   const double delta = zeta - uy;
   const double beta = (k == 0) ? 0.0 : gamma / sin.gamma_prev;
   const double denom = (k == 0) ? delta : delta - beta * gamma / sin.alpha_prev;
@@ -1036,30 +1307,58 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) publish_flag(host_flag, flag_base + k + 1, 0);   // verdict: keep going
   const double alpha = gamma / denom;
+  __syncthreads();                                      // the LDS image is complete
   double acc[2] = {0, 0};
+  const int t = threadIdx.x;
   if (live) {
-    const double* M = cs + CS * c + 12;
-    double w[6], hz[6];
+    const double* M = l_cs + CS * t + 12;
+    double h[21], mi[21];                               // into registers once: LDS stores below would force re-reads
+#pragma unroll
+    for (int q = 0; q < 21; ++q) { h[q] = l_h[21 * t + q]; mi[q] = l_mi[21 * t + q]; }
+    double zz[6], wy[6], pp[6], ss[6], rr[6], xx[6], w[6], hz[6];
+    {
+      double a[6] = {0, 0, 0, 0, 0, 0};
+      for (int kk = 0; kk < nparts; ++kk) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) a[q] += l_p6[kk][6 * t + q];
+      }
+      wy[0] = M[0] * a[0] + M[3] * a[1] + M[6] * a[2];
+      wy[1] = M[1] * a[0] + M[4] * a[1] + M[7] * a[2];
+      wy[2] = M[2] * a[0] + M[5] * a[1] + M[8] * a[2];
+      wy[3] = a[3]; wy[4] = a[4]; wy[5] = a[5];
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      zz[q] = l_v[0][6 * t + q]; pp[q] = l_v[1][6 * t + q]; ss[q] = l_v[2][6 * t + q];
+      rr[q] = l_v[3][6 * t + q]; xx[q] = l_v[4][6 * t + q];
+    }
     sym6_mul(h, zz, w);
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       w[q] -= wy[q];
       pp[q] = zz[q] + beta * pp[q];
       ss[q] = w[q] + beta * ss[q];
-      x[6 * c + q] = xx[q] + alpha * pp[q];
+      xx[q] = xx[q] + alpha * pp[q];
       rr[q] -= alpha * ss[q];
-      p[6 * c + q] = pp[q]; s[6 * c + q] = ss[q]; r[6 * c + q] = rr[q];
     }
     sym6_mul(mi, rr, zz);
     sym6_mul(h, zz, hz);
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-      z[6 * c + q] = zz[q];
+      l_v[0][6 * t + q] = zz[q]; l_v[1][6 * t + q] = pp[q]; l_v[2][6 * t + q] = ss[q];
+      l_v[3][6 * t + q] = rr[q]; l_v[4][6 * t + q] = xx[q];
       acc[0] += rr[q] * zz[q];
       acc[1] += zz[q] * hz[q];
     }
     write_vtil(M, zz, vtil + TA * c + 12);
   }
+  __syncthreads();
+  {                                                     // the five vectors back, coalesced (fixed camera: unchanged image)
+    double* vecs[5] = {z, p, s, r, x};
+#pragma unroll
+    for (int q = 0; q < 5; ++q) slice_write_back(vecs[q] + 6 * (size_t)c0, l_v[q], 6 * nc);
+  }
+  BA_STAMP(2, 3);
 #pragma unroll
   for (int q = 0; q < 2; ++q) acc[q] = wave_total_dpp(acc[q]);
   if (threadIdx.x == 0) {
@@ -1074,6 +1373,7 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
       *sout = o;
     }
   }
+  BA_STAMP(2, 6); BA_STAMP(2, 7);
 }
 
 // K7a: camera update.  cams_trial = cams + dc, camera state of the trial cameras, vtil =
@@ -1084,24 +1384,46 @@ k_cam_update(const double* __restrict__ cams, const double* __restrict__ dc, con
              const double* __restrict__ Hcc, const double* __restrict__ bc, const double* __restrict__ cs,
              int n_cams, int fixed_cam, double* __restrict__ cams_trial, double* __restrict__ cs_trial,
              double* __restrict__ vtil, double* __restrict__ camA_trial, double* __restrict__ partC) {
+  // LDS image of the workgroup's VC cameras (coalesced staging, see slice_load): cams dc rpcg bc | Hcc | cs,
+  // outputs cams_trial | cs_trial staged for a coalesced write-back
+  __shared__ double l_in[4][6 * VC], l_hcc[21 * VC], l_cs[CS * VC], l_ct[6 * VC], l_cst[CS * VC];
+  const int c0 = blockIdx.x * VC;
+  const int nc = min(VC, n_cams - c0);
   const int c = vec_camera(n_cams);
+  {
+    double2 vi[4][1], vh[3], vc[3];
+    const double* ins[4] = {cams, dc, rpcg, bc};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) slice_load(VecSlice{ins[q] + 6 * (size_t)c0, 6 * nc}, vi[q]);
+    slice_load(VecSlice{Hcc + 21 * (size_t)c0, 21 * nc}, vh);
+    slice_load(VecSlice{cs + CS * (size_t)c0, CS * nc}, vc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) slice_store_lds(l_in[q], 6 * VC, vi[q]);
+    slice_store_lds(l_hcc, 21 * VC, vh);
+    slice_store_lds(l_cs, CS * VC, vc);
+  }
+  __syncthreads();
   double acc[5] = {0, 0, 0, 0, 0};
+  const int t = threadIdx.x;
   if (c < n_cams) {
     double d[6];
-    for (int q = 0; q < 6; ++q) d[q] = (c == fixed_cam) ? 0.0 : dc[6 * c + q];
+    for (int q = 0; q < 6; ++q) d[q] = (c == fixed_cam) ? 0.0 : l_in[1][6 * t + q];
     for (int q = 0; q < 6; ++q) {
-      const double xq = cams[6 * c + q];
-      cams_trial[6 * c + q] = xq + d[q];
-      acc[0] += bc[6 * c + q] * d[q];
-      acc[1] += fmax(Hcc[21 * c + U6(q, q)], DIAG_FLOOR) * d[q] * d[q];
-      acc[2] += d[q] * ((c == fixed_cam) ? 0.0 : rpcg[6 * c + q]);
+      const double xq = l_in[0][6 * t + q];
+      l_ct[6 * t + q] = xq + d[q];
+      acc[0] += l_in[3][6 * t + q] * d[q];
+      acc[1] += fmax(l_hcc[21 * t + U6(q, q)], DIAG_FLOOR) * d[q] * d[q];
+      acc[2] += d[q] * ((c == fixed_cam) ? 0.0 : l_in[2][6 * t + q]);
       acc[3] += d[q] * d[q];
       acc[4] += xq * xq;
     }
-    write_vtil(cs + CS * c + 12, d, vtil + TA * c + 12);
-    camera_state(cams_trial + 6 * c, cs_trial + CS * c);
-    for (int q = 0; q < 12; ++q) camA_trial[TA * c + q] = cs_trial[CS * c + q];
+    write_vtil(l_cs + CS * t + 12, d, vtil + TA * c + 12);
+    camera_state(l_ct + 6 * t, l_cst + CS * t);
+    for (int q = 0; q < 12; ++q) camA_trial[TA * c + q] = l_cst[CS * t + q];
   }
+  __syncthreads();
+  slice_write_back(cams_trial + 6 * (size_t)c0, l_ct, 6 * nc);
+  slice_write_back(cs_trial + CS * (size_t)c0, l_cst, CS * nc);
 #pragma unroll
   for (int q = 0; q < 5; ++q) acc[q] = wave_total_dpp(acc[q]);
   if (threadIdx.x == 0) for (int q = 0; q < 5; ++q) partC[5 * blockIdx.x + q] = acc[q];
@@ -1112,11 +1434,31 @@ k_cam_update(const double* __restrict__ cams, const double* __restrict__ dc, con
 // camera partials (nC x 5, may be 0 rows); with st != null also the PCG verdict for
 // iteration `kit` (the test pcg_finished makes).  scal_host (nullable) is a host-mapped
 // mirror written in the same kernel, so the host needs no copy, only the stream sync.
+// The LM step's verdict, computed where its inputs are (one source of truth for host and device): gain ratio
+// rho = (cost - cost_new) / model with the model decrease of the damped, inexactly solved system
+// 0.5 (lambda d^T D d - g^T d + dc.r_pcg), and the damping an ACCEPTED step continues with (Nielsen's update).
+// The host takes both from here; a speculated point-half linearisation at the trial point reads res[S_LAM_NEXT]
+// from device memory before the host has decided anything.
+__device__ inline void lm_decide(double* __restrict__ res, double cost_cur, double lambda) {
+  const double cost_new = 0.5 * res[S_RHO];
+  const double gTd = res[S_PT_GD] + res[S_CAM_GD], dDd = res[S_PT_DDD] + res[S_CAM_DDD], dcr = res[S_DC_R];
+  const double model = 0.5 * (lambda * dDd - gTd + dcr);
+  const double rho = (model > 0.0 && isfinite(cost_new)) ? (cost_cur - cost_new) / model : -1.0;
+  const double t = 2.0 * rho - 1.0;
+  res[S_GAIN] = rho;
+  res[S_LAM_NEXT] = fmax(lambda * fmax(1.0 / 3.0, 1.0 - t * t * t), 1e-12);
+}
+// multi-rank form: the scalars are all-reduced between k_scalars and the decision
+__global__ void k_decide(double* __restrict__ scal, double cost_cur, double lambda) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) lm_decide(scal, cost_cur, lambda);
+}
+
 __global__ void __launch_bounds__(1024)
 k_scalars(const double* __restrict__ partR, int nR, const double* __restrict__ partB, int nB,
           const double* __restrict__ partC, int nC, int kit, const PcgState* __restrict__ st,
           const double* __restrict__ partV, int nblkV, double tol2, int min_iters,
-          double* __restrict__ scal, double* __restrict__ scal_host, long long* __restrict__ host_flag, long long seq) {
+          double* __restrict__ scal, double* __restrict__ scal_host, long long* __restrict__ host_flag, long long seq,
+          int decide, double cost_cur, double lambda) {
   __shared__ double sm[11 * 16];
   // PCG verdict first (wave 1, whole wave: pcg_finished sums across its lanes): its loads are in
   // flight while the partial sums below are read
@@ -1160,6 +1502,10 @@ k_scalars(const double* __restrict__ partR, int nR, const double* __restrict__ p
     res[S_PCG_ITERS] = pcg_iters;
   }
   __syncthreads();
+  if (decide) {
+    if (threadIdx.x == 0) lm_decide(res, cost_cur, lambda);
+    __syncthreads();
+  }
   if (threadIdx.x < S_COUNT) {
     scal[threadIdx.x] = res[threadIdx.x];
     if (scal_host) scal_host[threadIdx.x] = res[threadIdx.x];   // one wave: 24 consecutive host-mapped words
@@ -1172,34 +1518,14 @@ k_scalars(const double* __restrict__ partR, int nR, const double* __restrict__ p
   }
 }
 
-// out[0] = max |v[i]|  (single workgroup)
-__global__ void __launch_bounds__(256)
-k_absmax(const double* __restrict__ v, size_t n, double* __restrict__ out) {
-  __shared__ double sm[4];
+// out[0] = max over two arrays of per-workgroup maxima (multi-rank gtol path; single wave)
+__global__ void __launch_bounds__(64)
+k_max_partials(const double* __restrict__ a, int na, const double* __restrict__ b, int nb, double* __restrict__ out) {
   double m = 0.0;
-  for (size_t i = threadIdx.x; i < n; i += 256) m = fmax(m, fabs(v[i]));
-  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) out[0] = fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
-}
-
-// out_host[0] = max(max |a|, max |b|) (single workgroup; a host-mapped word the host reads after a later
-// kernel of the stream has published its flag -- the gtol test costs no copy and no stream sync)
-__global__ void __launch_bounds__(1024)
-k_absmax2(const double* __restrict__ a, size_t na, const double* __restrict__ b, size_t nb, double* __restrict__ out_host) {
-  __shared__ double sm[16];
-  double m = 0.0;
-  for (size_t i = threadIdx.x; i < na; i += 1024) m = fmax(m, fabs(a[i]));
-  for (size_t i = threadIdx.x; i < nb; i += 1024) m = fmax(m, fabs(b[i]));
-  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o, 64));
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = sm[0];
-    for (int w = 1; w < 16; ++w) t = fmax(t, sm[w]);
-    out_host[0] = t;
-  }
+  for (int i = threadIdx.x; i < na; i += 64) m = nanmax(m, a[i]);
+  for (int i = threadIdx.x; i < nb; i += 64) m = nanmax(m, b[i]);
+  m = wave_nanmax(m);
+  if (threadIdx.x == 0) out[0] = m;
 }
 
 // Not-converged PCG state for the test / bench hooks that run one pass in isolation.
