@@ -167,6 +167,9 @@ class BundleAdjuster:
         solver = self._get_solver()
         world = self.comm[1] if self.comm is not None else 1
         if world > 1:                          # this rank's landmark block; all cameras
+            if prob.n_pts < world:             # (the same on every rank: nobody enters a collective)
+                raise ValueError(f"{prob.n_pts} landmarks in the window cannot be sharded over {world} ranks; "
+                                 f"run this window on a single rank")
             p_begin, p_end = shard_by_landmark(prob, world)[self.comm[0]]
             shard, _ = extract_shard(prob, p_begin, p_end)
             solver.set_problem(shard)

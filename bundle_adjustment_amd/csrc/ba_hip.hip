@@ -160,6 +160,10 @@ struct ba_handle {
   // host-staged shared-memory transport (BA_COMM=shm): a test vehicle that lets several ranks
   // share ONE GPU (RCCL refuses that), so the multi-rank control flow can be exercised end to end
   struct ShmComm* shm = nullptr;
+  // first failed kernel launch since the last check (hipGetLastError right behind every launch)
+  hipError_t launch_err = hipSuccess;
+  char launch_what[160] = {0};
+  int debug_lds_extra = 0;     // BA_DEBUG_LDS_EXTRA: bytes added to the point passes' dynamic LDS (tests provoke a failed launch)
   // profiling
   bool profile = false;
   std::vector<hipEvent_t> ev;
@@ -168,6 +172,36 @@ struct ba_handle {
   ba_profile prof = {};
   std::vector<float> prof_ms[BA_PROFILE_SLOTS];   // every measured duration, per slot
 };
+
+// Every kernel launch goes through BA_LAUNCH: a launch the runtime refuses (dynamic LDS above the limit, an empty
+// grid, ...) is not reported by a later stream synchronise, so the error is picked up right here and kept in the
+// handle until the next check_launches().
+static void note_launch(ba_handle* h, const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess && h->launch_err == hipSuccess) {
+    h->launch_err = e;
+    snprintf(h->launch_what, sizeof h->launch_what, "%s", what);
+  }
+}
+#define BA_LAUNCH(kern, ...)                  \
+  do {                                        \
+    hipLaunchKernelGGL(kern, __VA_ARGS__);    \
+    note_launch(h, #kern);                    \
+  } while (0)
+static int check_launches(ba_handle* h);
+// drain the stream, then report the first launch that failed since the last check (a refused launch leaves the
+// outputs stale without making the synchronise fail)
+#define BA_SYNC(h)                                            \
+  do {                                                        \
+    HIPCHECK(hipStreamSynchronize((h)->stream));              \
+    if (int rc_sync_ = check_launches(h)) return rc_sync_;    \
+  } while (0)
+static int check_launches(ba_handle* h) {
+  if (h->launch_err == hipSuccess) return BA_OK;
+  const hipError_t e = h->launch_err;
+  h->launch_err = hipSuccess;
+  return fail(BA_ERR_HIP, "launch of kernel %s failed: %s", h->launch_what, hipGetErrorString(e));
+}
 
 static int set_device(ba_handle* h) {
   HIPCHECK(hipSetDevice(h->device));
@@ -186,13 +220,7 @@ static hipError_t allow_big_lds(F* f) {
   return hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TAB_BYTES);   // the largest table a launch asks for
 }
 
-extern "C" int ba_create(int device_id, ba_handle** out) {
-  if (!out) return fail(BA_ERR_INVALID, "null out pointer");
-  int n = 0;
-  HIPCHECK(hipGetDeviceCount(&n));
-  if (device_id < 0 || device_id >= n) return fail(BA_ERR_INVALID, "device %d not in [0,%d)", device_id, n);
-  ba_handle* h = new ba_handle();
-  h->device = device_id;
+static int create_impl(ba_handle* h, int device_id) {
   HIPCHECK(hipSetDevice(device_id));
   HIPCHECK(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device_id));
   if (h->n_cu < 1) h->n_cu = 1;
@@ -217,6 +245,24 @@ extern "C" int ba_create(int device_id, ba_handle** out) {
 #undef BA_BIG_LDS_SCH1
 #undef BA_BIG_LDS_LIN
 #undef BA_BIG_LDS
+  if (const char* e = getenv("BA_DEBUG_LDS_EXTRA")) h->debug_lds_extra = atoi(e);
+  return BA_OK;
+}
+extern "C" int ba_destroy(ba_handle* h);
+extern "C" int ba_create(int device_id, ba_handle** out) {
+  if (!out) return fail(BA_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  int n = 0;
+  HIPCHECK(hipGetDeviceCount(&n));
+  if (device_id < 0 || device_id >= n) return fail(BA_ERR_INVALID, "device %d not in [0,%d)", device_id, n);
+  ba_handle* h = new ba_handle();
+  h->device = device_id;
+  if (int rc = create_impl(h, device_id)) {      // nothing half-built leaks: stream, pinned blocks and the handle go
+    const std::string msg = g_err;
+    ba_destroy(h);
+    g_err = msg;
+    return rc;
+  }
   *out = h;
   return BA_OK;
 }
@@ -228,7 +274,7 @@ static int shm_init(ba_handle* h, int rank, int world, const void* id128);
 extern "C" int ba_destroy(ba_handle* h) {
   if (!h) return BA_OK;
   (void)hipSetDevice(h->device);
-  (void)hipStreamSynchronize(h->stream);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(h->nccl);
   shm_destroy(h);
   for (auto e : h->ev) (void)hipEventDestroy(e);
@@ -259,7 +305,7 @@ extern "C" int ba_destroy(ba_handle* h) {
 extern "C" int ba_synchronize(ba_handle* h) {
   if (!h) return fail(BA_ERR_INVALID, "null handle");
   if (set_device(h)) return BA_ERR_HIP;
-  HIPCHECK(hipStreamSynchronize(h->stream));
+  BA_SYNC(h);
   return BA_OK;
 }
 
@@ -427,7 +473,7 @@ static int shm_allreduce(ba_handle* h, double* buf, size_t count, bool is_max) {
   ShmComm* c = h->shm;
   if (count * sizeof(double) > ShmComm::SLOT) return fail(BA_ERR_COMM, "shm all-reduce of %zu doubles exceeds the slot", count);
   HIPCHECK(hipMemcpyAsync(c->stage, buf, count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHECK(hipStreamSynchronize(h->stream));
+  BA_SYNC(h);
   memcpy(c->slot(c->rank), c->stage, count * sizeof(double));
   if (c->barrier()) return fail(BA_ERR_COMM, "shm barrier timed out");
   for (size_t i = 0; i < count; ++i) {            // rank order: identical bits on every rank
@@ -437,7 +483,7 @@ static int shm_allreduce(ba_handle* h, double* buf, size_t count, bool is_max) {
   }
   if (c->barrier()) return fail(BA_ERR_COMM, "shm barrier timed out");
   HIPCHECK(hipMemcpyAsync(buf, c->stage, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCHECK(hipStreamSynchronize(h->stream));      // the staging buffer is reused by the next call
+  BA_SYNC(h);      // the staging buffer is reused by the next call
   return BA_OK;
 }
 
@@ -472,8 +518,14 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     if (cam_idx[i] < 0 || cam_idx[i] >= n_cams) return fail(BA_ERR_INVALID, "cam_idx[%lld]=%d out of range", (long long)i, cam_idx[i]);
     if (pt_idx[i] < 0 || pt_idx[i] >= n_pts) return fail(BA_ERR_INVALID, "pt_idx[%lld]=%d out of range", (long long)i, pt_idx[i]);
   }
+  if ((n_cams + VEC_CAMS - 1) / VEC_CAMS > 16384) return fail(BA_ERR_INVALID, "more than %d cameras are not supported", 16384 * VEC_CAMS);
   stage("validate");
   if (set_device(h)) return BA_ERR_HIP;
+  // From here on the previous problem is gone: should anything below fail (allocation, copy), the handle is left
+  // WITHOUT a problem rather than with new sizes over old buffers.
+  h->have_problem = false;
+  h->have_params = false;
+  h->linearized = false;
   const int Nc = n_cams, Np = n_pts, No = (int)n_obs;
   // internal point numbering.  When the whole camera table fits in LDS nothing is gained by
   // moving points, so the caller's order is kept.  Otherwise points are sorted by the mean index of
@@ -561,7 +613,6 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   h->Nc = Nc; h->Np = Np; h->Nobs = No; h->fixed = fixed_cam;
   memcpy(h->K4, K4, sizeof h->K4);
   h->nblkV = (Nc + VEC_CAMS - 1) / VEC_CAMS;
-  if (h->nblkV > 16384) return fail(BA_ERR_INVALID, "more than %d cameras are not supported", 16384 * VEC_CAMS);
   // point-pass workgroups: contiguous point ranges, PT_THREADS / LPP points per round.  When the
   // whole camera table fits in LDS (so a wider range cannot overflow it) no more workgroups are
   // started than the chip holds at once -- each then walks several rounds with one table fill
@@ -679,10 +730,10 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     HIPCHECK(hipMemcpyAsync(h->rbuf.p, uv, 2 * (size_t)No * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(hipMemcpyAsync(h->c_ptf[0].p, p_src.data(), No * sizeof(int), hipMemcpyHostToDevice, h->stream));
     const dim3 gg((No + 255) / 256), gb(256);
-    hipLaunchKernelGGL(k_gather_uv, gg, gb, 0, h->stream, (const double2*)h->rbuf.p, (const int*)h->c_ptf[0].p, No, h->p_uv.p);
-    hipLaunchKernelGGL(k_gather_uv, gg, gb, 0, h->stream, (const double2*)h->rbuf.p, (const int*)h->c_orig.p, No, h->c_uv.p);
+    BA_LAUNCH(k_gather_uv, gg, gb, 0, h->stream, (const double2*)h->rbuf.p, (const int*)h->c_ptf[0].p, No, h->p_uv.p);
+    BA_LAUNCH(k_gather_uv, gg, gb, 0, h->stream, (const double2*)h->rbuf.p, (const int*)h->c_orig.p, No, h->c_uv.p);
   }
-  HIPCHECK(hipStreamSynchronize(h->stream));   // host vectors go out of scope
+  BA_SYNC(h);   // host vectors go out of scope
   stage("upload");
   h->have_problem = true;
   h->have_params = false;
@@ -707,10 +758,10 @@ extern "C" int ba_set_params(ba_handle* h, const double* cams, const double* pts
   HIPCHECK(hipMemcpyAsync(h->cams[0].p, cams, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
   if (h->Np > 0) {
     HIPCHECK(hipMemcpyAsync(h->stage.p, pts, 3 * (size_t)h->Np * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_pack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->stage.p, h->slot.p, h->Np, h->ptab[0].p);
+    BA_LAUNCH(k_pack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->stage.p, h->slot.p, h->Np, h->ptab[0].p);
   }
-  hipLaunchKernelGGL(k_cam_prepare, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->cams[0].p, h->cs[0].p, h->camA[0].p, h->Nc);
-  HIPCHECK(hipStreamSynchronize(h->stream));
+  BA_LAUNCH(k_cam_prepare, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->cams[0].p, h->cs[0].p, h->camA[0].p, h->Nc);
+  BA_SYNC(h);
   h->have_params = true;
   h->linearized = false;
   return BA_OK;
@@ -722,10 +773,10 @@ extern "C" int ba_get_params(ba_handle* h, double* cams, double* pts) {
   if (set_device(h)) return BA_ERR_HIP;
   if (cams) HIPCHECK(hipMemcpyAsync(cams, h->cams[h->cur].p, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (pts && h->Np > 0) {
-    hipLaunchKernelGGL(k_unpack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->ptab[h->cur].p, h->slot.p, h->Np, h->stage.p);
+    BA_LAUNCH(k_unpack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->ptab[h->cur].p, h->slot.p, h->Np, h->stage.p);
     HIPCHECK(hipMemcpyAsync(pts, h->stage.p, 3 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   }
-  HIPCHECK(hipStreamSynchronize(h->stream));
+  BA_SYNC(h);
   return BA_OK;
 }
 
@@ -742,11 +793,11 @@ extern "C" int ba_allgather_points(ba_handle* h, int64_t p_begin, int64_t n_tota
   HIPCHECK(h->gather.alloc(3 * (size_t)n_total));
   HIPCHECK(hipMemsetAsync(h->gather.p, 0, 3 * (size_t)n_total * sizeof(double), h->stream));
   if (h->Np > 0)
-    hipLaunchKernelGGL(k_unpack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->ptab[h->cur].p, h->slot.p, h->Np,
+    BA_LAUNCH(k_unpack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->ptab[h->cur].p, h->slot.p, h->Np,
                        h->gather.p + 3 * (size_t)p_begin);
   if (int rc = allreduce(h, h->gather.p, 3 * (size_t)n_total)) return rc;
   HIPCHECK(hipMemcpyAsync(pts_all, h->gather.p, 3 * (size_t)n_total * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHECK(hipStreamSynchronize(h->stream));
+  BA_SYNC(h);
   return BA_OK;
 }
 
@@ -756,7 +807,7 @@ extern "C" int ba_get_rotations(ba_handle* h, double* R) {
   if (set_device(h)) return BA_ERR_HIP;
   HIPCHECK(hipMemcpy2DAsync(R, 9 * sizeof(double), h->cs[h->cur].p, CS * sizeof(double), 9 * sizeof(double), h->Nc,
                             hipMemcpyDeviceToHost, h->stream));
-  HIPCHECK(hipStreamSynchronize(h->stream));
+  BA_SYNC(h);
   return BA_OK;
 }
 
@@ -764,7 +815,7 @@ extern "C" int ba_get_rotations(ba_handle* h, double* R) {
 static void launch_residual(ba_handle* h, int which, bool robust, double fscale, double* r_out) {
   Scope sc(h, BA_K_RESIDUAL);
   auto kern = robust ? k_cam_residual<true> : k_cam_residual<false>;
-  hipLaunchKernelGGL(kern, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[which].p, h->ptab[which].p, h->offk.p,
+  BA_LAUNCH(kern, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[which].p, h->ptab[which].p, h->offk.p,
                      h->c_pt.p, h->c_uv.p, h->c_orig.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, h->cam_band, r_out,
                      h->partR.p);
 }
@@ -776,7 +827,7 @@ static void launch_scalars(ba_handle* h, bool with_step, int k = 0, double tol2 
                            double cost_cur = 0.0, double lambda = 0.0) {
   Scope sc(h, BA_K_MISC);
   const bool direct = with_step && h->world == 1;     // results straight into host-mapped memory + sequence word
-  hipLaunchKernelGGL(k_scalars, dim3(1), dim3(1024), 0, h->stream, h->partR.p, NPART * h->Nc, h->partB.p,
+  BA_LAUNCH(k_scalars, dim3(1), dim3(1024), 0, h->stream, h->partR.p, NPART * h->Nc, h->partB.p,
                      (with_step && h->Np > 0) ? h->nblkP + h->nblkL : 0, h->partC.p, with_step ? h->nblkV : 0, k,
                      with_step ? (const PcgState*)h->st.p : (const PcgState*)nullptr, h->partV.p, h->nblkV, tol2, min_iters,
                      h->scal.p, direct ? h->d_scal_host : (double*)nullptr, direct ? h->d_flags + 2 : (long long*)nullptr, seq,
@@ -785,12 +836,24 @@ static void launch_scalars(ba_handle* h, bool with_step, int k = 0, double tol2 
 // spin on a host-mapped sequence word until it reaches `target` (the device publishes with a
 // system-scope release); a wall-clock limit turns a wedged GPU into an error instead of a hang
 static int wait_flag(ba_handle* h, int idx, long long target) {
+  // a kernel the runtime refused to launch will never publish: say so instead of spinning into the time-out
+  if (int rc = check_launches(h)) return rc;
   volatile long long* f = h->h_flags + idx;
   const auto t0 = std::chrono::steady_clock::now();
+  double next_query = 2e-3;         // seconds of waiting before the stream is first asked for an error state
   unsigned spins = 0;
   while (*f < target) {
-    if ((++spins & 0xfff) == 0 &&
-        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 20.0)
+    if ((++spins & 0xfff) != 0) continue;
+    const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (waited > next_query) {      // a faulted kernel puts the stream into a sticky error state: report that, not a time-out
+      next_query = waited * 2;
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q != hipSuccess && q != hipErrorNotReady)
+        return fail(BA_ERR_HIP, "the stream reports '%s' while waiting for flag %d", hipGetErrorString(q), idx);
+      if (q == hipSuccess && *f < target)          // stream drained and the word was never written
+        return fail(BA_ERR_HIP, "the stream drained without publishing flag %d (%lld < %lld)", idx, (long long)*f, target);
+    }
+    if (waited > 20.0)
       return fail(BA_ERR_HIP, "timed out waiting for the device (flag %d: %lld < %lld)", idx, (long long)*f, target);
   }
   std::atomic_thread_fence(std::memory_order_acquire);
@@ -802,13 +865,13 @@ static void launch_lin_cam(ba_handle* h, int which, int buf, bool robust, double
   Scope sc(h, BA_K_LINEARIZE_CAM);
   auto kern = robust ? (cost ? k_camrow_linearize<true, true> : k_camrow_linearize<true, false>)
                      : (cost ? k_camrow_linearize<false, true> : k_camrow_linearize<false, false>);
-  hipLaunchKernelGGL(kern, dim3(row_grid(h)), dim3(ROW_LANES * ROWS), 0, h->stream, h->cs[which].p, h->ptab[which].p, h->offk.p,
+  BA_LAUNCH(kern, dim3(row_grid(h)), dim3(ROW_LANES * ROWS), 0, h->stream, h->cs[which].p, h->ptab[which].p, h->offk.p,
                      h->c_pt.p, h->c_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, h->cam_band, h->c_w[buf].p,
                      h->c_ptf[buf].p, h->partL[buf].p, h->partR.p);
 }
 static void launch_lin_finalize(ba_handle* h) {
   Scope sc(h, BA_K_MISC);
-  hipLaunchKernelGGL(k_lin_finalize, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->partL[h->lb].p, h->cs[h->cur].p,
+  BA_LAUNCH(k_lin_finalize, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->partL[h->lb].p, h->cs[h->cur].p,
                      h->Nc, h->fixed, h->HccBc.p, bc_ptr(h));
 }
 static PtWork pt_work(ba_handle* h) {        // every point; long tracks skipped when they have a launch of their own
@@ -823,8 +886,8 @@ static void launch_lin_pt(ba_handle* h, int w, int pbuf, bool robust, double fsc
 #define LP_HEAD h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_uv.p, h->blk_win.p
 #define LP_TAIL h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, lambda, lam_dev, h->Hpp[pbuf].p, h->bp[pbuf].p, h->p_w[pbuf].p,      \
                 h->p_camf[pbuf].p, h->Hppinv[pbuf].p, h->y0[pbuf].p, h->partG[pbuf].p
-#define LP_LAUNCH(R, L, LN, G, WK) hipLaunchKernelGGL((k_pt_linearize<R, L, LN>), dim3(G), dim3(PT_THREADS), h->lds_bytes, h->stream, LP_HEAD, WK, LP_TAIL)
-#define LP_BOTH(R, L) hipLaunchKernelGGL((k_pt_linearize_both<R, L>), dim3(h->nblkP + h->nblkL), dim3(PT_THREADS), h->lds_bytes, h->stream, \
+#define LP_LAUNCH(R, L, LN, G, WK) BA_LAUNCH((k_pt_linearize<R, L, LN>), dim3(G), dim3(PT_THREADS), h->lds_bytes, h->stream, LP_HEAD, WK, LP_TAIL)
+#define LP_BOTH(R, L) BA_LAUNCH((k_pt_linearize_both<R, L>), dim3(h->nblkP + h->nblkL), dim3(PT_THREADS), h->lds_bytes, h->stream, \
                                          LP_HEAD, wk, h->nblkP, wl, LP_TAIL)
   const PtWork wk = pt_work(h), wl = pt_work_long(h);
   if (h->nblkL) {          // short and long tracks in one launch
@@ -852,7 +915,7 @@ static void launch_lin_pt(ba_handle* h, int w, int pbuf, bool robust, double fsc
 static void launch_point_invert(ba_handle* h, double lambda) {
   if (h->Np == 0) return;
   Scope sc(h, BA_K_POINT_INVERT);
-  hipLaunchKernelGGL(k_point_invert, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp[h->pb].p, h->bp[h->pb].p, lambda,
+  BA_LAUNCH(k_point_invert, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp[h->pb].p, h->bp[h->pb].p, lambda,
                      h->Np, h->Hppinv[h->pb].p, h->y0[h->pb].p, h->ptab[h->cur].p);
 }
 // camera pass of the Schur product on the y slot of the current point table
@@ -867,21 +930,21 @@ static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int
   const dim3 g(cam_grid(h, segl) + (pcg ? 1 : 0)), b(64 * WPB);
 #define CS_PCG(R, JT)                                                                                       \
   do {                                                                                                      \
-    if (segl == 16) hipLaunchKernelGGL((k_cam_schur<R, true, JT, 16>), g, b, 0, h->stream, CS_ARGS);        \
-    else if (segl == 32) hipLaunchKernelGGL((k_cam_schur<R, true, JT, 32>), g, b, 0, h->stream, CS_ARGS);   \
-    else hipLaunchKernelGGL((k_cam_schur<R, true, JT, 64>), g, b, 0, h->stream, CS_ARGS);                   \
+    if (segl == 16) BA_LAUNCH((k_cam_schur<R, true, JT, 16>), g, b, 0, h->stream, CS_ARGS);        \
+    else if (segl == 32) BA_LAUNCH((k_cam_schur<R, true, JT, 32>), g, b, 0, h->stream, CS_ARGS);   \
+    else BA_LAUNCH((k_cam_schur<R, true, JT, 64>), g, b, 0, h->stream, CS_ARGS);                   \
   } while (0)
   if (diag) {
     auto kern = robust ? k_camrow_schur_diag<true> : k_camrow_schur_diag<false>;
-    hipLaunchKernelGGL(kern, dim3(row_grid(h)), dim3(ROW_LANES * ROWS), 0, h->stream, h->cs[w].p, h->ptab[w].p, h->offk.p,
+    BA_LAUNCH(kern, dim3(row_grid(h)), dim3(ROW_LANES * ROWS), 0, h->stream, h->cs[w].p, h->ptab[w].p, h->offk.p,
                        (robust ? h->c_ptf[h->lb].p : h->c_pt.p), h->c_w[h->lb].p, h->Hppinv[h->pb].p, h->K4[0], h->K4[1], h->Nc,
                        h->cam_band, h->fixed, p6_ptr(h), h->partE.p);
   } else if (pcg) {
     if (h->jac_f32) { if (robust) CS_PCG(true, float); else CS_PCG(false, float); }
     else            { if (robust) CS_PCG(true, double); else CS_PCG(false, double); }
   } else {
-    if (robust) hipLaunchKernelGGL((k_cam_schur<true, false, double, 64>), g, b, 0, h->stream, CS_ARGS);
-    else        hipLaunchKernelGGL((k_cam_schur<false, false, double, 64>), g, b, 0, h->stream, CS_ARGS);
+    if (robust) BA_LAUNCH((k_cam_schur<true, false, double, 64>), g, b, 0, h->stream, CS_ARGS);
+    else        BA_LAUNCH((k_cam_schur<false, false, double, 64>), g, b, 0, h->stream, CS_ARGS);
   }
 #undef CS_PCG
 #undef CS_ARGS
@@ -890,7 +953,15 @@ static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int
 // gmax_out (first PCG probe behind a fresh linearisation): host-mapped word that receives max |gradient|
 static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double tol2, int min_iters, long long flag_base = 0,
                             double* gmax_out = nullptr) {
-  if (h->Np == 0) return;
+  if (h->Np == 0) {
+    // an empty landmark shard (multi-rank): no point pass, but the PCG probe's verdict is still owed
+    if (mode == 0 && flag_base > 0) {
+      Scope sc(h, BA_K_SCHUR_PT);
+      BA_LAUNCH(k_pcg_probe, dim3(1), dim3(64), 0, h->stream, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->d_flags,
+                flag_base, h->verdict.p, (const double*)h->partGc.p, h->nblkV, gmax_out);
+    }
+    return;
+  }
   Scope sc(h, mode == 0 ? BA_K_SCHUR_PT : BA_K_BACKSUB);
   const int w = h->cur;
 #define PS_HEAD h->camA[w].p, h->ptab[w].p, h->pt_off.p, (robust ? h->p_camf[h->pb].p : h->p_cam.p), h->p_w[h->pb].p,                 \
@@ -898,14 +969,14 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
 #define PS_TAIL h->K4[0], h->K4[1], h->fixed, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0[h->pb].p,     \
                 h->Hpp[h->pb].p, h->bp[h->pb].p, h->ptab[1 - w].p, h->partB.p, flag, flag_base, h->verdict.p,                      \
                 (const double*)h->partG[h->pb].p, h->nblkP + h->nblkL, (const double*)h->partGc.p, h->nblkV, gmax_out
-  const size_t lds = h->lds_bytes;
+  const size_t lds = h->lds_bytes + (size_t)h->debug_lds_extra;
   long long* flag = (mode == 0 && flag_base > 0) ? h->d_flags : (long long*)nullptr;
   // data with long tracks: short and long tracks in one launch (workgroup 0 publishes the verdict)
 #define PS_ONE(R, M, L, LN, JT) \
-  hipLaunchKernelGGL((k_pt_schur<R, M, L, LN, JT>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, PS_HEAD, wk, PS_TAIL)
+  BA_LAUNCH((k_pt_schur<R, M, L, LN, JT>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, PS_HEAD, wk, PS_TAIL)
 #define PS_LAUNCH(R, M, L, JT)                                                                                              \
   do {                                                                                                                      \
-    if (h->nblkL) hipLaunchKernelGGL((k_pt_schur_both<R, M, L, JT>), dim3(h->nblkP + h->nblkL), dim3(PT_THREADS), lds,      \
+    if (h->nblkL) BA_LAUNCH((k_pt_schur_both<R, M, L, JT>), dim3(h->nblkP + h->nblkL), dim3(PT_THREADS), lds,      \
                                      h->stream, PS_HEAD, wk, h->nblkP, wl, PS_TAIL);                                        \
     else {                                                                                                                  \
       switch (h->lanes) {                                                                                                   \
@@ -941,7 +1012,7 @@ static int fold_and_reduce(ba_handle* h, double* parts, size_t n_per_part, doubl
   if (h->world == 1) return BA_OK;
   {
     Scope sc(h, BA_K_MISC);
-    hipLaunchKernelGGL(k_fold_parts, dim3((unsigned)((n_per_part + 255) / 256)), dim3(256), 0, h->stream, parts, n_per_part, NPART);
+    BA_LAUNCH(k_fold_parts, dim3((unsigned)((n_per_part + 255) / 256)), dim3(256), 0, h->stream, parts, n_per_part, NPART);
   }
   return allreduce(h, msg, msg_count);
 }
@@ -961,8 +1032,8 @@ static void launch_pcg_setup(ba_handle* h, double lambda, bool schur_diag, bool 
 #define SU_ARGS h->partL[h->lb].p, h->HccBc.p, bc_ptr(h), p6_ptr(h), h->partE.p, NPART, h->cs[h->cur].p, lambda,           \
                 schur_diag ? 1 : 0, h->Nc, h->fixed, h->Hccd.p, h->Minv.p, h->gvec.p, h->x.p, h->r.p, h->p.p, h->s.p,     \
                 h->z.p, h->camA[h->cur].p, h->partV.p, h->st.p, h->partGc.p
-  if (finalize) hipLaunchKernelGGL((k_pcg_setup<true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);
-  else          hipLaunchKernelGGL((k_pcg_setup<false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);
+  if (finalize) BA_LAUNCH((k_pcg_setup<true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);
+  else          BA_LAUNCH((k_pcg_setup<false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);
 #undef SU_ARGS
 }
 
@@ -983,7 +1054,7 @@ extern "C" int ba_residuals(ba_handle* h, int32_t loss, double f_scale, double* 
   if (int rc = allreduce(h, h->scal.p, 2)) return rc;
   HIPCHECK(hipMemcpyAsync(h->h_scal, h->scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (rdev) HIPCHECK(hipMemcpyAsync(r, rdev, 2 * (size_t)h->Nobs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHECK(hipStreamSynchronize(h->stream));
+  BA_SYNC(h);
   if (sse) *sse = h->h_scal[0];
   if (cost) *cost = 0.5 * h->h_scal[1];
   return BA_OK;
@@ -1008,15 +1079,15 @@ extern "C" int ba_linearize(ba_handle* h, int32_t loss, double f_scale, double* 
   if ((Hpp || bp) && h->Np) {          // per-point blocks back in the caller's point order
     HIPCHECK(h->rbuf.alloc(6 * (size_t)h->Np));
     if (Hpp) {
-      hipLaunchKernelGGL(k_unpermute_rows, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp[h->pb].p, h->slot.p, h->Np, 6, h->rbuf.p);
+      BA_LAUNCH(k_unpermute_rows, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp[h->pb].p, h->slot.p, h->Np, 6, h->rbuf.p);
       HIPCHECK(hipMemcpyAsync(Hpp, h->rbuf.p, 6 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
     if (bp) {
-      hipLaunchKernelGGL(k_unpermute_rows, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->bp[h->pb].p, h->slot.p, h->Np, 3, h->stage.p);
+      BA_LAUNCH(k_unpermute_rows, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->bp[h->pb].p, h->slot.p, h->Np, 3, h->stage.p);
       HIPCHECK(hipMemcpyAsync(bp, h->stage.p, 3 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     }
   }
-  HIPCHECK(hipStreamSynchronize(h->stream));
+  BA_SYNC(h);
   return BA_OK;
 }
 
@@ -1037,7 +1108,7 @@ extern "C" int ba_schur_rhs(ba_handle* h, double lambda, double* g) {
   if (set_device(h)) return BA_ERR_HIP;
   if (int rc = damped_system(h, lambda, true)) return rc;
   HIPCHECK(hipMemcpyAsync(g, h->gvec.p, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHECK(hipStreamSynchronize(h->stream));
+  BA_SYNC(h);
   return BA_OK;
 }
 
@@ -1049,20 +1120,20 @@ extern "C" int ba_schur_apply(ba_handle* h, double lambda, const double* v, doub
   HIPCHECK(hipMemcpyAsync(h->vin.p, v, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
   {
     Scope sc(h, BA_K_MISC);
-    hipLaunchKernelGGL(k_vtil, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->vin.p, h->cs[h->cur].p, h->Nc,
+    BA_LAUNCH(k_vtil, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->vin.p, h->cs[h->cur].p, h->Nc,
                        h->fixed, h->camA[h->cur].p);
-    hipLaunchKernelGGL(k_pcg_reset, dim3(1), dim3(64), 0, h->stream, h->st.p, h->partV.p, h->nblkV);
+    BA_LAUNCH(k_pcg_reset, dim3(1), dim3(64), 0, h->stream, h->st.p, h->partV.p, h->nblkV);
   }
   launch_pt_schur(h, h->lin_robust, 0, 0, -1.0, 1 << 30);        // y = Hppinv W^T v into the point table
   launch_cam_schur(h, h->lin_robust, false, false, 0, 0.0, 0);
   if (int rc = exchange_schur(h, false)) return rc;
   {
     Scope sc(h, BA_K_MISC);
-    hipLaunchKernelGGL(k_schur_combine, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->Hccd.p, h->vin.p, p6_ptr(h),
+    BA_LAUNCH(k_schur_combine, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->Hccd.p, h->vin.p, p6_ptr(h),
                        NPART, h->cs[h->cur].p, h->Nc, h->fixed, h->z.p);
   }
   HIPCHECK(hipMemcpyAsync(out, h->z.p, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHECK(hipStreamSynchronize(h->stream));
+  BA_SYNC(h);
   return BA_OK;
 }
 
@@ -1097,14 +1168,29 @@ static int eval_cost(ba_handle* h, int which, bool robust, double fscale, double
   launch_scalars(h, false);
   if (int rc = allreduce(h, h->scal.p, 2)) return rc;
   HIPCHECK(hipMemcpyAsync(h->h_scal, h->scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCHECK(hipStreamSynchronize(h->stream));
+  BA_SYNC(h);
   *sse = h->h_scal[0];
   *cost = 0.5 * h->h_scal[1];
   return BA_OK;
 }
 
+static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum);
 extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   if (!h || !opts || !sum) return fail(BA_ERR_INVALID, "null argument");
+  const int rc = solve_impl(h, opts, sum);
+  if (rc != BA_OK) {             // leave the handle usable: nothing queued, no per-solve mode left on
+    const std::string msg = g_err;
+    (void)hipStreamSynchronize(h->stream);
+    h->launch_err = hipSuccess;
+    if (h->profile) flush_profile(h);
+    h->profile = false;
+    h->jac_f32 = false;
+    h->linearized = false;
+    g_err = msg;
+  }
+  return rc;
+}
+static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   if (!h->have_params) return fail(BA_ERR_STATE, "ba_set_problem / ba_set_params first");
   if (opts->loss != BA_LOSS_LINEAR && opts->loss != BA_LOSS_HUBER) return fail(BA_ERR_INVALID, "unknown loss");
   if (!(opts->f_scale > 0) || opts->max_iters < 0 || opts->pcg_max_iters < 1 || !(opts->initial_lambda > 0))
@@ -1121,19 +1207,22 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   h->profile = opts->profile != 0;
   const double tol2 = opts->pcg_tol * opts->pcg_tol;
 
-  HIPCHECK(hipStreamSynchronize(h->stream));
+  BA_SYNC(h);
   const double t_begin = now_s();
   double sse = 0, cost = 0;
   if (int rc = eval_cost(h, h->cur, robust, fs, &sse, &cost)) return rc;
   if (!std::isfinite(cost)) return fail(BA_ERR_NUMERIC, "non-finite cost at the initial parameters");
   sum->initial_sse = sse;
   sum->initial_cost = cost;
-  if (h->Np == 0 || h->Nobs == 0) {       // nothing to adjust
+  // nothing to adjust.  Single rank only: a rank of a multi-rank job whose landmark shard is empty still has to
+  // join every collective of the loop below (with zero partials), or the other ranks wait for it forever.
+  if (h->world == 1 && (h->Np == 0 || h->Nobs == 0)) {
     sum->final_sse = sse; sum->final_cost = cost; sum->final_lambda = opts->initial_lambda;
     sum->seconds_total = now_s() - t_begin;
     h->profile = false;
     return BA_OK;
   }
+  const bool debug_poison = getenv("BA_DEBUG_POISON_TRIAL") != nullptr;     // tests: every trial cost comes out NaN
   double lambda = opts->initial_lambda, nu = 2.0;
   int it = 0, status = 0;
   bool need_linearize = true;      // a linearisation at the current parameters is needed before the next damped system
@@ -1168,12 +1257,12 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
         // bc is all-reduced (identical on every rank); bp is shard-local -> max over ranks
         {
           Scope sc(h, BA_K_MISC);
-          hipLaunchKernelGGL(k_max_partials, dim3(1), dim3(64), 0, h->stream, (const double*)h->partG[h->pb].p,
+          BA_LAUNCH(k_max_partials, dim3(1), dim3(64), 0, h->stream, (const double*)h->partG[h->pb].p,
                              h->Np > 0 ? h->nblkP + h->nblkL : 0, (const double*)h->partGc.p, h->nblkV, h->scal.p + 18);
         }
         if (int rc = allreduce(h, h->scal.p + 18, 1, true)) return rc;
         HIPCHECK(hipMemcpyAsync(h->h_gmax, h->scal.p + 18, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(hipStreamSynchronize(h->stream));
+        BA_SYNC(h);
         const double gmax = h->h_gmax[0];
         if (!std::isfinite(gmax)) return fail(BA_ERR_NUMERIC, "non-finite gradient at LM iteration %d", it);
         if (gmax <= opts->gtol) { status = 3; break; }
@@ -1198,7 +1287,7 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       launch_cam_schur(h, robust, false, true, kk, tol2, opts->pcg_min_iters);
       if (int rc = exchange_schur(h, false)) return rc;
       Scope sc(h, BA_K_PCG_UPDATE);
-      hipLaunchKernelGGL(k_pcg_step, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, kk, p6_ptr(h), NPART,
+      BA_LAUNCH(k_pcg_step, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, kk, p6_ptr(h), NPART,
                          (const double*)uy_ptr(h), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc,
                          h->fixed, tol2, opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA[h->cur].p,
                          h->partV.p, h->nblkV, h->st.p, h->d_flags, base, (const double*)h->verdict.p);
@@ -1225,7 +1314,7 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     // ---- step, trial point, gain-ratio scalars
     {
       Scope sc(h, BA_K_MISC);
-      hipLaunchKernelGGL(k_cam_update, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->cams[h->cur].p, h->x.p, h->r.p,
+      BA_LAUNCH(k_cam_update, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->cams[h->cur].p, h->x.p, h->r.p,
                          h->HccBc.p, bc_ptr(h), h->cs[h->cur].p, Nc, h->fixed, h->cams[1 - h->cur].p, h->cs[1 - h->cur].p,
                          h->camA[h->cur].p, h->camA[1 - h->cur].p, h->partC.p);
     }
@@ -1242,13 +1331,14 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     } else {
       launch_residual(h, 1 - h->cur, robust, fs, nullptr);
     }
+    if (debug_poison) BA_LAUNCH(k_poison, dim3(1), dim3(64), 0, h->stream, h->partR.p);
     const long long seq = ++h->step_seq;
     launch_scalars(h, true, k, tol2, opts->pcg_min_iters, seq, cost, lambda);
     if (h->world > 1) {
       if (int rc = allreduce(h, h->scal.p, 6)) return rc;
       {
         Scope sc(h, BA_K_MISC);
-        hipLaunchKernelGGL(k_decide, dim3(1), dim3(64), 0, h->stream, h->scal.p, cost, lambda);
+        BA_LAUNCH(k_decide, dim3(1), dim3(64), 0, h->stream, h->scal.p, cost, lambda);
       }
       HIPCHECK(hipMemcpyAsync(h->h_scal, h->scal.p, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIPCHECK(hipEventRecord(h->ev_decide, h->stream));
@@ -1281,6 +1371,9 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       need_linearize = true;
       if (dcost <= opts->ftol * cost) { status = 1; stop = true; }
     } else {
+      // a trial cost that is not finite even at the largest damping the loop allows cannot be stepped away from
+      if (!std::isfinite(cost_new) && lambda >= 1e12)
+        return fail(BA_ERR_NUMERIC, "non-finite cost at the trial point of LM iteration %d with the damping at its cap", it);
       lambda = std::min(lambda * nu, 1e12);
       nu *= 2.0;
     }
@@ -1288,7 +1381,7 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     sum->seconds_update += now_s() - t2;
     if (stop) break;
   }
-  HIPCHECK(hipStreamSynchronize(h->stream));
+  BA_SYNC(h);
   sum->seconds_total = now_s() - t_begin;
   sum->iterations = it;
   sum->status = status;
@@ -1314,7 +1407,7 @@ extern "C" int ba_time_kernel(ba_handle* h, int slot, int reps, double* mean_us)
   launch_lin_pt(h, h->cur, h->pb, robust, h->lin_fscale, 1e-4);
   h->linearized = true;
   if (int rc = damped_system(h, 1e-4, true)) return rc;
-  hipLaunchKernelGGL(k_pcg_reset, dim3(1), dim3(64), 0, h->stream, h->st.p, h->partV.p, h->nblkV);
+  BA_LAUNCH(k_pcg_reset, dim3(1), dim3(64), 0, h->stream, h->st.p, h->partV.p, h->nblkV);
   hipEvent_t e0, e1;
   HIPCHECK(hipEventCreate(&e0));
   HIPCHECK(hipEventCreate(&e1));
@@ -1350,7 +1443,7 @@ extern "C" int ba_time_kernel(ba_handle* h, int slot, int reps, double* mean_us)
 extern "C" int ba_debug_stamps(ba_handle* h, int kind, unsigned long long* out, int n_blocks) {
   if (!h || !out || kind < 0 || kind > 2 || n_blocks < 1 || n_blocks > STAMP_BLOCKS) return fail(BA_ERR_INVALID, "bad argument");
   if (set_device(h)) return BA_ERR_HIP;
-  HIPCHECK(hipStreamSynchronize(h->stream));
+  BA_SYNC(h);
   HIPCHECK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)n_blocks * 8 * sizeof(unsigned long long),
                                (size_t)kind * STAMP_BLOCKS * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return BA_OK;

@@ -851,6 +851,42 @@ k_point_invert(const double* __restrict__ Hpp, const double* __restrict__ bp, do
 // MODE 0 (PCG): y[p] = Hppinv u into the point table, partA[block] = sum u.y; early exit when done.
 // MODE 1 (back substitution): dp = -(y0 + Hppinv u), trial point = X + dp, partB[block][4] =
 //         bp.dp, sum Dp dp^2, |dp|^2, |X|^2.
+// Head of a PCG iteration, run by wave 0 of every point-pass workgroup (all 64 lanes): sum the vector kernel's
+// partials and decide whether iteration kit runs.  Workgroup 0 also (i) leaves the verdict word for the iteration's
+// other kernels, (ii) on the first probe behind a fresh linearisation folds max |gradient| from the partials of the
+// point half (partG) and of k_pcg_setup (partGc) into host-mapped memory -- the reference's gtol test costs no kernel
+// of its own -- and (iii) tells the host NOW whether this iteration runs (it then queues the next one behind it) or
+// PCG is over (it queues the step kernels instead).
+__device__ inline bool pcg_probe(int kit, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV,
+                                 double tol2, int min_iters, long long* __restrict__ host_flag, long long flag_base,
+                                 double* __restrict__ verdict, const double* __restrict__ partG, int nG,
+                                 const double* __restrict__ partGc, int nGc, double* __restrict__ gmax_out) {
+  double g, z;
+  const bool fin = pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z);
+  double gmx = 0.0;
+  if (gmax_out && blockIdx.x == 0) {
+    for (int b = threadIdx.x; b < nG; b += 64) gmx = nanmax(gmx, partG[b]);
+    for (int b = threadIdx.x; b < nGc; b += 64) gmx = nanmax(gmx, partGc[b]);
+    gmx = wave_nanmax(gmx);
+  }
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (gmax_out) gmax_out[0] = gmx;      // ordered ahead of the sequence word by publish_flag's release
+    double* vd = verdict + 4 * (kit & 1);
+    vd[0] = g; vd[1] = z; vd[2] = fin ? 1.0 : 0.0;
+    const PcgState& s = st[kit & 1];
+    publish_flag(host_flag, flag_base + kit + 1, fin ? (long long)(s.done ? s.iters : kit) + 1 : 0);
+  }
+  return fin;
+}
+// The probe alone: a rank whose landmark shard is empty has no point pass to launch, but its host loop and the
+// other kernels of the iteration still need the verdict (multi-rank jobs).  partA has no entries then.
+__global__ void __launch_bounds__(64)
+k_pcg_probe(int kit, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2, int min_iters,
+            long long* __restrict__ host_flag, long long flag_base, double* __restrict__ verdict,
+            const double* __restrict__ partGc, int nGc, double* __restrict__ gmax_out) {
+  (void)pcg_probe(kit, st, partV, nblkV, tol2, min_iters, host_flag, flag_base, verdict, nullptr, 0, partGc, nGc, gmax_out);
+}
+
 template <bool ROBUST, int MODE, bool ALL_LDS, int LANES, typename JT>
 __device__ __forceinline__ void
 pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,
@@ -883,29 +919,8 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
     // the table-fill barrier anyway)
     __shared__ int s_fin;
     if (threadIdx.x < 64) {
-      double g, z;
-      const bool fin = pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z);
-      // first probe behind a fresh linearisation: max |gradient| from the partials of the point half (partG) and of
-      // k_pcg_setup (partGc), into host-mapped memory -- the reference's gtol test costs no kernel of its own
-      double gmx = 0.0;
-      if (gmax_out && blockIdx.x == 0) {
-        for (int b = threadIdx.x; b < nG; b += 64) gmx = nanmax(gmx, partG[b]);
-        for (int b = threadIdx.x; b < nGc; b += 64) gmx = nanmax(gmx, partGc[b]);
-        gmx = wave_nanmax(gmx);
-      }
-      if (threadIdx.x == 0) {
-        s_fin = fin ? 1 : 0;
-        // first kernel of iteration kit: workgroup 0 (whichever kind of track it works on) leaves the verdict
-        // word for the iteration's other kernels and tells the host now whether this iteration runs (it then
-        // queues the next one behind it) or PCG is over (it queues the step kernels instead)
-        if (blockIdx.x == 0) {
-          if (gmax_out) gmax_out[0] = gmx;      // ordered ahead of the sequence word by publish_flag's release
-          double* vd = verdict + 4 * (kit & 1);
-          vd[0] = g; vd[1] = z; vd[2] = fin ? 1.0 : 0.0;
-          const PcgState& s = st[kit & 1];
-          publish_flag(host_flag, flag_base + kit + 1, fin ? (long long)(s.done ? s.iters : kit) + 1 : 0);
-        }
-      }
+      const bool fin = pcg_probe(kit, st, partV, nblkV, tol2, min_iters, host_flag, flag_base, verdict, partG, nG, partGc, nGc, gmax_out);
+      if (threadIdx.x == 0) s_fin = fin ? 1 : 0;
     }
     __syncthreads();
     if (s_fin) return;
@@ -1526,6 +1541,11 @@ k_max_partials(const double* __restrict__ a, int na, const double* __restrict__ 
   for (int i = threadIdx.x; i < nb; i += 64) m = nanmax(m, b[i]);
   m = wave_nanmax(m);
   if (threadIdx.x == 0) out[0] = m;
+}
+
+// test hook (BA_DEBUG_POISON_TRIAL): makes the trial cost of every LM step non-finite
+__global__ void k_poison(double* __restrict__ partR) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { partR[0] = __builtin_nan(""); partR[1] = __builtin_nan(""); }
 }
 
 // Not-converged PCG state for the test / bench hooks that run one pass in isolation.

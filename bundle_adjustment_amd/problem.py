@@ -177,7 +177,9 @@ def flatten_map_window(gmap, local_kf_ids, camera_matrix):
 def shard_by_landmark(problem: BAProblem, n_shards: int):
     """Split the points into ``n_shards`` contiguous index ranges balanced by
     observation count.  Returns ``[(p_begin, p_end)]``; shard g owns those points and
-    every observation of them; cameras are replicated."""
+    every observation of them; cameras are replicated.  No shard is
+    empty when ``n_pts >= n_shards``; with fewer points than shards the trailing shards are
+    empty (the library copes: an empty rank still joins every collective)."""
     npt = problem.n_pts
     counts = np.bincount(problem.pt_idx, minlength=npt).astype(np.int64)
     cum = np.concatenate([[0], np.cumsum(counts)])
@@ -188,6 +190,13 @@ def shard_by_landmark(problem: BAProblem, n_shards: int):
         b = int(np.searchsorted(cum, target, side='left'))
         bounds.append(min(max(b, bounds[-1]), npt))
     bounds.append(npt)
+    if npt >= n_shards:
+        # never an empty shard while there are at least as many points as shards (a few very long tracks can pull
+        # two cuts onto the same point): every shard keeps one point or more
+        for g in range(1, n_shards):
+            bounds[g] = max(bounds[g], bounds[g - 1] + 1)
+        for g in range(n_shards - 1, 0, -1):
+            bounds[g] = min(bounds[g], npt - (n_shards - g))
     return [(bounds[g], bounds[g + 1]) for g in range(n_shards)]
 
 

@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--max-nfev", type=int, default=400)
     ap.add_argument("--lsmr-tol", type=float, default=1e-10)
     ap.add_argument("--skip-fd-check", action="store_true")
+    ap.add_argument("--chunk", type=int, default=200, help="evaluations per scipy call; the fixture is rewritten after each")
+    ap.add_argument("--stall", type=float, default=2e-8, help="stop when the RMSE moved less than this over each of the last two chunks")
     ap.add_argument("--warm-start", action="store_true",
                     help="first run the same scipy call with loss='linear' to convergence and start the requested loss there "
                          "(scipy's Huber TRF crawls for hundreds of iterations from a 9 px start; the minimum pinned is the same)")
@@ -129,23 +131,38 @@ def main():
                             tr_options=dict(atol=args.lsmr_tol, btol=args.lsmr_tol))
         print(f"warm start: linear-loss solution after {pre.nfev} evaluations, sse {2 * pre.cost:.9f}", flush=True)
         x_start = pre.x
-    res = least_squares(logged, x_start, jac=jac, method="trf", tr_solver="lsmr", x_scale="jac", loss=args.loss, f_scale=1.0,
-                        xtol=1e-15, ftol=1e-14, gtol=1e-11, max_nfev=args.max_nfev,
-                        tr_options=dict(atol=args.lsmr_tol, btol=args.lsmr_tol))
-    f_ref = ref_fun(res.x)                       # the reference's own arithmetic at the solution
-    sse = float(f_ref @ f_ref)
-    rmse = float(np.sqrt(sse / p.n_obs))
-    cost = 0.5 * float(o.huber_rho(f_ref ** 2)[0].sum()) if args.loss == "huber" else 0.5 * sse
-    print(f"done: status {res.status} nfev {res.nfev} njev {res.njev} scipy cost {res.cost:.12f} "
-          f"reference-evaluated cost {cost:.12f} sse {sse:.9f} rmse {rmse:.9f} optimality {res.optimality:.3e} "
-          f"({time.time() - t_start:.0f} s)", flush=True)
+    # the requested loss, in chunks of --chunk evaluations: the fixture is (re)written after every chunk, each chunk
+    # restarts scipy from the previous chunk's solution (scipy 1.15 has no callback; a restart only resets the trust
+    # radius), so a long crawl can be stopped at any time and still leave a usable pin with its history
     name = f"conv_{args.config.lower()}_{args.loss}.npz"
-    np.savez_compressed(os.path.join(HERE, name), config=np.array(args.config), seed=args.seed, loss=np.array(args.loss),
-                        fun=np.array(args.fun), n_cams=p.n_cams, n_pts=p.n_pts, n_obs=p.n_obs,
-                        problem_sha256=np.array(problem_checksum(p)), sse0=float(f0_ref @ f0_ref),
-                        res_cost=cost, res_cost_scipy=float(res.cost), res_sse=sse, res_rmse=rmse,
-                        res_optimality=float(res.optimality), res_nfev=int(res.nfev), res_status=int(res.status),
-                        jac_fd_max_abs_diff=fd_err, lsmr_tol=args.lsmr_tol, warm_start=bool(args.warm_start))
+    history = []            # (cumulative nfev, rmse by the reference's arithmetic) after each chunk
+    x_cur, total = x_start, 0
+    while total < args.max_nfev:
+        res = least_squares(logged, x_cur, jac=jac, method="trf", tr_solver="lsmr", x_scale="jac", loss=args.loss, f_scale=1.0,
+                            xtol=1e-15, ftol=1e-14, gtol=1e-11, max_nfev=min(args.chunk, args.max_nfev - total),
+                            tr_options=dict(atol=args.lsmr_tol, btol=args.lsmr_tol))
+        total += int(res.nfev)
+        x_cur = res.x
+        f_ref = ref_fun(res.x)                       # the reference's own arithmetic at the solution
+        sse = float(f_ref @ f_ref)
+        rmse = float(np.sqrt(sse / p.n_obs))
+        cost = 0.5 * float(o.huber_rho(f_ref ** 2)[0].sum()) if args.loss == "huber" else 0.5 * sse
+        history.append((total, rmse))
+        print(f"chunk done: status {res.status} nfev {total} scipy cost {res.cost:.12f} "
+              f"reference-evaluated cost {cost:.12f} sse {sse:.9f} rmse {rmse:.9f} optimality {res.optimality:.3e} "
+              f"({time.time() - t_start:.0f} s)", flush=True)
+        np.savez_compressed(os.path.join(HERE, name), config=np.array(args.config), seed=args.seed, loss=np.array(args.loss),
+                            fun=np.array(args.fun), n_cams=p.n_cams, n_pts=p.n_pts, n_obs=p.n_obs,
+                            problem_sha256=np.array(problem_checksum(p)), sse0=float(f0_ref @ f0_ref),
+                            res_cost=cost, res_cost_scipy=float(res.cost), res_sse=sse, res_rmse=rmse,
+                            res_optimality=float(res.optimality), res_nfev=total, res_status=int(res.status),
+                            jac_fd_max_abs_diff=fd_err, lsmr_tol=args.lsmr_tol, warm_start=bool(args.warm_start),
+                            rmse_history=np.array(history, dtype=np.float64))
+        if res.status in (1, 2, 3, 4):               # gtol / ftol / xtol: scipy itself says converged
+            break
+        if len(history) >= 3 and abs(history[-1][1] - history[-2][1]) < args.stall and abs(history[-2][1] - history[-3][1]) < args.stall:
+            print(f"RMSE moved less than {args.stall:g} px over each of the last two chunks: stopping", flush=True)
+            break
     print("wrote", name)
 
 

@@ -1,0 +1,82 @@
+"""GPU: the library's failure codes ("failure detection"): a kernel launch the runtime refuses
+comes back as BA_ERR_HIP with the kernel's name instead of a 20 s spin; non-finite costs come back as
+BA_ERR_NUMERIC, at the initial parameters and mid-solve; a failed call leaves the handle usable."""
+import numpy as np
+import pytest
+
+from bundle_adjustment_amd import hip_backend
+from bundle_adjustment_amd.synthetic import make_problem
+
+pytestmark = pytest.mark.gpu
+KW = dict(loss="huber", max_iters=30, ftol=1e-10, xtol=1e-10, gtol=1e-12)
+
+
+def test_refused_kernel_launch_is_reported_with_its_name(monkeypatch):
+    """Debug knob BA_DEBUG_LDS_EXTRA asks the point passes for more dynamic LDS than the device allows."""
+    import time
+    p = make_problem(8, 400, 4, seed=0)
+    monkeypatch.setenv("BA_DEBUG_LDS_EXTRA", "400000")
+    s = hip_backend.Solver(0)
+    try:
+        s.set_problem(p)
+        t0 = time.perf_counter()
+        with pytest.raises(hip_backend.BAHipError) as ei:
+            s.solve(**KW)
+        assert time.perf_counter() - t0 < 5.0                    # not the 20 s wait for a word nobody will publish
+        msg = str(ei.value)
+        assert "launch of kernel" in msg and "k_pt_schur" in msg, msg
+        assert "error -2" in msg                                 # BA_ERR_HIP
+        # the handle survives: the residual entry point (no point pass) still answers
+        r, sse, cost = s.residuals("huber")
+        assert np.isfinite(sse)
+    finally:
+        s.close()
+    monkeypatch.delenv("BA_DEBUG_LDS_EXTRA")
+    with hip_backend.Solver(0) as s2:
+        s2.set_problem(p)
+        out = s2.solve(**KW)
+        assert out["final_cost"] < out["initial_cost"]
+
+
+def test_nan_pixel_is_a_numeric_error_at_the_initial_cost():
+    p = make_problem(8, 400, 4, seed=1)
+    uv = p.uv.copy()
+    uv[5, 0] = np.nan
+    q = type(p)(p.cams, p.pts, p.cam_idx, p.pt_idx, uv, p.K4, 0)
+    with hip_backend.Solver(0) as s:
+        s.set_problem(q)
+        with pytest.raises(hip_backend.BAHipError, match="non-finite cost at the initial parameters"):
+            s.solve(**KW)
+        s.set_problem(p)                                         # and the handle is good for the next problem
+        assert s.solve(**KW)["final_cost"] > 0
+
+
+def test_trial_cost_that_never_becomes_finite_is_a_numeric_error(monkeypatch):
+    """Debug knob BA_DEBUG_POISON_TRIAL turns every trial cost into NaN: each step is rejected, the damping climbs to
+    its cap, and the solve must then stop with BA_ERR_NUMERIC instead of burning max_iters."""
+    p = make_problem(8, 400, 4, seed=2)
+    with hip_backend.Solver(0) as s:
+        s.set_problem(p)
+        monkeypatch.setenv("BA_DEBUG_POISON_TRIAL", "1")
+        with pytest.raises(hip_backend.BAHipError, match="non-finite cost at the trial point"):
+            s.solve(**dict(KW, max_iters=50, xtol=0.0))      # (with xtol on, the shrinking rejected steps would stop it first)
+        monkeypatch.delenv("BA_DEBUG_POISON_TRIAL")
+        cams, pts = s.get_params()
+        assert np.array_equal(cams, p.cams) and np.array_equal(pts, p.pts)      # no rejected step leaked into the parameters
+        out = s.solve(**KW)
+        assert out["final_cost"] < out["initial_cost"]
+
+
+def test_rejected_set_problem_keeps_the_previous_problem():
+    """Argument errors are caught before anything is touched (the C ABI itself; the Python wrapper's own validate()
+    would stop this earlier): the previous problem is still there and solvable."""
+    p = make_problem(6, 200, 3, seed=3)
+    with hip_backend.Solver(0) as s:
+        s.set_problem(p)
+        bad = p.cam_idx.copy()
+        bad[7] = 99
+        rc = s._lib.ba_set_problem(s._h, p.n_cams, p.n_pts, p.n_obs, bad.ctypes.data_as(hip_backend._IP),
+                                   p.pt_idx.ctypes.data_as(hip_backend._IP), hip_backend._dp(p.uv), hip_backend._dp(p.K4), 0)
+        assert rc == -1 and b"out of range" in s._lib.ba_last_error()          # BA_ERR_INVALID
+        out = s.solve(**KW)
+        assert out["final_cost"] < out["initial_cost"]

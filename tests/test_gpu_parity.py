@@ -208,7 +208,9 @@ def test_c2_solve_and_properties(solver):
     solver.set_problem(p)
     out = solver.solve(loss="linear", max_iters=30, ftol=1e-10, xtol=1e-12, gtol=0.0)
     rmse = np.sqrt(out["final_sse"] / p.n_obs)
-    assert rmse < 0.75 and out["final_sse"] < out["initial_sse"]
+    # 30 iterations at ftol 1e-10 already sit on the scipy path's converged value (the 1e-6 px pin with tight
+    # tolerances is tests/test_gpu_converged.py)
+    assert abs(rmse - float(load_golden("conv_c2_linear")["res_rmse"])) <= 1e-5 and out["final_sse"] < out["initial_sse"]
     cams1, pts1 = solver.get_params()
     # determinism: same inputs -> bitwise same outputs
     solver.set_problem(p)
@@ -237,7 +239,10 @@ def test_headline_size_properties(solver):
     out = solver.solve(loss="huber", max_iters=25, ftol=1e-8, xtol=1e-10, gtol=0.0)
     assert out["final_cost"] < out["initial_cost"]
     rmse = np.sqrt(out["final_sse"] / p.n_obs)
-    assert rmse < 0.72, rmse            # noise floor: 0.5 px per coordinate -> ~0.707 px per observation
+    # Huber minimiser at C3: plain-SSE RMSE a little above the linear-loss minimum the scipy path converges to
+    # (golden conv_c3_linear, 0.651152 px); the 1e-6 px pins are in tests/test_gpu_converged.py
+    lin = float(load_golden("conv_c3_linear")["res_rmse"])
+    assert lin <= rmse <= lin + 1e-3, (rmse, lin)
     r2, sse2, _ = solver.residuals("huber")
     assert abs(sse2 - out["final_sse"]) <= 1e-9 * sse2
 

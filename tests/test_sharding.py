@@ -32,6 +32,41 @@ def test_shards_partition_points_and_observations():
         assert max(counts) - min(counts) <= 2 * 4 + 4          # balanced by observation count
 
 
+def test_skewed_tracks_never_give_an_empty_shard():
+    """A few very long tracks can pull two cuts onto the same point; with at least as many points as shards every
+    shard must still own a point (an empty rank is legal for the library but wastes a GPU)."""
+    from bundle_adjustment_amd.problem import BAProblem
+    K4 = np.array([500.0, 500.0, 320.0, 240.0])
+    for lens, world in (([1, 1, 10], 2), ([40, 1, 1, 1], 4), ([1, 1, 1, 90], 3), ([5] * 8, 8), ([1, 200], 2)):
+        npt = len(lens)
+        pt_idx = np.repeat(np.arange(npt, dtype=np.int32), lens)
+        cam_idx = np.concatenate([np.arange(n, dtype=np.int32) % 3 for n in lens])
+        p = BAProblem(np.zeros((3, 6)), np.zeros((npt, 3)), cam_idx, pt_idx, np.zeros((pt_idx.size, 2)), K4, 0)
+        ranges = shard_by_landmark(p, world)
+        assert ranges[0][0] == 0 and ranges[-1][1] == npt
+        assert all(e > b for b, e in ranges), (lens, world, ranges)
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    # fewer points than shards: the trailing shards are empty, the leading ones keep one point each
+    p = BAProblem(np.zeros((3, 6)), np.zeros((2, 3)), np.array([0, 1], dtype=np.int32), np.array([0, 1], dtype=np.int32),
+                  np.zeros((2, 2)), K4, 0)
+    ranges = shard_by_landmark(p, 4)
+    assert ranges[0][0] == 0 and ranges[-1][1] == 2 and sum(e - b for b, e in ranges) == 2
+
+
+def test_run_refuses_fewer_landmarks_than_ranks():
+    """SPMD run(): a window with fewer landmarks than ranks raises the same error on every rank before any collective."""
+    from bundle_adjustment_amd import BundleAdjuster
+    from bundle_adjustment_amd.synthetic import problem_to_map
+    from tests.fake_solver import GlooOracleSolver
+    p = make_problem(3, 2, 2, seed=0)
+    K = np.array([[p.K4[0], 0, p.K4[2]], [0, p.K4[1], p.K4[3]], [0, 0, 1.0]])
+    ba = BundleAdjuster(K, window_size=p.n_cams, comm=(0, 4, b"x" * 128))
+    ba._solver = GlooOracleSolver()
+    ba._solver.comm_init(0, 4, b"")
+    with pytest.raises(ValueError, match="cannot be sharded"):
+        ba.run(problem_to_map(p))
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
