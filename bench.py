@@ -158,34 +158,42 @@ def main():
     ndev = hip_backend.device_count()
     dev = (local_rank % ndev) if world > 1 else 0
     solver = hip_backend.Solver(dev)
-    comm_note = "none (single rank)"
+    comm_note, transport, ranks_up = "none (single rank)", "none", 1
     if world > 1:
         import torch
-
-        def connect(s):
-            uid = [hip_backend.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            s.comm_init(rank, world, uid[0])
-            s.set_problem(shard)
-            s.residuals("linear", want_vector=False)        # first collective: proves the transport works
-        comm_note = os.environ.get("BA_COMM", "rccl")
-        ok, err = 1, ""
-        try:
-            connect(solver)
-        except hip_backend.BAHipError as e:
-            ok, err = 0, str(e)
+        # Transport: RCCL over xGMI unless BA_COMM=shm was asked for (the host-staged test transport that lets several
+        # ranks share one GPU).  There is NO fallback: if RCCL cannot be brought up on every rank the run exits non-zero
+        # -- a scaling line over the wrong transport would be worse than none.
+        transport = "shm" if os.environ.get("BA_COMM") == "shm" else "rccl"
+        ok, err, uid = 1, "", None
+        if rank == 0:                         # rank 0 ALWAYS reaches the broadcast, with or without an id
+            try:
+                uid = hip_backend.comm_unique_id()
+            except hip_backend.BAHipError as e:
+                ok, err = 0, str(e)
+        box = [(ok, uid)]
+        dist.broadcast_object_list(box, src=0)
+        ok0, uid = box[0]
+        if ok0:
+            try:
+                solver.comm_init(rank, world, uid)
+                solver.set_problem(shard)
+                solver.residuals("linear", want_vector=False)        # first collective: proves the transport works
+            except hip_backend.BAHipError as e:
+                ok, err = 0, str(e)
+        else:
+            ok = 0
         flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            if comm_note == "shm":
-                raise SystemExit(f"shared-memory transport failed: {err}")
-            # RCCL could not be brought up on some rank: every rank moves to the host-staged
-            # shared-memory transport (slow; labelled in the output) rather than report nothing
-            os.environ["BA_COMM"] = "shm"
-            solver.close()
-            solver = hip_backend.Solver(dev)
-            connect(solver)
-            comm_note = "shm FALLBACK (RCCL failed: %s)" % (err or "on another rank")
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM)                  # how many ranks joined the communicator
+        ranks_up = int(flag.item())
+        if ranks_up != world:
+            if rank == 0:
+                print(json.dumps({"error": f"{transport} communicator came up on {ranks_up} of {world} ranks", "detail": err,
+                                  "n_gpus": world}), flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+            raise SystemExit(3)
+        comm_note = f"{transport}: communicator of {world} ranks initialised on {ranks_up} ranks, first all-reduce done"
     else:
         solver.set_problem(shard)
 
@@ -269,6 +277,8 @@ def main():
             "config": {"workload": f"{args.config}: {prob.n_cams} cams / {prob.n_pts} pts / {n_obs_total} obs, "
                                    f"loss={args.loss}, LM+Schur+PCG(tol {args.pcg_tol})",
                        "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU", "comm": comm_note,
+                       "world": world, "transport": transport, "ranks_in_communicator": ranks_up,
+                       "devices_visible": ndev, "device_of_rank0": dev,
                        "final_rmse_px": round(rmse, 6), "initial_rmse_px": round(float(np.sqrt(out['initial_sse'] / n_obs_total)), 6),
                        "pcg_iterations_per_lm": round(out["pcg_iterations"] / max(steps_done, 1), 2),
                        "accepted_steps": out["accepted"],

@@ -31,14 +31,14 @@ import numpy as np
 from . import hip_backend
 from .map_structures import Map
 from .parameters import DEBUG_DIRS
-from .problem import BAProblem, extract_shard, flatten_map_window, gather_window, shard_by_landmark
+from .problem import BAProblem, WindowCache, extract_shard, flatten_map_window, gather_window, shard_by_landmark
 from .rotations import matrices_to_rvecs
 
 
 class BundleAdjuster:
     def __init__(self, camera_matrix, window_size=5, *, device_id=0, loss='huber', f_scale=1.0, ftol=1e-5,
                  xtol=1e-5, gtol=1e-8, max_iters=50, pcg_tol=0.1, pcg_max_iters=200, preconditioner='schur_jacobi',
-                 jacobian='f64', comm=None, sparsity_plot_hook=None, verbose=0):
+                 jacobian='f64', comm=None, sparsity_plot_hook=None, verbose=0, reuse_window=True):
         self.camera_matrix = camera_matrix
         self.window_size = window_size
         self.device_id = device_id
@@ -49,6 +49,11 @@ class BundleAdjuster:
         self.sparsity_plot_hook = sparsity_plot_hook
         self.last_summary = None
         self._solver = None
+        # what survives between consecutive run() calls (src/pipeline.py:99 calls run after every keyframe): the
+        # flattened window (problem.WindowCache) and, while its observation structure is unchanged, the problem the
+        # solver already holds on the device
+        self._window = WindowCache() if reuse_window else None
+        self._uploaded_token = None
 
     # -- device -------------------------------------------------------------------------
     def _get_solver(self):
@@ -63,6 +68,7 @@ class BundleAdjuster:
         if self._solver is not None:
             self._solver.close()
             self._solver = None
+        self._uploaded_token = None
 
     # -- reference-compatible helpers -----------------------------------------------------
     def _cost_function(self, params, fixed_kf_pose, fixed_kf_id, adjustable_kf_ids, map_point_ids, observations,
@@ -91,6 +97,7 @@ class BundleAdjuster:
                          np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]]), 0)
         s = self._get_solver()
         s.set_problem(prob)
+        self._uploaded_token = None               # the solver no longer holds run()'s window
         r, _, _ = s.residuals('linear')
         return r.ravel()
 
@@ -135,9 +142,17 @@ class BundleAdjuster:
         for i, kf_id in enumerate(adjustable_kf_ids):
             keyframes[kf_id].R = np.array(rotations[i], dtype=np.float64).reshape(3, 3)
             keyframes[kf_id].t = tvecs[i].reshape(3, 1).copy()
-        # like the reference (:239-240) every position is a (3,1) view into the one result array
-        for mp_id, pos in zip(local_map_point_ids, pts.reshape(-1, 3, 1)):
-            map_points[mp_id].position = pos
+        # Points: one native call stores each row into the landmark's existing (3,1) float64 position array, in place
+        # (csrc/mapwalk.c scatter_positions; no Python object per landmark).  Landmarks whose position is anything else
+        # get, like every landmark in the reference (:239-240), a fresh (3,1) view into the result array.
+        from . import _mapwalk
+        ids = np.ascontiguousarray(local_map_point_ids, dtype=np.int64)
+        pts = np.ascontiguousarray(pts)
+        todo = _mapwalk.scatter_positions(map_points, ids, pts)
+        if todo:
+            views = pts.reshape(-1, 3, 1)
+            for i in todo:
+                map_points[int(ids[i])].position = views[i]
 
     # -- the solve step -------------------------------------------------------------------
     def run(self, gmap: Map):
@@ -154,27 +169,40 @@ class BundleAdjuster:
             print("    -> LBA Skipped: No adjustable keyframes.")
             return
         # array-level form of _gather_local_data + the parameter packing of :157-162
-        prob, local_map_point_ids = flatten_map_window(gmap, local_kf_ids, self.camera_matrix)
-        if not local_map_point_ids:
+        if self._window is not None:
+            prob, local_map_point_ids, token = self._window.flatten(gmap, local_kf_ids, self.camera_matrix)
+        else:
+            prob, ids_list = flatten_map_window(gmap, local_kf_ids, self.camera_matrix)
+            local_map_point_ids, token = np.asarray(ids_list, dtype=np.int64), None
+        if len(local_map_point_ids) == 0:
             print("    -> LBA Skipped: No points in the local window.")
             return
 
         if self.sparsity_plot_hook is not None:
             _, observations, _ = self._gather_local_data(gmap, local_kf_ids)
             self.sparsity_plot_hook(self._prepare_sparsity_matrix(len(adjustable_kf_ids), len(local_map_point_ids),
-                                                                  adjustable_kf_ids, local_map_point_ids, observations),
+                                                                  adjustable_kf_ids, local_map_point_ids.tolist(), observations),
                                     fixed_kf_id, local_kf_ids[-1])
         solver = self._get_solver()
         world = self.comm[1] if self.comm is not None else 1
+        # same observation structure as the problem the solver already holds (a repeated run on an unchanged window,
+        # e.g. the final global BA after the last sliding-window one): parameters only, no re-sort, no re-upload
+        same_structure = token is not None and token == self._uploaded_token
         if world > 1:                          # this rank's landmark block; all cameras
             if prob.n_pts < world:             # (the same on every rank: nobody enters a collective)
                 raise ValueError(f"{prob.n_pts} landmarks in the window cannot be sharded over {world} ranks; "
                                  f"run this window on a single rank")
             p_begin, p_end = shard_by_landmark(prob, world)[self.comm[0]]
-            shard, _ = extract_shard(prob, p_begin, p_end)
-            solver.set_problem(shard)
+            if same_structure:
+                solver.set_params(prob.cams, prob.pts[p_begin:p_end])
+            else:
+                shard, _ = extract_shard(prob, p_begin, p_end)
+                solver.set_problem(shard)
+        elif same_structure:
+            solver.set_params(prob.cams, prob.pts)
         else:
             solver.set_problem(prob)
+        self._uploaded_token = token
         summary = solver.solve(**self.solver_options)          # costs / verdicts are global on every rank
         self.last_summary = summary
         initial_cost, final_cost = summary["initial_sse"], summary["final_sse"]     # plain SSE (:165, :176)

@@ -137,7 +137,6 @@ struct ba_handle {
   DBuf<double> partR, partL[2], part6, partE, partA, partB, partC, partV;
   DBuf<double> partG[2], partGc;   // per-workgroup max |bp| (point half, double-buffered like it) and max |bc| (k_pcg_setup): the gtol test
   int lb = 0;                  // which c_w / partL buffer holds the current linearisation
-  hipEvent_t ev_decide = nullptr;
   // PCG vectors, comm buffers (multi-rank), scalars
   DBuf<double> gvec, x, r, p, s, z, vin, scal, rbuf, gather;
   DBuf<PcgState> st;
@@ -150,7 +149,6 @@ struct ba_handle {
   // pinned host mirror for scalars
   double* h_scal = nullptr;
   double* d_scal_host = nullptr;   // device-side address of h_scal (host-mapped, coherent)
-  double* h_gmax = nullptr;
   long long* h_flags = nullptr;    // host-mapped progress words: [0..1] PCG verdicts, [2..3] step scalars
   long long* d_flags = nullptr;
   long long flag_base = 1, step_seq = 1;
@@ -225,10 +223,8 @@ static int create_impl(ba_handle* h, int device_id) {
   HIPCHECK(hipDeviceGetAttribute(&h->n_cu, hipDeviceAttributeMultiprocessorCount, device_id));
   if (h->n_cu < 1) h->n_cu = 1;
   HIPCHECK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  HIPCHECK(hipEventCreateWithFlags(&h->ev_decide, hipEventDisableTiming));
   HIPCHECK(hipHostMalloc((void**)&h->h_scal, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
   HIPCHECK(hipHostGetDevicePointer((void**)&h->d_scal_host, h->h_scal, 0));
-  HIPCHECK(hipHostMalloc((void**)&h->h_gmax, 8 * sizeof(double)));
   HIPCHECK(hipHostMalloc((void**)&h->h_flags, 8 * sizeof(long long), hipHostMallocMapped | hipHostMallocCoherent));
   memset(h->h_flags, 0, 8 * sizeof(long long));
   HIPCHECK(hipHostGetDevicePointer((void**)&h->d_flags, h->h_flags, 0));
@@ -278,7 +274,6 @@ extern "C" int ba_destroy(ba_handle* h) {
   if (h->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(h->nccl);
   shm_destroy(h);
   for (auto e : h->ev) (void)hipEventDestroy(e);
-  if (h->ev_decide) (void)hipEventDestroy(h->ev_decide);
   DBuf<int>* ib[] = {&h->offk, &h->c_pt, &h->c_orig, &h->pt_off, &h->p_cam, &h->slot, &h->long_pts, &h->c_ptf[0], &h->c_ptf[1],
                      &h->p_camf[0], &h->p_camf[1]};
   for (auto b : ib) b->release();
@@ -295,7 +290,6 @@ extern "C" int ba_destroy(ba_handle* h) {
   h->st.release();
   h->verdict.release();
   if (h->h_scal) (void)hipHostFree(h->h_scal);
-  if (h->h_gmax) (void)hipHostFree(h->h_gmax);
   if (h->h_flags) (void)hipHostFree(h->h_flags);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1251,21 +1245,18 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     if (fresh && opts->gtol > 0) {
       // max |gradient| = max(|bc|, |bp|): per-workgroup maxima come out of the point half (partG) and of
       // k_pcg_setup (partGc); single rank: the first PCG probe folds them into host-mapped memory
-      if (h->world == 1) {
-        gtol_pending = true;
-      } else {
-        // bc is all-reduced (identical on every rank); bp is shard-local -> max over ranks
+      gtol_pending = true;
+      if (h->world > 1) {
+        // bc is all-reduced (identical on every rank); bp is shard-local -> max over the ranks' partial maxima, then
+        // the word goes to host-mapped memory ahead of the first probe (no copy, no stream synchronise)
         {
           Scope sc(h, BA_K_MISC);
           BA_LAUNCH(k_max_partials, dim3(1), dim3(64), 0, h->stream, (const double*)h->partG[h->pb].p,
-                             h->Np > 0 ? h->nblkP + h->nblkL : 0, (const double*)h->partGc.p, h->nblkV, h->scal.p + 18);
+                    h->Np > 0 ? h->nblkP + h->nblkL : 0, (const double*)h->partGc.p, h->nblkV, h->scal.p + 18);
         }
         if (int rc = allreduce(h, h->scal.p + 18, 1, true)) return rc;
-        HIPCHECK(hipMemcpyAsync(h->h_gmax, h->scal.p + 18, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        BA_SYNC(h);
-        const double gmax = h->h_gmax[0];
-        if (!std::isfinite(gmax)) return fail(BA_ERR_NUMERIC, "non-finite gradient at LM iteration %d", it);
-        if (gmax <= opts->gtol) { status = 3; break; }
+        Scope sc(h, BA_K_MISC);
+        BA_LAUNCH(k_word_to_host, dim3(1), dim3(64), 0, h->stream, (const double*)(h->scal.p + 18), h->d_scal_host + GMAX_HOST_SLOT);
       }
     }
     double t1 = now_s();
@@ -1281,7 +1272,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     h->flag_base += opts->pcg_max_iters + 8;
     auto launch_point_pass = [&](int kk) {
       launch_pt_schur(h, robust, 0, kk, tol2, opts->pcg_min_iters, base,
-                      (kk == 0 && gtol_pending) ? h->d_scal_host + GMAX_HOST_SLOT : (double*)nullptr);
+                      (kk == 0 && gtol_pending && h->world == 1) ? h->d_scal_host + GMAX_HOST_SLOT : (double*)nullptr);
     };
     auto launch_rest = [&](int kk) -> int {
       launch_cam_schur(h, robust, false, true, kk, tol2, opts->pcg_min_iters);
@@ -1334,18 +1325,13 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     if (debug_poison) BA_LAUNCH(k_poison, dim3(1), dim3(64), 0, h->stream, h->partR.p);
     const long long seq = ++h->step_seq;
     launch_scalars(h, true, k, tol2, opts->pcg_min_iters, seq, cost, lambda);
-    if (h->world > 1) {
+    if (h->world > 1) {       // the six sums over ranks, then the verdict on the all-reduced block; same host-mapped mirror + word
       if (int rc = allreduce(h, h->scal.p, 6)) return rc;
-      {
-        Scope sc(h, BA_K_MISC);
-        BA_LAUNCH(k_decide, dim3(1), dim3(64), 0, h->stream, h->scal.p, cost, lambda);
-      }
-      HIPCHECK(hipMemcpyAsync(h->h_scal, h->scal.p, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      HIPCHECK(hipEventRecord(h->ev_decide, h->stream));
+      Scope sc(h, BA_K_MISC);
+      BA_LAUNCH(k_decide, dim3(1), dim3(64), 0, h->stream, h->scal.p, cost, lambda, h->d_scal_host, h->d_flags + 2, seq);
     }
     if (speculated) launch_lin_pt(h, 1 - h->cur, 1 - h->pb, robust, fs, 0.0, h->scal.p + S_LAM_NEXT);
-    if (h->world > 1) HIPCHECK(hipEventSynchronize(h->ev_decide));
-    else if (int rc = wait_flag(h, 2, seq)) return rc;
+    if (int rc = wait_flag(h, 2, seq)) return rc;
     if (pcg_done_iters < 0) pcg_done_iters = (h->h_scal[S_PCG_FIN] != 0.0) ? (int)h->h_scal[S_PCG_ITERS] : k;
     sum->pcg_iterations += pcg_done_iters;
     double t2 = now_s();

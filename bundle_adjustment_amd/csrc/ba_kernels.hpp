@@ -1463,9 +1463,29 @@ __device__ inline void lm_decide(double* __restrict__ res, double cost_cur, doub
   res[S_GAIN] = rho;
   res[S_LAM_NEXT] = fmax(lambda * fmax(1.0 / 3.0, 1.0 - t * t * t), 1e-12);
 }
-// multi-rank form: the scalars are all-reduced between k_scalars and the decision
-__global__ void k_decide(double* __restrict__ scal, double cost_cur, double lambda) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) lm_decide(scal, cost_cur, lambda);
+// multi-rank form: the scalars are all-reduced between k_scalars and the decision; like k_scalars on a single rank,
+// the kernel mirrors the block into host-mapped memory and publishes the step's sequence word (one wave)
+__global__ void __launch_bounds__(64)
+k_decide(double* __restrict__ scal, double cost_cur, double lambda, double* __restrict__ scal_host,
+         long long* __restrict__ host_flag, long long seq) {
+  __shared__ double res[S_COUNT];
+  if (threadIdx.x < S_COUNT) res[threadIdx.x] = scal[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) lm_decide(res, cost_cur, lambda);
+  __syncthreads();
+  if (threadIdx.x < S_COUNT) {
+    scal[threadIdx.x] = res[threadIdx.x];
+    if (scal_host) scal_host[threadIdx.x] = res[threadIdx.x];
+  }
+  if (host_flag) {
+    __threadfence_system();
+    if (threadIdx.x == 0) publish_flag(host_flag, seq, 0);
+  }
+}
+// one device word into host-mapped memory (multi-rank: the all-reduced gradient maximum, read by the host at the
+// first PCG verdict -- no copy, no stream synchronise)
+__global__ void k_word_to_host(const double* __restrict__ src, double* __restrict__ dst_host) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) dst_host[0] = src[0];
 }
 
 __global__ void __launch_bounds__(1024)

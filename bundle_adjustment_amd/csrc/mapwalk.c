@@ -9,6 +9,8 @@
  *                         listed twice takes the LAST keypoint for every one of its rows (the
  *                         reference keys its pixel dict by the pair, :214-216).
  *   gather_positions  <-> the point packing of :161-162.
+ *   scatter_positions <-> the point half of _update_map (:238-240), in place where the map allows it.
+ *   count_present     <-> the membership filter of :208, for a cached window.
  * Arrays cross as writable buffers (numpy arrays on the Python side), so no numpy headers are
  * needed.  problem.flatten_map_window is the caller and keeps a numpy implementation of the
  * same walk, which tests/test_bundle_adjuster_host.py compares this one with.
@@ -267,9 +269,97 @@ done:
   return result;
 }
 
+/*
+ * scatter_positions(map_points, ids[int64 buffer], pts[f64 x3 buffer]) -> list of row indices NOT written
+ *   <-> the point half of BundleAdjuster._update_map (src/bundle_adjuster.py:238-240).  Row i of pts goes to
+ *   map_points[ids[i]].position.  Where that attribute already is a writable C-contiguous float64 array of
+ *   shape (3, 1) -- what the reference's own write-back leaves there, and what the pipeline creates -- the three
+ *   numbers are stored into it in place: no Python object is created per landmark.  Rows whose position is anything
+ *   else are returned, for the caller to rebind with a fresh (3, 1) array exactly as the reference does.
+ */
+static PyObject *scatter_positions(PyObject *self, PyObject *args) {
+  PyObject *map_points, *o_ids, *o_pts;
+  if (!PyArg_ParseTuple(args, "O!OO", &PyDict_Type, &map_points, &o_ids, &o_pts)) return NULL;
+  Py_buffer b_ids, b_pts;
+  if (PyObject_GetBuffer(o_ids, &b_ids, PyBUF_C_CONTIGUOUS) < 0) return NULL;
+  if (PyObject_GetBuffer(o_pts, &b_pts, PyBUF_C_CONTIGUOUS) < 0) { PyBuffer_Release(&b_ids); return NULL; }
+  PyObject *todo = NULL, *result = NULL;
+  const Py_ssize_t n = b_ids.len / 8;
+  if (b_ids.itemsize != 8 || b_pts.itemsize != 8 || b_pts.len / 24 < n) {
+    PyErr_SetString(PyExc_ValueError, "ids must be int64 and pts hold 3 doubles per id");
+    goto done;
+  }
+  todo = PyList_New(0);
+  if (!todo) goto done;
+  const int64_t *ids = (const int64_t *)b_ids.buf;
+  const double *pts = (const double *)b_pts.buf;
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    PyObject *key = PyLong_FromLongLong(ids[i]);
+    if (!key) goto done;
+    PyObject *obj = PyDict_GetItemWithError(map_points, key);   /* borrowed */
+    if (!obj) { if (!PyErr_Occurred()) PyErr_SetObject(PyExc_KeyError, key); Py_DECREF(key); goto done; }
+    Py_DECREF(key);
+    PyObject *pos = PyObject_GetAttr(obj, s_position);
+    if (!pos) goto done;
+    int written = 0;
+    Py_buffer b;
+    if (PyObject_CheckBuffer(pos)) {
+      if (PyObject_GetBuffer(pos, &b, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS | PyBUF_FORMAT | PyBUF_ND) == 0) {
+        if (b.itemsize == 8 && b.len == 24 && b.ndim == 2 && b.shape[0] == 3 && b.shape[1] == 1 && b.format &&
+            (strcmp(b.format, "d") == 0 || strcmp(b.format, "<d") == 0)) {
+          memcpy(b.buf, pts + 3 * i, 24);
+          written = 1;
+        }
+        PyBuffer_Release(&b);
+      } else {
+        PyErr_Clear();
+      }
+    }
+    Py_DECREF(pos);
+    if (!written) {
+      PyObject *idx = PyLong_FromSsize_t(i);
+      if (!idx || PyList_Append(todo, idx) < 0) { Py_XDECREF(idx); goto done; }
+      Py_DECREF(idx);
+    }
+  }
+  result = todo; todo = NULL;
+done:
+  Py_XDECREF(todo);
+  PyBuffer_Release(&b_ids); PyBuffer_Release(&b_pts);
+  return result;
+}
+
+/* count_present(map_points, ids[int64 buffer]) -> how many of the ids are keys of the dict (a cached window is
+ * reusable only while every landmark it lists still exists: src/bundle_adjuster.py:208 filters by membership) */
+static PyObject *count_present(PyObject *self, PyObject *args) {
+  PyObject *map_points, *o_ids;
+  if (!PyArg_ParseTuple(args, "O!O", &PyDict_Type, &map_points, &o_ids)) return NULL;
+  Py_buffer b_ids;
+  if (PyObject_GetBuffer(o_ids, &b_ids, PyBUF_C_CONTIGUOUS) < 0) return NULL;
+  PyObject *result = NULL;
+  if (b_ids.itemsize != 8) { PyErr_SetString(PyExc_ValueError, "ids must be int64"); goto done; }
+  const Py_ssize_t n = b_ids.len / 8;
+  const int64_t *ids = (const int64_t *)b_ids.buf;
+  Py_ssize_t present = 0;
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    PyObject *key = PyLong_FromLongLong(ids[i]);
+    if (!key) goto done;
+    const int have = PyDict_Contains(map_points, key);
+    Py_DECREF(key);
+    if (have < 0) goto done;
+    present += have;
+  }
+  result = PyLong_FromSsize_t(present);
+done:
+  PyBuffer_Release(&b_ids);
+  return result;
+}
+
 static PyMethodDef methods[] = {
   {"walk_window", walk_window, METH_VARARGS, "walk a keyframe window into flat observation arrays"},
   {"gather_positions", gather_positions, METH_VARARGS, "copy MapPoint.position of the given ids into (n,3)"},
+  {"scatter_positions", scatter_positions, METH_VARARGS, "write rows of (n,3) into MapPoint.position in place where it is a (3,1) float64 array"},
+  {"count_present", count_present, METH_VARARGS, "how many of the ids are keys of the map-point dict"},
   {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_mapwalk", "native walk over Map objects", -1, methods};

@@ -238,3 +238,19 @@ def test_c3_sized_shard_pair_reproduces_the_single_rank_iterates(tmp_path):
     pts = np.concatenate([np.load(tmp_path / f"pts_{k}.npy") for k in range(2)])
     assert ranges[1][1] == p.n_pts and pts.shape == pts_ref.shape
     assert np.abs(pts - pts_ref).max() <= 1e-10 * np.abs(pts_ref).max()
+
+
+def test_bench_two_ranks_over_the_shm_transport_reports_its_transport(tmp_path):
+    """bench.py --gpus 2 under torch.distributed.run, both ranks on the one GPU through BA_COMM=shm: the JSON line
+    names the transport and how many ranks joined the communicator (what a SCALE record is checked against); without
+    BA_COMM=shm two ranks on one device must make RCCL fail and the bench exit NON-ZERO instead of falling back."""
+    env = dict(os.environ, BA_COMM="shm")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--config", "C2", "--repeats", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and cfg["world"] == 2 and cfg["transport"] == "shm" and cfg["ranks_in_communicator"] == 2
+    assert line["steps"] == 4 and line["value"] > 0 and line["repeats"] == 2

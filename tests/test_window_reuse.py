@@ -1,0 +1,178 @@
+"""CPU: what BundleAdjuster.run keeps between consecutive calls: the flattened window
+(problem.WindowCache) must give, on every call of a growing map, exactly the problem a from-scratch walk gives
+(reference layout: src/bundle_adjuster.py:195-218), and the native write-back must leave the map as the reference's
+_update_map (:220-240) would."""
+import io
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from bundle_adjustment_amd import bundle_adjuster as ba_mod
+from bundle_adjustment_amd import _mapwalk
+from bundle_adjustment_amd.map_structures import Keyframe, KeyPoint, Map, MapPoint
+from bundle_adjustment_amd.problem import WindowCache, flatten_map_window
+from bundle_adjustment_amd.synthetic import make_problem, problem_to_map
+from tests.fake_solver import OracleSolver
+
+
+def _same(p, q):
+    for name in ("cam_idx", "pt_idx", "uv", "cams", "pts", "K4"):
+        np.testing.assert_array_equal(getattr(p, name), getattr(q, name), err_msg=name)
+
+
+def _grow(gmap, rng, n_new_pts=40, reobserve=60):
+    """What src/pipeline.py:226-313 does when a keyframe is inserted: a new keyframe that re-observes existing
+    landmarks and creates new ones; the previous keyframe gets the matching observations appended too."""
+    kf_id = max(gmap.keyframes) + 1
+    prev = gmap.keyframes[kf_id - 1]
+    kps, obs = [], []
+    ids = sorted(gmap.map_points)
+    for mp in rng.choice(ids, size=min(reobserve, len(ids)), replace=False).tolist():
+        kps.append(KeyPoint(pt=(float(np.float32(rng.uniform(0, 1280))), float(np.float32(rng.uniform(0, 720))))))
+        obs.append((int(mp), len(kps) - 1))
+    nxt = max(ids) + 1
+    for j in range(n_new_pts):
+        gmap.add_map_point(MapPoint(id=nxt + j, position=rng.normal(size=(3, 1)) + np.array([[0], [0], [10.0]]), observations=[],
+                                    color=np.zeros((3, 1))))
+        kps.append(KeyPoint(pt=(float(np.float32(rng.uniform(0, 1280))), float(np.float32(rng.uniform(0, 720))))))
+        obs.append((nxt + j, len(kps) - 1))
+        prev.keypoints.append(KeyPoint(pt=(float(np.float32(rng.uniform(0, 1280))), float(np.float32(rng.uniform(0, 720))))))
+        prev.observations.append((nxt + j, len(prev.keypoints) - 1))            # the list of an OLD keyframe grows
+    gmap.add_keyframe(Keyframe(id=kf_id, R=np.eye(3), t=rng.normal(size=(3, 1)), keypoints=kps, descriptors=None,
+                               observations=obs, img=None))
+
+
+def test_cached_window_equals_a_fresh_walk_on_a_growing_map():
+    rng = np.random.default_rng(3)
+    p = make_problem(7, 300, 4, seed=2)
+    gmap = problem_to_map(p)
+    K = np.array([[p.K4[0], 0, p.K4[2]], [0, p.K4[1], p.K4[3]], [0, 0, 1.0]])
+    cache = WindowCache()
+    w = 5
+    tokens = []
+    for step in range(7):
+        local = sorted(gmap.keyframes)[-(w + 1):-1]
+        got, ids, token = cache.flatten(gmap, local, K)
+        ref, ref_ids = flatten_map_window(gmap, local, K)
+        assert ids.tolist() == ref_ids
+        _same(got, ref)
+        tokens.append(token)
+        if step == 2:                       # same map again: the whole window is reused, same structure token
+            got2, ids2, token2 = cache.flatten(gmap, local, K)
+            assert token2 == token and cache.hits["window"] >= 1
+            _same(got2, ref)
+            # positions and poses are read afresh even on a full hit
+            some = gmap.map_points[int(ids[0])]
+            some.position = some.position + 1.0
+            gmap.keyframes[local[1]].t = gmap.keyframes[local[1]].t + 0.5
+            got3, _, token3 = cache.flatten(gmap, local, K)
+            assert token3 == token
+            _same(got3, flatten_map_window(gmap, local, K)[0])
+        if step == 4:                       # a landmark disappears: rows that listed it must go (:208), cache or not
+            del gmap.map_points[int(ids[len(ids) // 2])]
+            got4, ids4, token4 = cache.flatten(gmap, local, K)
+            ref4, ref_ids4 = flatten_map_window(gmap, local, K)
+            assert token4 != token and ids4.tolist() == ref_ids4
+            _same(got4, ref4)
+        if step == 5:                       # a duplicated (keyframe, landmark) row: last pixel wins for both rows
+            kf = gmap.keyframes[local[-1]]
+            mp0 = kf.observations[0][0]
+            kf.keypoints.append(KeyPoint(pt=(11.25, 77.5)))
+            kf.observations.append((mp0, len(kf.keypoints) - 1))
+        _grow(gmap, rng)
+    assert len(set(tokens)) == len(tokens)                      # every growth step changed the structure
+    assert cache.hits["keyframe"] > 0 and cache.hits["walked"] < 7 * w      # the sliding window re-walked only what changed
+
+
+def test_large_windows_take_the_one_shot_walk_and_reuse_the_whole_window():
+    p = make_problem(WindowCache.PER_KF_LIMIT + 6, 400, 3, seed=4)
+    gmap = problem_to_map(p)
+    K = np.array([[p.K4[0], 0, p.K4[2]], [0, p.K4[1], p.K4[3]], [0, 0, 1.0]])
+    local = sorted(gmap.keyframes)[:-1]
+    cache = WindowCache()
+    a, ids_a, ta = cache.flatten(gmap, local, K)
+    b, ids_b, tb = cache.flatten(gmap, local, K)
+    ref, ref_ids = flatten_map_window(gmap, local, K)
+    assert ta == tb and cache.hits["window"] == 1 and not cache.per_kf
+    assert ids_a.tolist() == ref_ids
+    _same(a, ref)
+    _same(b, ref)
+
+
+def test_native_write_back_in_place_and_rebinding():
+    """(3,1) float64 positions are overwritten in place (no new objects); anything else is rebound to a (3,1) array,
+    which is what the reference leaves for every landmark (src/bundle_adjuster.py:239-240)."""
+    mps = {}
+    for i in range(6):
+        mps[i] = MapPoint(id=i, position=np.zeros((3, 1)), observations=[], color=np.zeros((3, 1)))
+    mps[1].position = np.zeros(3)                               # wrong shape
+    mps[2].position = np.zeros((3, 1), dtype=np.float32)        # wrong dtype
+    mps[3].position = [0.0, 0.0, 0.0]                           # not an array
+    ro = np.zeros((3, 1)); ro.setflags(write=False)
+    mps[4].position = ro                                        # read-only
+    keep = {i: mps[i].position for i in (0, 5)}
+    ids = np.array([0, 1, 2, 3, 4, 5], dtype=np.int64)
+    pts = np.arange(18, dtype=np.float64).reshape(6, 3)
+    todo = _mapwalk.scatter_positions(mps, ids, pts)
+    assert todo == [1, 2, 3, 4]
+    for i in (0, 5):
+        assert mps[i].position is keep[i]                       # same object, new numbers
+        np.testing.assert_array_equal(mps[i].position, pts[i].reshape(3, 1))
+    with pytest.raises(KeyError):
+        _mapwalk.scatter_positions(mps, np.array([99], dtype=np.int64), pts)
+    assert _mapwalk.count_present(mps, np.array([0, 5, 99, -3], dtype=np.int64)) == 2
+    # through _update_map every landmark ends (3,1) float64 with the new numbers, and poses are rebound
+    gm = Map()
+    for m in mps.values():
+        gm.add_map_point(m)
+    gm.add_keyframe(Keyframe(id=7, R=np.eye(3), t=np.zeros((3, 1)), keypoints=[], descriptors=None, observations=[], img=None))
+    ba = ba_mod.BundleAdjuster(np.eye(3), window_size=2)
+    x = np.concatenate([[0.1, 0.2, 0.3], [1.0, 2.0, 3.0], (pts + 100).ravel()])
+    ba._update_map(gm, x, [7], [0, 1, 2, 3, 4, 5])
+    for i in range(6):
+        pos = gm.map_points[i].position
+        assert isinstance(pos, np.ndarray) and pos.shape == (3, 1) and pos.dtype == np.float64
+        np.testing.assert_array_equal(pos.ravel(), pts[i] + 100)
+    assert gm.keyframes[7].R.shape == (3, 3) and gm.keyframes[7].t.shape == (3, 1)
+    np.testing.assert_array_equal(gm.keyframes[7].t.ravel(), [1.0, 2.0, 3.0])
+
+
+def test_run_sends_parameters_only_when_the_structure_is_unchanged(monkeypatch):
+    calls = []
+
+    class Counting(OracleSolver):
+        def set_problem(self, prob, with_params=True):
+            calls.append("problem")
+            super().set_problem(prob, with_params)
+
+        def set_params(self, cams, pts):
+            calls.append("params")
+            self.cams, self.pts = np.array(cams, dtype=np.float64), np.array(pts, dtype=np.float64)
+
+    monkeypatch.setattr(ba_mod.hip_backend, "Solver", Counting)
+    p = make_problem(6, 250, 4, seed=6)
+    gmap = problem_to_map(p)
+    K = np.array([[p.K4[0], 0, p.K4[2]], [0, p.K4[1], p.K4[3]], [0, 0, 1.0]])
+    ba = ba_mod.BundleAdjuster(K, window_size=5, ftol=1e-10, xtol=1e-10)
+    ref = ba_mod.BundleAdjuster(K, window_size=5, ftol=1e-10, xtol=1e-10, reuse_window=False)
+    gref = problem_to_map(p)
+    logs = []
+    for step in range(3):
+        for b, g in ((ba, gmap), (ref, gref)):
+            buf = io.StringIO()
+            with redirect_stdout(buf):
+                b.run(g)
+            logs.append(buf.getvalue())
+        assert logs[-1] == logs[-2]                             # with or without the cache: the same log line
+        if step == 1:
+            rng = np.random.default_rng(9)
+            _grow(gmap, rng)
+            _grow(gref, np.random.default_rng(9))
+    mine = [c for c in calls]
+    # ba: problem, params (unchanged window), problem (map grew); ref: problem every time
+    assert mine.count("params") == 1 and mine.count("problem") == 2 + 3
+    for i in sorted(gmap.map_points):
+        np.testing.assert_array_equal(gmap.map_points[i].position, gref.map_points[i].position)
+    for k in sorted(gmap.keyframes):
+        np.testing.assert_array_equal(gmap.keyframes[k].R, gref.keyframes[k].R)

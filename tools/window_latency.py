@@ -30,3 +30,28 @@ print(f"{n_cams} cams / {n_pts} pts / {p.n_obs} obs; {out['iterations']} LM iter
 for k_, v in times.items():
     v = np.array(v[5:]) * 1e3
     print(f"  {k_:12s} median {np.median(v):7.3f} ms   min {v.min():7.3f}")
+
+# ---- the reference's actual use: run() after every new keyframe (src/pipeline.py:99), window sliding by one ----
+from bundle_adjustment_amd.map_structures import Map
+extra = 25
+pl = make_problem(n_cams + extra, n_pts * 3, k, seed=1)
+for reuse in (True, False):
+    full = problem_to_map(pl, extra_newest=False)       # a fresh (unoptimised) map for each mode
+    gv = Map()
+    gv.map_points = full.map_points
+    ids = sorted(full.keyframes)
+    for i in ids[:n_cams + 1]:
+        gv.add_keyframe(full.keyframes[i])
+    bs = BundleAdjuster(K, window_size=n_cams, reuse_window=reuse)
+    lat = []
+    for i in ids[n_cams + 1:]:
+        buf = io.StringIO()
+        t = time.perf_counter()
+        with redirect_stdout(buf):
+            bs.run(gv)
+        lat.append(time.perf_counter() - t)
+        gv.add_keyframe(full.keyframes[i])
+    lat = np.array(lat[3:]) * 1e3
+    extra_note = f", cache hits {bs._window.hits}" if reuse else ""
+    print(f"  sliding window, reuse_window={reuse}: run() median {np.median(lat):7.3f} ms   min {lat.min():7.3f}{extra_note}")
+    bs.close()
