@@ -38,7 +38,7 @@ from .rotations import matrices_to_rvecs
 class BundleAdjuster:
     def __init__(self, camera_matrix, window_size=5, *, device_id=0, loss='huber', f_scale=1.0, ftol=1e-5,
                  xtol=1e-5, gtol=1e-8, max_iters=50, pcg_tol=0.1, pcg_max_iters=200, preconditioner='schur_jacobi',
-                 jacobian='f64', comm=None, sparsity_plot_hook=None, verbose=0, reuse_window=True):
+                 jacobian='f64', comm=None, sparsity_plot_hook=None, verbose=0, reuse_window=True, metrics_path=None):
         self.camera_matrix = camera_matrix
         self.window_size = window_size
         self.device_id = device_id
@@ -48,6 +48,7 @@ class BundleAdjuster:
         self.comm = comm                       # None, or (rank, world, unique_id bytes)
         self.sparsity_plot_hook = sparsity_plot_hook
         self.last_summary = None
+        self.metrics_path = metrics_path       # JSON lines, one per run(): sizes, summary, per-iteration trace
         self._solver = None
         # what survives between consecutive run() calls (src/pipeline.py:99 calls run after every keyframe): the
         # flattened window (problem.WindowCache) and, while its observation structure is unchanged, the problem the
@@ -63,6 +64,11 @@ class BundleAdjuster:
                 rank, world, unique_id = self.comm
                 self._solver.comm_init(rank, world, unique_id)
         return self._solver
+
+    def _write_metrics(self, prob, local_kf_ids, summary, solver):
+        trace = solver.trace() if hasattr(solver, "trace") else []
+        with open(self.metrics_path, "a") as f:
+            f.write(_metrics_line(prob, local_kf_ids, summary, trace) + "\n")
 
     def close(self):
         if self._solver is not None:
@@ -205,6 +211,8 @@ class BundleAdjuster:
         self._uploaded_token = token
         summary = solver.solve(**self.solver_options)          # costs / verdicts are global on every rank
         self.last_summary = summary
+        if self.metrics_path and (self.comm is None or self.comm[0] == 0):
+            self._write_metrics(prob, local_kf_ids, summary, solver)
         initial_cost, final_cost = summary["initial_sse"], summary["final_sse"]     # plain SSE (:165, :176)
         if final_cost >= initial_cost:
             print(f"    -> LBA Diverged! Cost increased from {initial_cost:.2f} to {final_cost:.2f}. Discarding results.")
@@ -228,6 +236,21 @@ class BundleAdjuster:
                 pcd_filename = os.path.join(lba_steps_dir, f"map_after_lba_kf_{fixed_kf_id}.pcd")
                 _write_ascii_pcd(pcd_filename, pcd.points, pcd.colors)
                 print(f"    -> Saved intermediate map to {pcd_filename}")
+
+
+def _metrics_line(prob, local_kf_ids, summary, trace):
+    """One JSON object per run(): what the reference only prints as a log line (src/bundle_adjuster.py:183-184) plus
+    the trajectory -- sizes, costs, iterations, seconds, and one record per LM iteration (ba_get_trace)."""
+    import json
+    rec = dict(event="lba", fixed_keyframe=int(local_kf_ids[0]), last_keyframe=int(local_kf_ids[-1]),
+               n_keyframes=int(prob.n_cams), n_landmarks=int(prob.n_pts), n_observations=int(prob.n_obs))
+    rec.update({k: (float(v) if isinstance(v, float) else v) for k, v in summary.items()})
+    n_obs = max(int(prob.n_obs), 1)
+    rec["initial_rmse_px"] = float(np.sqrt(summary["initial_sse"] / n_obs))
+    rec["final_rmse_px"] = float(np.sqrt(summary["final_sse"] / n_obs))
+    rec["lm_iterations_per_s"] = float(summary["iterations"] / summary["seconds_total"]) if summary.get("seconds_total") else None
+    rec["trace"] = trace
+    return json.dumps(rec)
 
 
 def _write_ascii_pcd(path, points, colors):

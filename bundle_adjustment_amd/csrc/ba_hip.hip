@@ -31,6 +31,7 @@
 
 #include "../../include/ba_hip.h"
 #include "ba_kernels.hpp"
+#include "ba_triangulate.hpp"
 
 using namespace ba;
 
@@ -87,6 +88,32 @@ static int load_rccl() {
   return BA_OK;
 }
 
+// ----------------------------------------------------------------------------- roctx
+// Optional named ranges around the phases of an LM iteration (BA_ROCTX=1): they show up in rocprofv3
+// --marker-trace timelines.  libroctx64 is loaded on demand; without it, or without the variable, nothing happens.
+struct Roctx {
+  bool tried = false;
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+};
+static Roctx g_roctx;
+static void roctx_load() {
+  if (g_roctx.tried) return;
+  g_roctx.tried = true;
+  if (!getenv("BA_ROCTX")) return;
+  void* lib = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return;
+  g_roctx.push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+  g_roctx.pop = (int (*)())dlsym(lib, "roctxRangePop");
+  if (!g_roctx.push || !g_roctx.pop) { g_roctx.push = nullptr; g_roctx.pop = nullptr; }
+}
+struct Range {        // host-side range: covers the launches (and host waits) of one phase
+  bool on;
+  explicit Range(const char* name) : on(g_roctx.push != nullptr) { if (on) g_roctx.push(name); }
+  ~Range() { if (on) g_roctx.pop(); }
+};
+
 // ---------------------------------------------------------------------------- handle
 template <typename T>
 struct DBuf {
@@ -140,6 +167,7 @@ struct ba_handle {
   // PCG vectors, comm buffers (multi-rank), scalars
   DBuf<double> gvec, x, r, p, s, z, vin, scal, rbuf, gather;
   DBuf<PcgState> st;
+  DBuf<double> tri;            // staging of ba_triangulate
   DBuf<double> verdict;        // PCG verdict words {gamma, zeta, finished, -} x 2 iteration parities (point pass -> camera pass, vector kernel)
   int cam_segl = 64;           // lanes per (camera, partition) segment in the PCG camera pass (BA_CAM_SEGL, tuning)
   int nblkP = 1, ppb = 1, nblkV = 1;
@@ -162,6 +190,7 @@ struct ba_handle {
   hipError_t launch_err = hipSuccess;
   char launch_what[160] = {0};
   int debug_lds_extra = 0;     // BA_DEBUG_LDS_EXTRA: bytes added to the point passes' dynamic LDS (tests provoke a failed launch)
+  std::vector<ba_iter_record> trace;   // one record per LM iteration of the last ba_solve
   // profiling
   bool profile = false;
   std::vector<hipEvent_t> ev;
@@ -288,6 +317,7 @@ extern "C" int ba_destroy(ba_handle* h) {
                         &h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin, &h->scal, &h->rbuf, &h->gather};
   for (auto b : db) b->release();
   h->st.release();
+  h->tri.release();
   h->verdict.release();
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->h_flags) (void)hipHostFree(h->h_flags);
@@ -1194,6 +1224,9 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   h->jac_f32 = opts->jacobian_precision == 1;
   if (set_device(h)) return BA_ERR_HIP;
   memset(sum, 0, sizeof *sum);
+  h->trace.clear();
+  roctx_load();
+  Range r_solve("ba_solve");
   const bool robust = opts->loss == BA_LOSS_HUBER;
   const bool schur_diag = opts->preconditioner == BA_PRECOND_SCHUR_JACOBI;
   const double fs = opts->f_scale;
@@ -1226,7 +1259,9 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   while (it < opts->max_iters) {
     double t0 = now_s();
     bool fresh = false;
+    Range r_iter("lm_iteration");
     if (need_linearize) {
+      Range r_lin("linearize");
       if (!have_lin) {
         launch_lin_cam(h, h->cur, h->lb, robust, fs);
         launch_lin_pt(h, h->cur, h->pb, robust, fs, lambda);          // also Hpp^-1, y0 at this lambda
@@ -1240,7 +1275,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       fresh = true;
     }
     // ---- damped system, right-hand side, preconditioner, first PCG vectors
-    if (int rc = damped_system(h, lambda, schur_diag, !fresh, fresh)) return rc;
+    { Range r_damp("damped_system"); if (int rc = damped_system(h, lambda, schur_diag, !fresh, fresh)) return rc; }
     bool gtol_pending = false;     // single rank: max |gradient| lands in host-mapped memory, read at the first PCG verdict
     if (fresh && opts->gtol > 0) {
       // max |gradient| = max(|bc|, |bp|): per-workgroup maxima come out of the point half (partG) and of
@@ -1284,6 +1319,8 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
                          h->partV.p, h->nblkV, h->st.p, h->d_flags, base, (const double*)h->verdict.p);
       return BA_OK;
     };
+    Range* r_pcg = new Range("pcg");
+    struct RangeGuard { Range*& r; ~RangeGuard() { delete r; r = nullptr; } } r_pcg_guard{r_pcg};
     launch_point_pass(0);
     while (true) {
       if (int rc = wait_flag(h, 0, base + k + 1)) return rc;
@@ -1301,8 +1338,10 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       if (k >= opts->pcg_max_iters) break;
       launch_point_pass(k);
     }
+    delete r_pcg; r_pcg = nullptr;
     if (gtol_stop) { status = 3; break; }      // converged by gradient: no step (the queued probe exits on its own)
     // ---- step, trial point, gain-ratio scalars
+    Range r_step("step");
     {
       Scope sc(h, BA_K_MISC);
       BA_LAUNCH(k_cam_update, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->cams[h->cur].p, h->x.p, h->r.p,
@@ -1344,6 +1383,13 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     if (opts->verbose)
       fprintf(stderr, "[ba] it %3d cost %.9e -> %.9e lambda %.3e rho %+.3f pcg %d |step| %.3e\n", it, cost, cost_new,
               lambda, rho, pcg_done_iters, std::sqrt(step2));
+    {
+      ba_iter_record rec = {};
+      rec.iteration = it; rec.accepted = (rho > 0 && std::isfinite(cost_new)) ? 1 : 0; rec.pcg_iterations = pcg_done_iters;
+      rec.cost = cost; rec.cost_trial = cost_new; rec.sse_trial = sse_new; rec.lambda = lambda; rec.gain_ratio = rho;
+      rec.step_norm = std::sqrt(step2); rec.seconds = now_s() - t0;
+      h->trace.push_back(rec);
+    }
     bool stop = false;
     if (rho > 0 && std::isfinite(cost_new)) {
       const double dcost = cost - cost_new;
@@ -1377,6 +1423,46 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   if (h->profile) flush_profile(h);
   h->profile = false;
   h->jac_f32 = false;
+  return BA_OK;
+}
+
+// --------------------------------------------------------- two-view triangulation (row f3)
+extern "C" int ba_triangulate(ba_handle* h, const double K[9], const double R_rel[9], const double t_rel[3], int64_t n,
+                              const double* pts1, const double* pts2, double* xyz, uint8_t* valid) {
+  if (!h || !K || !R_rel || !t_rel || n < 0) return fail(BA_ERR_INVALID, "bad argument");
+  if (n == 0) return BA_OK;
+  if (!pts1 || !pts2 || !xyz || !valid) return fail(BA_ERR_INVALID, "null point arrays");
+  if (set_device(h)) return BA_ERR_HIP;
+  TriView v;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) {
+      v.P1[4 * r + c] = (c < 3) ? K[3 * r + c] : 0.0;                                   // K [I | 0]
+      double s2 = 0.0;
+      for (int k = 0; k < 3; ++k) s2 += K[3 * r + k] * ((c < 3) ? R_rel[3 * k + c] : t_rel[k]);
+      v.P2[4 * r + c] = s2;                                                             // K [R | t]
+    }
+  memcpy(v.R, R_rel, sizeof v.R);
+  memcpy(v.t, t_rel, sizeof v.t);
+  // staging: 2n + 2n doubles in, 3n doubles + n bytes out, in the handle's scratch buffer
+  const size_t words = 7 * (size_t)n + ((size_t)n + 7) / 8 + 8;
+  HIPCHECK(h->tri.alloc(words));
+  double* d1 = h->tri.p;
+  double* d2 = d1 + 2 * (size_t)n;
+  double* dx = d2 + 2 * (size_t)n;
+  uint8_t* dv = (uint8_t*)(dx + 3 * (size_t)n);
+  HIPCHECK(hipMemcpyAsync(d1, pts1, 2 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(hipMemcpyAsync(d2, pts2, 2 * (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  BA_LAUNCH(k_triangulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, v, n, (const double2*)d1, (const double2*)d2, dx, dv);
+  HIPCHECK(hipMemcpyAsync(xyz, dx, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipMemcpyAsync(valid, dv, (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  BA_SYNC(h);
+  return BA_OK;
+}
+
+extern "C" int ba_get_trace(ba_handle* h, ba_iter_record* out, int32_t capacity, int32_t* n) {
+  if (!h || !n || capacity < 0) return fail(BA_ERR_INVALID, "bad argument");
+  *n = (int32_t)h->trace.size();
+  if (out) memcpy(out, h->trace.data(), sizeof(ba_iter_record) * (size_t)std::min<int32_t>(capacity, *n));
   return BA_OK;
 }
 

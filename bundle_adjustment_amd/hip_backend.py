@@ -48,6 +48,12 @@ class BASummary(C.Structure):
         return d
 
 
+class BAIterRecord(C.Structure):
+    _fields_ = [("iteration", C.c_int32), ("accepted", C.c_int32), ("pcg_iterations", C.c_int32), ("reserved", C.c_int32),
+                ("cost", C.c_double), ("cost_trial", C.c_double), ("sse_trial", C.c_double), ("lambda_", C.c_double),
+                ("gain_ratio", C.c_double), ("step_norm", C.c_double), ("seconds", C.c_double)]
+
+
 class BAProfile(C.Structure):
     _fields_ = [("launches", C.c_int32 * PROFILE_SLOTS), ("total_ms", C.c_double * PROFILE_SLOTS),
                 ("working_launches", C.c_int32 * PROFILE_SLOTS), ("working_ms", C.c_double * PROFILE_SLOTS)]
@@ -81,6 +87,8 @@ SYMBOLS = {
     "ba_get_profile": (C.c_int, [C.c_void_p, C.POINTER(BAProfile)]),
     "ba_reset_profile": (C.c_int, [C.c_void_p]),
     "ba_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _DP]),
+    "ba_triangulate": (C.c_int, [C.c_void_p, _DP, _DP, _DP, C.c_int64, _DP, _DP, _DP, C.POINTER(C.c_uint8)]),
+    "ba_get_trace": (C.c_int, [C.c_void_p, C.POINTER(BAIterRecord), C.c_int32, C.POINTER(C.c_int32)]),
 }
 
 
@@ -234,6 +242,32 @@ class Solver:
         s = BASummary()
         _check(self._lib.ba_solve(self._h, C.byref(o), C.byref(s)))
         return s.as_dict()
+
+    def triangulate(self, camera_matrix, R_rel, t_rel, pts1, pts2):
+        """ba_triangulate: (n,3) points in the first camera's frame and the (n,) cheirality mask."""
+        K = np.ascontiguousarray(camera_matrix, dtype=np.float64).reshape(3, 3)
+        R = np.ascontiguousarray(R_rel, dtype=np.float64).reshape(3, 3)
+        t = np.ascontiguousarray(t_rel, dtype=np.float64).reshape(3)
+        p1 = np.ascontiguousarray(pts1, dtype=np.float64).reshape(-1, 2)
+        p2 = np.ascontiguousarray(pts2, dtype=np.float64).reshape(-1, 2)
+        n = p1.shape[0]
+        xyz = np.empty((n, 3))
+        valid = np.zeros(n, dtype=np.uint8)
+        _check(self._lib.ba_triangulate(self._h, _dp(K), _dp(R), _dp(t), n, _dp(p1), _dp(p2), _dp(xyz),
+                                        valid.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return xyz, valid.astype(bool)
+
+    def trace(self):
+        """Per-iteration records of the last solve (ba_get_trace): list of dicts."""
+        n = C.c_int32(0)
+        _check(self._lib.ba_get_trace(self._h, None, 0, C.byref(n)))
+        if n.value == 0:
+            return []
+        buf = (BAIterRecord * n.value)()
+        _check(self._lib.ba_get_trace(self._h, buf, n.value, C.byref(n)))
+        return [dict(iteration=r.iteration, accepted=bool(r.accepted), pcg_iterations=r.pcg_iterations, cost=r.cost,
+                     cost_trial=r.cost_trial, sse_trial=r.sse_trial, damping=r.lambda_, gain_ratio=r.gain_ratio,
+                     step_norm=r.step_norm, seconds=r.seconds) for r in buf[:n.value]]
 
     def profile(self, reset=False):
         p = BAProfile()

@@ -80,6 +80,23 @@ typedef struct ba_summary {
   double seconds_update;
 } ba_summary;
 
+/* One record per LM iteration of the last ba_solve ("metrics / logging": the reference only
+ * prints one line per run, src/bundle_adjuster.py:183-184; benchmarks and the drop-in's JSON metrics sink want the
+ * trajectory).  Kept on the host, costs nothing on the device. */
+typedef struct ba_iter_record {
+  int32_t iteration;       /* 1-based */
+  int32_t accepted;        /* 1 = step taken */
+  int32_t pcg_iterations;  /* of this LM iteration */
+  int32_t reserved;
+  double cost;             /* 0.5 sum rho(r^2) before the step */
+  double cost_trial;       /* ... at the trial point */
+  double sse_trial;        /* sum r^2 at the trial point */
+  double lambda;           /* damping the step was computed with */
+  double gain_ratio;       /* actual / predicted decrease */
+  double step_norm;        /* |dx| */
+  double seconds;          /* wall time of this iteration on the host clock */
+} ba_iter_record;
+
 /* Per-kernel event timing collected when ba_options.profile = 1. */
 #define BA_PROFILE_SLOTS 16
 typedef struct ba_profile {
@@ -97,6 +114,16 @@ enum ba_kernel_slot {
 
 const char* ba_last_error(void);
 const char* ba_kernel_name(int slot);
+/* Batched two-view triangulation + cheirality test: replaces VisualOdometryPipeline._triangulate_points,
+ * src/pipeline.py:315-336 (cv2.triangulatePoints on P1 = K [I|0], P2 = K [R_rel|t_rel], division by (w + 1e-6),
+ * z > 0 in both cameras).  K, R_rel row-major 3x3; pts1 / pts2 double[n][2] pixels in the two views; xyz double[n][3]
+ * in the first camera's frame (EVERY point, kept or not); valid uint8[n] = the cheirality mask of :328-334.
+ * Needs no ba_set_problem. */
+int ba_triangulate(ba_handle* h, const double K[9], const double R_rel[9], const double t_rel[3], int64_t n,
+                   const double* pts1, const double* pts2, double* xyz, uint8_t* valid);
+/* Copies up to `capacity` records of the last ba_solve into out (may be NULL to ask for the count only);
+ * *n = number of LM iterations recorded. */
+int ba_get_trace(ba_handle* h, ba_iter_record* out, int32_t capacity, int32_t* n);
 
 /* Device / handle -------------------------------------------------------------------- */
 int ba_device_count(int* n);

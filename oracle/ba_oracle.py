@@ -585,3 +585,29 @@ def flat_jacobian_fun(cams0, npts, cam_idx, pt_idx, K4, fixed_cam):
         return coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
                           shape=(2 * nobs, 6 * na + 3 * npts)).tocsr()
     return jac
+
+
+# ---------------------------------------------------------------------------
+# Two-view triangulation (row f3): restatement of src/pipeline.py:315-336
+# ---------------------------------------------------------------------------
+def triangulate_points(K, R_rel, t_rel, pts1, pts2):
+    """``_triangulate_points`` of the reference with ``cv2.triangulatePoints`` restated from OpenCV's published DLT
+    (per point the 4x4 system A = [x1 P1[2]-P1[0]; y1 P1[2]-P1[1]; x2 P2[2]-P2[0]; y2 P2[2]-P2[1]], solution = right
+    singular vector of the smallest singular value; numpy SVD on A itself, not on A^T A).  The singular vector's sign
+    is fixed as w >= 0 (OpenCV leaves it to its SVD; the reference's ``+ 1e-6`` makes the result depend on it at the
+    1e-6 level: parity unpinned at the cv2 boundary).  Returns (xyz (n,3) for EVERY point, valid mask (n,))."""
+    K = np.asarray(K, dtype=np.float64).reshape(3, 3)
+    R = np.asarray(R_rel, dtype=np.float64).reshape(3, 3)
+    t = np.asarray(t_rel, dtype=np.float64).reshape(3, 1)
+    P1 = K @ np.hstack((np.eye(3), np.zeros((3, 1))))
+    P2 = K @ np.hstack((R, t))
+    p1 = np.asarray(pts1, dtype=np.float64).reshape(-1, 2)
+    p2 = np.asarray(pts2, dtype=np.float64).reshape(-1, 2)
+    A = np.stack([p1[:, :1] * P1[2] - P1[0], p1[:, 1:] * P1[2] - P1[1],
+                  p2[:, :1] * P2[2] - P2[0], p2[:, 1:] * P2[2] - P2[1]], axis=1)          # (n,4,4)
+    _, _, Vt = np.linalg.svd(A)
+    X = Vt[:, 3, :]
+    X = np.where(X[:, 3:] < 0, -X, X)
+    xyz = X[:, :3] / (X[:, 3:] + 1e-6)
+    z2 = (xyz @ R.T + t.ravel())[:, 2]
+    return xyz, (xyz[:, 2] > 0) & (z2 > 0)

@@ -21,6 +21,9 @@ class OracleSolver:
         self.cams, self.pts = prob.cams.copy(), prob.pts.copy()
         self.n_cams, self.n_pts, self.n_obs = prob.n_cams, prob.n_pts, prob.n_obs
 
+    def set_params(self, cams, pts):
+        self.cams, self.pts = np.array(cams, dtype=np.float64), np.array(pts, dtype=np.float64)
+
     def residuals(self, loss="linear", f_scale=1.0, want_vector=True):
         p = self.prob
         r = o.residuals(self.cams, self.pts, p.cam_idx, p.pt_idx, p.uv, p.K4)
@@ -35,7 +38,7 @@ class OracleSolver:
             return dict(initial_sse=out["sse0"], final_sse=out["sse0"] * 1.5, iterations=1, accepted=0)
         self.cams, self.pts = out["cams"], out["pts"]
         return dict(initial_sse=out["sse0"], final_sse=out["sse"], initial_cost=out["cost0"], final_cost=out["cost"],
-                    iterations=out["iterations"], accepted=out["accepted"], pcg_iterations=out["pcg_iters"])
+                    iterations=out["iterations"], accepted=out["accepted"], pcg_iterations=out["pcg_iters"], seconds_total=1e-3)
 
     def get_params(self):
         return self.cams.copy(), self.pts.copy()

@@ -215,3 +215,22 @@ def test_pcd_snapshot_only_when_directory_exists(fake_device, tmp_path, monkeypa
     assert "Saved intermediate map to" in log
     txt = (d / "map_after_lba_kf_0.pcd").read_text()
     assert "POINTS 40" in txt and txt.count("\n") == 11 + 40
+
+
+def test_metrics_sink_writes_one_json_line_per_run(fake_device, tmp_path):
+    """SURVEY.md section 5 (metrics / logging): next to the reference's log line, run() can append one JSON object per
+    call -- sizes, costs, RMSE, iteration counts and (from the device library) the per-iteration trace."""
+    import json
+    p = make_problem(6, 150, 4, seed=12)
+    gmap = problem_to_map(p)
+    K = np.array([[p.K4[0], 0, p.K4[2]], [0, p.K4[1], p.K4[3]], [0, 0, 1.0]])
+    path = tmp_path / "lba_metrics.jsonl"
+    ba = ba_mod.BundleAdjuster(K, window_size=p.n_cams, metrics_path=str(path))
+    _run(ba, gmap)
+    _run(ba, gmap)
+    lines = [json.loads(ln) for ln in open(path)]
+    assert len(lines) == 2
+    m = lines[0]
+    assert m["event"] == "lba" and m["n_keyframes"] == p.n_cams and m["n_landmarks"] == p.n_pts and m["n_observations"] == p.n_obs
+    assert m["fixed_keyframe"] == 0 and m["final_sse"] < m["initial_sse"] and m["final_rmse_px"] < m["initial_rmse_px"]
+    assert isinstance(m["trace"], list)

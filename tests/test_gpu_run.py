@@ -7,7 +7,7 @@ from contextlib import redirect_stdout
 import numpy as np
 import pytest
 
-from bundle_adjustment_amd import BundleAdjuster
+from bundle_adjustment_amd import BundleAdjuster, hip_backend
 from bundle_adjustment_amd.synthetic import make_config, problem_to_map
 from oracle import ba_oracle as o
 from tests.helpers import golden_cost_case, load_golden, rebuild_map
@@ -109,3 +109,23 @@ def test_integration_md_binding_runs():
     # default tolerances stop far from the last digit, and scale is a weak direction: loose on the parameters
     np.testing.assert_allclose(rv, cams_ref[1:, :3], atol=2e-3)
     np.testing.assert_allclose(pts, pts_ref, rtol=1e-2, atol=1e-2)
+
+
+def test_iteration_trace_matches_the_summary():
+    """ba_get_trace: one record per LM iteration of the last solve, consistent with the summary."""
+    from bundle_adjustment_amd.synthetic import make_problem
+    p = make_problem(10, 800, 5, seed=31, outlier_frac=0.02)
+    with hip_backend.Solver(0) as s:
+        s.set_problem(p)
+        assert s.trace() == []
+        out = s.solve(loss="huber", max_iters=25, ftol=1e-10, xtol=1e-12, gtol=1e-12, pcg_tol=1e-2)
+        tr = s.trace()
+    assert len(tr) == out["iterations"] and [t["iteration"] for t in tr] == list(range(1, len(tr) + 1))
+    assert sum(t["pcg_iterations"] for t in tr) == out["pcg_iterations"]
+    assert sum(t["accepted"] for t in tr) == out["accepted"]
+    assert abs(tr[0]["cost"] - out["initial_cost"]) <= 1e-12 * out["initial_cost"]
+    last_acc = [t for t in tr if t["accepted"]][-1]
+    assert abs(last_acc["cost_trial"] - out["final_cost"]) <= 1e-12 * out["final_cost"]
+    for t in tr:
+        assert (t["cost_trial"] < t["cost"]) == t["accepted"] or not np.isfinite(t["cost_trial"])
+        assert t["damping"] > 0 and t["seconds"] > 0 and t["step_norm"] >= 0

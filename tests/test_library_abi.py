@@ -33,10 +33,11 @@ def test_struct_layouts_match_header():
     assert C.sizeof(hb.BASummary) == 4 * 4 + 9 * 8
     assert C.sizeof(hb.BAProfile) == 2 * (16 * 4 + 16 * 8)
     hdr = open(os.path.join(ROOT, "include", "ba_hip.h")).read()
-    for struct, cls in (("ba_options", hb.BAOptions), ("ba_summary", hb.BASummary)):
+    assert C.sizeof(hb.BAIterRecord) == 4 * 4 + 7 * 8
+    for struct, cls in (("ba_options", hb.BAOptions), ("ba_summary", hb.BASummary), ("ba_iter_record", hb.BAIterRecord)):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, flags=re.S).group(1)
         names = re.findall(r"(?:int32_t|double)\s+([a-z_0-9]+)\s*;", body)
-        assert names == [n for n, _ in cls._fields_]
+        assert names == [n.rstrip("_") for n, _ in cls._fields_]          # (lambda_ <-> lambda: a Python keyword)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
