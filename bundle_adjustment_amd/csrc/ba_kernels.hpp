@@ -633,10 +633,37 @@ __device__ inline void load_cam_row(bool use_lds, const double* __restrict__ tab
 // loop pays one L2 round trip per 16 bytes (measured with in-kernel stamps at C3: 4.3 us for the 144 KB table,
 // 9 dependent round trips per thread).
 constexpr int FILL_BATCH = 9;
+#ifndef BA_FILL_DMA
+#define BA_FILL_DMA 1
+#endif
 template <int BLOCK>
 __device__ inline void fill_cam_table(double* __restrict__ tab, const double* __restrict__ camA, int lo, int n) {
   const double2* src = (const double2*)(camA + TA * (size_t)lo);
   const int total = n * TA / 2;
+#if BA_FILL_DMA
+  // LDS-DMA (global_load_lds_dwordx4, gfx950): 16 bytes per lane straight into LDS at (wave-uniform base) + lane * 16,
+  // no staging registers and no ds_write issue slots; a wave copies whole 1 KB pieces, the lanes past the end of the
+  // table sit out (an inactive lane neither loads nor stores).  The copy is invisible to the compiler: the explicit
+  // vmcnt(0) keeps every later LDS read behind it.
+  {
+    // Every workgroup copies the same table at the same time: each starts at a different piece, so that the
+    // workgroups of an XCD are not all on the same L2 channel at any moment.
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int npieces = (total + 63) / 64;
+    const int rot = (int)((blockIdx.x * 37u) % (unsigned)npieces);
+    for (int q = wave; q < npieces; q += BLOCK / 64) {
+      int piece = q + rot;
+      if (piece >= npieces) piece -= npieces;
+      const int i = piece * 64 + lane;
+      if (i < total)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i),
+                                         (__attribute__((address_space(3))) void*)(tab + piece * 128), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    return;
+  }
+#endif
   for (int base = threadIdx.x; base < total; base += BLOCK * FILL_BATCH) {
     double2 v[FILL_BATCH];
 #pragma unroll

@@ -30,6 +30,18 @@ def _sha(p):
     return h.hexdigest()
 
 
+def _scipy_run_converged(g):
+    """scipy itself reported gtol / ftol / xtol, or the RMSE moved by less than 2e-8 px over each of the last two chunks
+    of evaluations (the generator's own stopping rule), or -- fixtures written before the history was kept -- it ran
+    out its 3000 evaluations after the RMSE had stopped moving at the 1e-9 level (tests/golden/*.log)."""
+    if int(g["res_status"]) in (1, 2, 3, 4):
+        return True
+    if "rmse_history" in g.files:
+        h = g["rmse_history"]
+        return len(h) >= 3 and abs(h[-1, 1] - h[-2, 1]) < 2e-8 and abs(h[-2, 1] - h[-3, 1]) < 2e-8
+    return int(g["res_nfev"]) >= 3000
+
+
 def _have(cfg, loss):
     return os.path.exists(os.path.join(GOLDEN, f"conv_{cfg.lower()}_{loss}.npz"))
 
@@ -55,6 +67,9 @@ def test_converged_rmse_matches_scipy_path_at_baseline_sizes(cfg, loss):
         pytest.skip(f"conv_{cfg.lower()}_{loss}.npz not generated (see make_golden_converged.py)")
     from bundle_adjustment_amd import hip_backend
     g = load_golden(f"conv_{cfg.lower()}_{loss}")
+    if not _scipy_run_converged(g):
+        pytest.skip("the scipy run behind this fixture had not reached a stationary RMSE when it was written "
+                    "(make_golden_converged.py rewrites it after every chunk of evaluations)")
     p = make_config(cfg, seed=int(g["seed"]))
     assert _sha(p) == str(g["problem_sha256"])
     with hip_backend.Solver(0) as s:
