@@ -1084,6 +1084,38 @@ extern "C" int ba_residuals(ba_handle* h, int32_t loss, double f_scale, double* 
   return BA_OK;
 }
 
+// K1 for the BAL 9-parameter camera (row f2): same problem upload and row order as ba_residuals, the cameras'
+// (f, k1, k2) handed over per call; the handle's K4 is not used.
+extern "C" int ba_residuals_bal(ba_handle* h, const double* intr, int32_t loss, double f_scale, double* r, double* sse,
+                                double* cost) {
+  if (!h || !intr) return fail(BA_ERR_INVALID, "null argument");
+  if (!h->have_params) return fail(BA_ERR_STATE, "ba_set_problem / ba_set_params first");
+  if (loss != BA_LOSS_LINEAR && loss != BA_LOSS_HUBER) return fail(BA_ERR_INVALID, "unknown loss %d", loss);
+  if (!(f_scale > 0)) return fail(BA_ERR_INVALID, "f_scale must be positive");
+  if (set_device(h)) return BA_ERR_HIP;
+  HIPCHECK(h->tri.alloc(3 * (size_t)h->Nc + 8));
+  HIPCHECK(hipMemcpyAsync(h->tri.p, intr, 3 * (size_t)h->Nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  double* rdev = nullptr;
+  if (r && h->Nobs > 0) {
+    HIPCHECK(h->rbuf.alloc(2 * (size_t)h->Nobs));
+    rdev = h->rbuf.p;
+  }
+  {
+    Scope sc(h, BA_K_RESIDUAL);
+    auto kern = loss == BA_LOSS_HUBER ? k_cam_residual_bal<true> : k_cam_residual_bal<false>;
+    BA_LAUNCH(kern, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[h->cur].p, (const double*)h->tri.p, h->ptab[h->cur].p,
+              h->offk.p, h->c_pt.p, h->c_uv.p, h->c_orig.p, f_scale, h->Nc, h->cam_band, rdev, h->partR.p);
+  }
+  launch_scalars(h, false);
+  if (int rc = allreduce(h, h->scal.p, 2)) return rc;
+  HIPCHECK(hipMemcpyAsync(h->h_scal, h->scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (rdev) HIPCHECK(hipMemcpyAsync(r, rdev, 2 * (size_t)h->Nobs * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  BA_SYNC(h);
+  if (sse) *sse = h->h_scal[0];
+  if (cost) *cost = 0.5 * h->h_scal[1];
+  return BA_OK;
+}
+
 // --------------------------------------------------------------------- K2 entry point
 extern "C" int ba_linearize(ba_handle* h, int32_t loss, double f_scale, double* Hcc, double* bc, double* Hpp, double* bp) {
   if (!h) return fail(BA_ERR_INVALID, "null handle");

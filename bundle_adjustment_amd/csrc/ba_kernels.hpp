@@ -221,6 +221,48 @@ k_cam_residual(const double* __restrict__ cs, const double* __restrict__ ptab, c
   wave_store_sums<2>(acc, s.lane, partR + ((size_t)s.k * n_cams + s.c) * 2);
 }
 
+// K1 for the BAL 9-parameter camera (row f2; bal.py): intr[c] = (f, k1, k2), the camera looks down -z,
+// p = -P[:2] / P.z, projection f (1 + k1 |p|^2 + k2 |p|^4) p, origin at the image centre.  Same mapping, partial sums
+// and row order as k_cam_residual.
+template <bool ROBUST>
+__global__ void __launch_bounds__(64 * WPB)
+k_cam_residual_bal(const double* __restrict__ cs, const double* __restrict__ intr, const double* __restrict__ ptab,
+                   const int* __restrict__ offk, const int* __restrict__ c_pt, const double2* __restrict__ c_uv,
+                   const int* __restrict__ c_orig, double hub_c, int n_cams, int band,
+                   double* __restrict__ r_out, double* __restrict__ partR) {
+  Seg s;
+  if (!cam_segment(offk, n_cams, band, s)) return;
+  const double* cam = cs + CS * s.c;
+  const double f = intr[3 * s.c], k1 = intr[3 * s.c + 1], k2 = intr[3 * s.c + 2];
+  double acc[2] = {0.0, 0.0};
+  for (int i = s.beg + s.lane; i < s.end; i += 64) {
+    const int p = c_pt[i];
+    const double2 uv = c_uv[i];
+    const double4 X = *(const double4*)(ptab + PT * (size_t)p);
+    double xh, yh;
+    obs_project(cam, X.x, X.y, X.z, xh, yh);             // P.x / P.z, P.y / P.z  (z == 0 guarded as in cv2)
+    const double px = -xh, py = -yh;
+    const double n2 = px * px + py * py;
+    const double rad = f * (1.0 + n2 * (k1 + k2 * n2));
+    const double ru = uv.x - rad * px;
+    const double rv = uv.y - rad * py;
+    acc[0] += ru * ru + rv * rv;
+    if (ROBUST) {
+      double t0, t1, w;
+      huber(ru, hub_c, t0, w);
+      huber(rv, hub_c, t1, w);
+      acc[1] += t0 + t1;
+    }
+    if (r_out) {
+      const int o = c_orig[i];
+      r_out[2 * (size_t)o] = ru;
+      r_out[2 * (size_t)o + 1] = rv;
+    }
+  }
+  if (!ROBUST) acc[1] = acc[0];
+  wave_store_sums<2>(acc, s.lane, partR + ((size_t)s.k * n_cams + s.c) * 2);
+}
+
 // rows of the pre-M camera Jacobian: J0 = [P0 x X | -d00 0 -d02], J1 = [P1 x X | 0 -d11 -d12]
 __device__ inline void cam_jac_rows(const Geom& g, double X0, double X1, double X2, double (&J0)[6], double (&J1)[6]) {
   J0[0] = g.P[1] * X2 - g.P[2] * X1; J0[1] = g.P[2] * X0 - g.P[0] * X2; J0[2] = g.P[0] * X1 - g.P[1] * X0;

@@ -79,6 +79,7 @@ SYMBOLS = {
     "ba_get_rotations": (C.c_int, [C.c_void_p, _DP]),
     "ba_allgather_points": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _DP]),
     "ba_residuals": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _DP, _DP, _DP]),
+    "ba_residuals_bal": (C.c_int, [C.c_void_p, _DP, C.c_int32, C.c_double, _DP, _DP, _DP]),
     "ba_linearize": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _DP, _DP, _DP, _DP]),
     "ba_schur_rhs": (C.c_int, [C.c_void_p, C.c_double, _DP]),
     "ba_schur_apply": (C.c_int, [C.c_void_p, C.c_double, _DP, _DP]),
@@ -242,6 +243,18 @@ class Solver:
         s = BASummary()
         _check(self._lib.ba_solve(self._h, C.byref(o), C.byref(s)))
         return s.as_dict()
+
+    def residuals_bal(self, bal, loss="linear", f_scale=1.0, want_vector=True):
+        """BAL 9-parameter camera residuals (bal.BALProblem) on the GPU: uploads the problem, returns (r, sse, cost)."""
+        from .problem import BAProblem
+        self.set_problem(BAProblem(np.ascontiguousarray(bal.cams[:, :6]), bal.pts, bal.cam_idx, bal.pt_idx, bal.uv,
+                                   np.array([1.0, 1.0, 0.0, 0.0]), -1))
+        intr = np.ascontiguousarray(bal.cams[:, 6:9], dtype=np.float64)
+        r = np.empty((self.n_obs, 2)) if want_vector else None
+        sse, cost = C.c_double(0), C.c_double(0)
+        _check(self._lib.ba_residuals_bal(self._h, _dp(intr), LOSS[loss] if isinstance(loss, str) else loss, float(f_scale),
+                                          _dp(r), C.byref(sse), C.byref(cost)))
+        return r, sse.value, cost.value
 
     def triangulate(self, camera_matrix, R_rel, t_rel, pts1, pts2):
         """ba_triangulate: (n,3) points in the first camera's frame and the (n,) cheirality mask."""

@@ -161,6 +161,12 @@ int ba_allgather_points(ba_handle* h, int64_t p_begin, int64_t n_total, double* 
  * r may be NULL.  sse = sum r^2 (":165"), cost = 0.5 sum rho(r^2) for `loss`. */
 int ba_residuals(ba_handle* h, int32_t loss, double f_scale, double* r, double* sse, double* cost);
 
+/* K1 for the BAL 9-parameter camera [rvec | t | f k1 k2] (grail.cs.washington.edu/projects/bal; SURVEY.md 8f row 2;
+ * the reference has no counterpart: its only camera is cv2.projectPoints(..., distCoeffs=None), :67): cameras (rvec, t)
+ * and points as set by ba_set_params, intr double[Nc][3] = (f, k1, k2) per camera, pixels relative to the image
+ * centre, the camera looking down -z.  Same row order and outputs as ba_residuals. */
+int ba_residuals_bal(ba_handle* h, const double* intr, int32_t loss, double f_scale, double* r, double* sse, double* cost);
+
 /* K2/K3: linearise at the current parameters.  Outputs (any may be NULL):
  *   Hcc double[Nc][21]  upper triangle of Jc^T w Jc, row-major (00 01 .. 05 11 .. 55)
  *   bc  double[Nc][6]   Jc^T w r

@@ -611,3 +611,59 @@ def triangulate_points(K, R_rel, t_rel, pts1, pts2):
     xyz = X[:, :3] / (X[:, 3:] + 1e-6)
     z2 = (xyz @ R.T + t.ravel())[:, 2]
     return xyz, (xyz[:, 2] > 0) & (z2 > 0)
+
+
+# ---------------------------------------------------------------------------
+# BAL 9-parameter camera (row f2): [rvec | t | f k1 k2], p = -P[:2]/P[2], proj = f (1 + k1 |p|^2 + k2 |p|^4) p
+# ---------------------------------------------------------------------------
+def bal_residuals(cams9, pts, cam_idx, pt_idx, uv):
+    """observed - projected for the BAL camera model (grail.cs.washington.edu/projects/bal), (Nobs, 2)."""
+    cams9 = np.asarray(cams9, dtype=np.float64).reshape(-1, 9)
+    R = rodrigues_batch(cams9[:, :3])
+    P = np.einsum('nij,nj->ni', R[cam_idx], np.asarray(pts, dtype=np.float64)[pt_idx]) + cams9[cam_idx, 3:6]
+    p = -P[:, :2] / P[:, 2:3]
+    n2 = (p * p).sum(axis=1)
+    f, k1, k2 = cams9[cam_idx, 6], cams9[cam_idx, 7], cams9[cam_idx, 8]
+    rad = 1.0 + k1 * n2 + k2 * n2 * n2
+    return np.asarray(uv, dtype=np.float64) - (f * rad)[:, None] * p
+
+
+def bal_jacobian_blocks(cams9, pts, cam_idx, pt_idx):
+    """Analytic blocks of the BAL residual: Jc (Nobs, 2, 9) w.r.t. [rvec | t | f k1 k2] (additive rotation-vector update,
+    like the 6-parameter blocks above) and Jp (Nobs, 2, 3) w.r.t. the point."""
+    cams9 = np.asarray(cams9, dtype=np.float64).reshape(-1, 9)
+    pts = np.asarray(pts, dtype=np.float64)
+    R = rodrigues_batch(cams9[:, :3])[cam_idx]
+    M = so3_right_jacobian(cams9[:, :3])[cam_idx]
+    X = pts[pt_idx]
+    P = np.einsum('nij,nj->ni', R, X) + cams9[cam_idx, 3:6]
+    iz = 1.0 / P[:, 2]
+    p = -P[:, :2] * iz[:, None]
+    n2 = (p * p).sum(axis=1)
+    f, k1, k2 = cams9[cam_idx, 6], cams9[cam_idx, 7], cams9[cam_idx, 8]
+    rad = 1.0 + k1 * n2 + k2 * n2 * n2
+    drad = k1 + 2.0 * k2 * n2                                   # d rad / d n2
+    n = len(cam_idx)
+    # d proj / d p  (2x2) = f (rad I + 2 drad p p^T)
+    dproj_dp = f[:, None, None] * (rad[:, None, None] * np.eye(2)[None] + 2.0 * drad[:, None, None] * p[:, :, None] * p[:, None, :])
+    # d p / d P (2x3) = -1/Pz [I | -P[:2]/Pz] = [-iz 0 Px iz^2; 0 -iz Py iz^2]
+    dp_dP = np.zeros((n, 2, 3))
+    dp_dP[:, 0, 0] = -iz
+    dp_dP[:, 1, 1] = -iz
+    dp_dP[:, 0, 2] = P[:, 0] * iz * iz
+    dp_dP[:, 1, 2] = P[:, 1] * iz * iz
+    dproj_dP = np.einsum('nij,njk->nik', dproj_dp, dp_dP)      # (n,2,3)
+    Jp = -np.einsum('nij,njk->nik', dproj_dP, R)               # residual = uv - proj
+    Xx = np.zeros((n, 3, 3))
+    Xx[:, 0, 1], Xx[:, 0, 2] = -X[:, 2], X[:, 1]
+    Xx[:, 1, 0], Xx[:, 1, 2] = X[:, 2], -X[:, 0]
+    Xx[:, 2, 0], Xx[:, 2, 1] = -X[:, 1], X[:, 0]
+    # d (R X) / d rvec = -R [X]x M
+    dP_dr = -np.einsum('nij,njk,nkl->nil', R, Xx, M)
+    Jc = np.zeros((n, 2, 9))
+    Jc[:, :, :3] = -np.einsum('nij,njk->nik', dproj_dP, dP_dr)
+    Jc[:, :, 3:6] = -dproj_dP
+    Jc[:, :, 6] = -(rad[:, None] * p)
+    Jc[:, :, 7] = -(f * n2)[:, None] * p
+    Jc[:, :, 8] = -(f * n2 * n2)[:, None] * p
+    return Jc, Jp
