@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--pcg-tol", type=float, default=0.1)
     ap.add_argument("--pcg-max-iters", type=int, default=200)
-    ap.add_argument("--precond", default="schur_jacobi", choices=["schur_jacobi", "jacobi"])
+    ap.add_argument("--precond", default="schur_jacobi", choices=["schur_jacobi", "jacobi", "two_level"])
     ap.add_argument("--jacobian", default="f64", choices=["f64", "f32"], help="f32: config 5's fp32 Jacobian blocks in the PCG passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=11, help="timed repeats of the K-step solve; value = the median repeat")

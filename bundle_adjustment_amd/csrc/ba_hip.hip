@@ -32,6 +32,7 @@
 #include "../../include/ba_hip.h"
 #include "ba_kernels.hpp"
 #include "ba_triangulate.hpp"
+#include "ba_coarse.hpp"
 
 using namespace ba;
 
@@ -168,6 +169,14 @@ struct ba_handle {
   DBuf<double> gvec, x, r, p, s, z, vin, scal, rbuf, gather;
   DBuf<PcgState> st;
   DBuf<double> tri;            // staging of ba_triangulate
+  // two-level preconditioner for band-structured problems (ba_coarse.hpp): structures built by ba_set_problem
+  bool two_level_ok = false;   // this problem has them
+  bool two_level = false;      // the current solve uses them
+  int n_agg = 0, n_runs = 0, n_pairs = 0, coarse_bw = 0;
+  DBuf<int> run_beg, run_pt, run_agg;
+  DBuf<int2> run_pairs;
+  DBuf<double> coarseU, coarseE, coarseEinv, coarse_rc, coarse_info;
+  DBuf<long long> coarseEint;
   DBuf<double> verdict;        // PCG verdict words {gamma, zeta, finished, -} x 2 iteration parities (point pass -> camera pass, vector kernel)
   int cam_segl = 64;           // lanes per (camera, partition) segment in the PCG camera pass (BA_CAM_SEGL, tuning)
   int nblkP = 1, ppb = 1, nblkV = 1;
@@ -318,6 +327,9 @@ extern "C" int ba_destroy(ba_handle* h) {
   for (auto b : db) b->release();
   h->st.release();
   h->tri.release();
+  h->run_beg.release(); h->run_pt.release(); h->run_agg.release(); h->run_pairs.release();
+  h->coarseU.release(); h->coarseE.release(); h->coarseEinv.release(); h->coarse_rc.release(); h->coarse_info.release();
+  h->coarseEint.release();
   h->verdict.release();
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->h_flags) (void)hipHostFree(h->h_flags);
@@ -572,6 +584,74 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   for (int i = 0; i < No; ++i) pt_new[i] = slot[pt_idx[i]];
   pt_idx = pt_new.data();
   stage("point numbering");
+  // point-pass workgroups: contiguous point ranges, PT_THREADS / LPP points per round.  When the
+  // whole camera table fits in LDS (so a wider range cannot overflow it) no more workgroups are
+  // started than the chip holds at once -- each then walks several rounds with one table fill
+  // (C3 x 10: Schur point pass 133 -> 93 us); with camera windows the ranges stay one round long
+  // so that the windows stay narrow.  BA_PT_BLOCKS overrides (tuning only).
+  // A smaller problem (a sliding window, a shard of a multi-GPU job) gives every point 4, 8 or 16 lanes
+  // instead of 2 -- more workgroups, fewer observations per lane -- the most for which the
+  // workgroups are still all resident at once.  BA_PT_LANES overrides (tuning only).
+  const size_t full_table = (size_t)Nc * TA * sizeof(double);
+  const bool table_fits = full_table <= (size_t)LDS_TAB_BYTES;
+  const int per_cu = !table_fits ? 1 : (int)std::max<size_t>(1, std::min<size_t>(2048 / PT_THREADS, (size_t)(160 * 1024) / (full_table + 1024)));
+  h->lanes = LPP;
+  for (int ln = 16; ln > LPP; ln >>= 1)
+    if ((Np + PT_THREADS / ln - 1) / (PT_THREADS / ln) <= h->n_cu * per_cu) { h->lanes = ln; break; }
+  if (const char* e = getenv("BA_PT_LANES")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) h->lanes = v; }
+  const int pts_per_pass = PT_THREADS / h->lanes;
+  const int want = std::max(1, (Np + pts_per_pass - 1) / pts_per_pass);
+  h->nblkP = std::min(want, 4096);
+  if (table_fits) h->nblkP = std::min(h->nblkP, h->n_cu * per_cu);
+  if (const char* e = getenv("BA_PT_BLOCKS")) h->nblkP = std::max(1, std::min(want, atoi(e)));
+  if (const char* e = getenv("BA_XCD_RANGES")) h->xcd_ranges = atoi(e) != 0;
+  if (const char* e = getenv("BA_CAM_SEGL")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) h->cam_segl = v; }
+  h->ppb = std::max(1, (Np + h->nblkP - 1) / h->nblkP);
+  // ---- bank-aware visiting order inside a point (2-lane point passes with the camera table in LDS).
+  // A point pass reads a camera's 144-byte LDS row with nine ds_read_b128; the hardware serves such a read in groups of
+  // 16 lanes, and two lanes of a group collide when their rows fall into the same of 16 bank classes (row mod 16: the
+  // row stride is 36 dwords).  With random cameras a group sees ~3 lanes per class: SQ_LDS_BANK_CONFLICT was 64 % of
+  // the LDS cycles (profiles/).  The ORDER in which a point's observations are visited is free, so it is chosen here,
+  // greedily per group of eight points and per step, so that the sixteen rows read together are in distinct classes
+  // wherever the data allows.  Pure scheduling: every sum keeps a fixed order, results stay bit-reproducible.
+  auto bank_aware_order = [&](std::vector<int>& p_cam, std::vector<int>& p_src, const std::vector<int>& pt_off) {
+    if (h->lanes != LPP || !table_fits || getenv("BA_NO_BANK_ORDER")) return;
+    // b128 lane groups of a 32-lane half (MI355X_MICROARCH.md, LDS): {0-3,12-15,20-27} and {4-11,16-19,28-31};
+    // with 2 lanes per point, lane pair q of a half <-> point q of a 16-point chunk
+    static const int group_of_pair[16] = {0, 0, 1, 1, 1, 1, 0, 0, 1, 1, 0, 0, 0, 0, 1, 1};
+    std::vector<int> tmp_c, tmp_s;
+    for (int b = 0; b < h->nblkP; ++b) {
+      const int p0 = std::min(Np, b * h->ppb), p1 = std::min(Np, (b + 1) * h->ppb);
+      for (int c0 = p0; c0 < p1; c0 += 16) {              // one 32-lane half: 16 points, two groups of 8
+        for (int g = 0; g < 2; ++g) {
+          int pts[8], npts = 0;
+          for (int q = 0; q < 16 && c0 + q < p1; ++q)
+            if (group_of_pair[((c0 - p0) + q) & 15] == g) pts[npts++] = c0 + q;
+          int maxlen = 0;
+          for (int i = 0; i < npts; ++i) maxlen = std::max(maxlen, pt_off[pts[i] + 1] - pt_off[pts[i]]);
+          if (maxlen > 64) continue;                      // (long tracks: their own launch, other mapping)
+          // remaining observations of each point as a small list; at every step each point places up to two
+          int cur[8];
+          for (int i = 0; i < npts; ++i) cur[i] = pt_off[pts[i]];
+          for (int step = 0; 2 * step < maxlen; ++step) {
+            unsigned used = 0;                            // bank classes taken in this step
+            for (int i = 0; i < npts; ++i) {
+              const int end = pt_off[pts[i] + 1];
+              for (int sub = 0; sub < 2 && cur[i] < end; ++sub) {
+                int pick = cur[i];
+                for (int j = cur[i]; j < end; ++j)
+                  if (!(used >> (p_cam[j] & 15) & 1u)) { pick = j; break; }
+                used |= 1u << (p_cam[pick] & 15);
+                std::swap(p_cam[pick], p_cam[cur[i]]);
+                std::swap(p_src[pick], p_src[cur[i]]);
+                ++cur[i];
+              }
+            }
+          }
+        }
+      }
+    }
+  };
   // point order: stable counting sort by point (keeps the caller's order inside a point)
   std::vector<int> pt_off(Np + 1, 0);
   for (int i = 0; i < No; ++i) pt_off[pt_idx[i] + 1]++;
@@ -585,6 +665,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
       p_cam[b] = cam_idx[i]; p_src[b] = i;
     }
   }
+  bank_aware_order(p_cam, p_src, pt_off);
   stage("sort by point");
   // camera order: stable counting sort of the POINT-ordered list by camera, so that every
   // camera's observations are ascending in point index (needed by the partition split)
@@ -634,32 +715,61 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     if (const char* e = getenv("BA_CAM_BAND")) h->cam_band = atoi(e) != 0;
   }
   stage("partitions + XCD statistic");
+  // ---- two-level preconditioner structures (ba_coarse.hpp), for band-structured problems on one rank: observations
+  // inside a point sorted by camera, so that a point's observations of one 16-camera aggregate are one RUN
+  std::vector<int> run_beg, run_pt, run_agg;
+  std::vector<int2> run_pairs;
+  h->two_level_ok = false;
+  {
+    // band statistic: mean camera span of a track against the number of cameras (sequential captures: a few
+    // cameras; random visibility: most of the range)
+    double span_sum = 0.0;
+    long long tracks = 0;
+    for (int p = 0; p < Np; ++p) {
+      if (pt_off[p + 1] == pt_off[p]) continue;
+      int lo = Nc, hi = -1;
+      for (int j = pt_off[p]; j < pt_off[p + 1]; ++j) { lo = std::min(lo, p_cam[j]); hi = std::max(hi, p_cam[j]); }
+      span_sum += hi - lo;
+      ++tracks;
+    }
+    bool want = tracks > 0 && span_sum / tracks <= Nc / 8.0 && h->world == 1;
+    if (const char* e = getenv("BA_TWO_LEVEL")) want = atoi(e) != 0 && h->world == 1;
+    if (want && Nc >= 2 * VEC_CAMS && Np > 0 && No > 0) {
+      std::vector<std::pair<int, int>> tmp;
+      int bwa = 0;
+      for (int p = 0; p < Np; ++p) {
+        const int b = pt_off[p], e = pt_off[p + 1];
+        tmp.resize(e - b);
+        for (int j = b; j < e; ++j) tmp[j - b] = std::make_pair(p_cam[j], p_src[j]);
+        std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first < y.first; });
+        for (int j = b; j < e; ++j) { p_cam[j] = tmp[j - b].first; p_src[j] = tmp[j - b].second; }
+        const int first_run = (int)run_pt.size();
+        for (int j = b; j < e;) {
+          const int a = p_cam[j] / VEC_CAMS;
+          run_beg.push_back(j); run_pt.push_back(p); run_agg.push_back(a);
+          while (j < e && p_cam[j] / VEC_CAMS == a) ++j;
+        }
+        const int last_run = (int)run_pt.size();
+        for (int r1 = first_run; r1 < last_run; ++r1)
+          for (int r2 = r1; r2 < last_run; ++r2) {
+            run_pairs.push_back(make_int2(r1, r2));
+            bwa = std::max(bwa, run_agg[r2] - run_agg[r1]);
+          }
+      }
+      run_beg.push_back(No);
+      h->n_agg = (Nc + VEC_CAMS - 1) / VEC_CAMS;
+      h->n_runs = (int)run_pt.size();
+      h->n_pairs = (int)run_pairs.size();
+      h->coarse_bw = std::min(6 * h->n_agg - 1, 6 * bwa + 5);
+      // the banded factorisation keeps one column of the band in LDS (512 words) and E^-1 is dense: give up the
+      // coarse level when the problem is not band-structured enough for either
+      h->two_level_ok = h->coarse_bw <= 500 && 6 * h->n_agg <= 4096;
+    }
+  }
+  stage("coarse-level structures");
   h->Nc = Nc; h->Np = Np; h->Nobs = No; h->fixed = fixed_cam;
   memcpy(h->K4, K4, sizeof h->K4);
   h->nblkV = (Nc + VEC_CAMS - 1) / VEC_CAMS;
-  // point-pass workgroups: contiguous point ranges, PT_THREADS / LPP points per round.  When the
-  // whole camera table fits in LDS (so a wider range cannot overflow it) no more workgroups are
-  // started than the chip holds at once -- each then walks several rounds with one table fill
-  // (C3 x 10: Schur point pass 133 -> 93 us); with camera windows the ranges stay one round long
-  // so that the windows stay narrow.  BA_PT_BLOCKS overrides (tuning only).
-  // A smaller problem (a sliding window, a shard of a multi-GPU job) gives every point 4, 8 or 16 lanes
-  // instead of 2 -- more workgroups, fewer observations per lane -- the most for which the
-  // workgroups are still all resident at once.  BA_PT_LANES overrides (tuning only).
-  const size_t full_table = (size_t)Nc * TA * sizeof(double);
-  const bool table_fits = full_table <= (size_t)LDS_TAB_BYTES;
-  const int per_cu = !table_fits ? 1 : (int)std::max<size_t>(1, std::min<size_t>(2048 / PT_THREADS, (size_t)(160 * 1024) / (full_table + 1024)));
-  h->lanes = LPP;
-  for (int ln = 16; ln > LPP; ln >>= 1)
-    if ((Np + PT_THREADS / ln - 1) / (PT_THREADS / ln) <= h->n_cu * per_cu) { h->lanes = ln; break; }
-  if (const char* e = getenv("BA_PT_LANES")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) h->lanes = v; }
-  const int pts_per_pass = PT_THREADS / h->lanes;
-  const int want = std::max(1, (Np + pts_per_pass - 1) / pts_per_pass);
-  h->nblkP = std::min(want, 4096);
-  if (table_fits) h->nblkP = std::min(h->nblkP, h->n_cu * per_cu);
-  if (const char* e = getenv("BA_PT_BLOCKS")) h->nblkP = std::max(1, std::min(want, atoi(e)));
-  if (const char* e = getenv("BA_XCD_RANGES")) h->xcd_ranges = atoi(e) != 0;
-  if (const char* e = getenv("BA_CAM_SEGL")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) h->cam_segl = v; }
-  h->ppb = std::max(1, (Np + h->nblkP - 1) / h->nblkP);
   // long tracks: one DPP row (16 lanes) per point in a launch of their own
   std::vector<int> long_pts;
   {   // long = more than max(8, 2 x median track length) observations (BA_LONG_TRACK overrides)
@@ -735,6 +845,17 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   DBuf<double>* v6[] = {&h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin};
   for (auto b : v6) HIPCHECK(b->alloc(6 * (size_t)Nc));
   HIPCHECK(h->scal.alloc(64));
+  if (h->two_level_ok) {
+    const size_t nc6 = 6 * (size_t)h->n_agg;
+    HIPCHECK(h->run_beg.alloc(run_beg.size())); HIPCHECK(h->run_pt.alloc(run_pt.size())); HIPCHECK(h->run_agg.alloc(run_agg.size()));
+    HIPCHECK(h->run_pairs.alloc(run_pairs.size()));
+    HIPCHECK(hipMemcpyAsync(h->run_beg.p, run_beg.data(), run_beg.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipMemcpyAsync(h->run_pt.p, run_pt.data(), run_pt.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipMemcpyAsync(h->run_agg.p, run_agg.data(), run_agg.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipMemcpyAsync(h->run_pairs.p, run_pairs.data(), run_pairs.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h->coarseU.alloc(18 * (size_t)h->n_runs)); HIPCHECK(h->coarseE.alloc(nc6 * nc6)); HIPCHECK(h->coarseEinv.alloc(nc6 * nc6));
+    HIPCHECK(h->coarseEint.alloc(nc6 * nc6)); HIPCHECK(h->coarse_rc.alloc(nc6)); HIPCHECK(h->coarse_info.alloc(8));
+  }
   HIPCHECK(h->st.alloc(2));
   HIPCHECK(h->verdict.alloc(8));
   HIPCHECK(hipMemsetAsync(h->verdict.p, 0, 8 * sizeof(double), h->stream));
@@ -1055,7 +1176,7 @@ static void launch_pcg_setup(ba_handle* h, double lambda, bool schur_diag, bool 
   Scope sc(h, BA_K_PCG_UPDATE);
 #define SU_ARGS h->partL[h->lb].p, h->HccBc.p, bc_ptr(h), p6_ptr(h), h->partE.p, NPART, h->cs[h->cur].p, lambda,           \
                 schur_diag ? 1 : 0, h->Nc, h->fixed, h->Hccd.p, h->Minv.p, h->gvec.p, h->x.p, h->r.p, h->p.p, h->s.p,     \
-                h->z.p, h->camA[h->cur].p, h->partV.p, h->st.p, h->partGc.p
+                h->z.p, h->camA[h->cur].p, h->partV.p, h->st.p, h->partGc.p, (h->two_level ? h->coarse_rc.p : (double*)nullptr)
   if (finalize) BA_LAUNCH((k_pcg_setup<true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);
   else          BA_LAUNCH((k_pcg_setup<false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);
 #undef SU_ARGS
@@ -1147,14 +1268,46 @@ extern "C" int ba_linearize(ba_handle* h, int32_t loss, double f_scale, double* 
   return BA_OK;
 }
 
+// Two-level preconditioner: E = P^T S P at the current damping, its banded factor and explicit inverse, then the first
+// PCG vectors redone with the coarse term (k_pcg_coarse with k = -1 writes the partials iteration 0's probe sums).
+static void coarse_build(ba_handle* h) {
+  const int n = 6 * h->n_agg;
+  const bool robust = h->lin_robust;
+  Scope sc(h, BA_K_PRECOND);
+  (void)hipMemsetAsync(h->coarseEint.p, 0, (size_t)n * n * sizeof(long long), h->stream);
+  BA_LAUNCH(k_coarse_diag, dim3(1), dim3(1024), 0, h->stream, (const double*)h->Hccd.p, h->Nc, h->fixed, h->n_agg, h->coarseEint.p,
+            h->coarse_info.p);
+  if (robust)
+    BA_LAUNCH(k_coarse_runs<true>, dim3((h->n_runs + 255) / 256), dim3(256), 0, h->stream, (const double*)h->cs[h->cur].p,
+              (const double*)h->ptab[h->cur].p, (const int*)h->run_beg.p, (const int*)h->run_pt.p, (const int*)h->p_camf[h->pb].p,
+              (const double2*)h->p_w[h->pb].p, h->K4[0], h->K4[1], h->fixed, h->n_runs, h->coarseU.p);
+  else
+    BA_LAUNCH(k_coarse_runs<false>, dim3((h->n_runs + 255) / 256), dim3(256), 0, h->stream, (const double*)h->cs[h->cur].p,
+              (const double*)h->ptab[h->cur].p, (const int*)h->run_beg.p, (const int*)h->run_pt.p, (const int*)h->p_cam.p,
+              (const double2*)h->p_w[h->pb].p, h->K4[0], h->K4[1], h->fixed, h->n_runs, h->coarseU.p);
+  BA_LAUNCH(k_coarse_pairs, dim3((h->n_pairs + 255) / 256), dim3(256), 0, h->stream, (const int2*)h->run_pairs.p, h->n_pairs,
+            (const int*)h->run_pt.p, (const int*)h->run_agg.p, (const double*)h->coarseU.p, (const double*)h->Hppinv[h->pb].p,
+            h->n_agg, (const double*)h->coarse_info.p, (unsigned long long*)h->coarseEint.p);
+  BA_LAUNCH(k_coarse_to_double, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, h->stream,
+            (const long long*)h->coarseEint.p, n, (const double*)h->coarse_info.p, h->coarseE.p);
+  BA_LAUNCH(k_coarse_cholesky, dim3(1), dim3(1024), 0, h->stream, h->coarseE.p, n, h->coarse_bw);
+  BA_LAUNCH(k_coarse_inverse, dim3((n + 63) / 64), dim3(64), 0, h->stream, (const double*)h->coarseE.p, n, h->coarse_bw,
+            h->coarseEinv.p);
+  BA_LAUNCH(k_pcg_coarse, dim3(h->n_agg), dim3(VEC_BLOCK), 0, h->stream, -1, (const double*)h->coarseEinv.p,
+            (const double*)h->coarse_rc.p, h->n_agg, (const double*)h->Hccd.p, (const double*)h->cs[h->cur].p, h->Nc, h->fixed,
+            (const double*)h->r.p, h->z.p, h->camA[h->cur].p, h->partV.p, h->nblkV, (const double*)h->verdict.p, 0);
+}
+
 // --------------------------------------------------------------------- K4 test hooks
 // invert: (re)compute the damped point inverses (not needed right after launch_lin_pt at the
 // same lambda); finalize: Hcc | bc still have to be folded from the camera-half partials
+static void coarse_build(ba_handle* h);
 static int damped_system(ba_handle* h, double lambda, bool schur_diag, bool invert = true, bool finalize = false) {
   if (invert) launch_point_invert(h, lambda);
   launch_cam_schur(h, h->lin_robust, schur_diag, false, 0, 0.0, 0);
   if (int rc = exchange_schur(h, schur_diag)) return rc;
   launch_pcg_setup(h, lambda, schur_diag, finalize);
+  if (h->two_level) coarse_build(h);
   return BA_OK;
 }
 
@@ -1241,6 +1394,7 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     if (h->profile) flush_profile(h);
     h->profile = false;
     h->jac_f32 = false;
+    h->two_level = false;
     h->linearized = false;
     g_err = msg;
   }
@@ -1260,7 +1414,12 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   roctx_load();
   Range r_solve("ba_solve");
   const bool robust = opts->loss == BA_LOSS_HUBER;
-  const bool schur_diag = opts->preconditioner == BA_PRECOND_SCHUR_JACOBI;
+  if (opts->preconditioner < BA_PRECOND_JACOBI || opts->preconditioner > BA_PRECOND_TWO_LEVEL) return fail(BA_ERR_INVALID, "unknown preconditioner");
+  if (opts->preconditioner == BA_PRECOND_TWO_LEVEL && !h->two_level_ok)
+    return fail(BA_ERR_STATE, "the two-level preconditioner needs a band-structured problem on a single rank "
+                              "(ba_set_problem found none for this one)");
+  const bool schur_diag = opts->preconditioner != BA_PRECOND_JACOBI;
+  h->two_level = opts->preconditioner == BA_PRECOND_TWO_LEVEL;
   const double fs = opts->f_scale;
   const int Nc = h->Nc;
   h->profile = opts->profile != 0;
@@ -1345,10 +1504,18 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       launch_cam_schur(h, robust, false, true, kk, tol2, opts->pcg_min_iters);
       if (int rc = exchange_schur(h, false)) return rc;
       Scope sc(h, BA_K_PCG_UPDATE);
-      BA_LAUNCH(k_pcg_step, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, kk, p6_ptr(h), NPART,
-                         (const double*)uy_ptr(h), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc,
-                         h->fixed, tol2, opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA[h->cur].p,
-                         h->partV.p, h->nblkV, h->st.p, h->d_flags, base, (const double*)h->verdict.p);
+#define STEP_ARGS kk, p6_ptr(h), NPART, (const double*)uy_ptr(h), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc, h->fixed, tol2,       \
+                  opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA[h->cur].p, h->partV.p, h->nblkV, h->st.p, \
+                  h->d_flags, base, (const double*)h->verdict.p
+      if (h->two_level) {
+        BA_LAUNCH(k_pcg_step<true>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, h->coarse_rc.p);
+        BA_LAUNCH(k_pcg_coarse, dim3(h->n_agg), dim3(VEC_BLOCK), 0, h->stream, kk, (const double*)h->coarseEinv.p,
+                  (const double*)h->coarse_rc.p, h->n_agg, (const double*)h->Hccd.p, (const double*)h->cs[h->cur].p, Nc, h->fixed,
+                  (const double*)h->r.p, h->z.p, h->camA[h->cur].p, h->partV.p, h->nblkV, (const double*)h->verdict.p, 1);
+      } else {
+        BA_LAUNCH(k_pcg_step<false>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, (double*)nullptr);
+      }
+#undef STEP_ARGS
       return BA_OK;
     };
     Range* r_pcg = new Range("pcg");
@@ -1455,6 +1622,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   if (h->profile) flush_profile(h);
   h->profile = false;
   h->jac_f32 = false;
+  h->two_level = false;
   return BA_OK;
 }
 

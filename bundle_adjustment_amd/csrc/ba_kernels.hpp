@@ -1187,7 +1187,9 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
             int use_schur_diag, int n_cams, int fixed_cam, double* __restrict__ Hccd, double* __restrict__ Minv,
             double* __restrict__ gvec, double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
             double* __restrict__ s, double* __restrict__ z, double* __restrict__ vtil,
-            double* __restrict__ partV, PcgState* __restrict__ st, double* __restrict__ partGc) {
+            double* __restrict__ partV, PcgState* __restrict__ st, double* __restrict__ partGc, double* __restrict__ rc) {
+  // (rc != null: two-level preconditioner -- also the aggregate's restricted right-hand side; z, partV and vtil written
+  // here are then the single-level ones and are redone by k_pcg_coarse once E^-1 exists)
   // LDS image of the workgroup's VC cameras.  Inputs: partition-folded sums (a: 27 of the linearisation when
   // FINALIZE, e: 21 Schur-Jacobi, w6: 6 of W y0), Hcc | bc (when not FINALIZE), cs.  Outputs staged for a
   // coalesced write-back: Hcc | bc (FINALIZE), Hccd, Minv, g = r, z (x = p = s = 0 written directly).
@@ -1248,6 +1250,7 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
   }
   __syncthreads();
   double acc[2] = {0, 0};
+  double gsum[6] = {0, 0, 0, 0, 0, 0};
   double gmc = 0.0;
   const int t = threadIdx.x;
   if (c < n_cams) {
@@ -1288,8 +1291,17 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
       l_z[6 * t + q] = zz[q];
       acc[0] += g[q] * zz[q];
       acc[1] += zz[q] * hz[q];
+      gsum[q] = g[q];
     }
     write_vtil(M, zz, vtil + TA * c + 12);
+  }
+  if (rc) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) gsum[q] = wave_total_dpp(gsum[q]);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) rc[6 * blockIdx.x + q] = gsum[q];
+    }
   }
   __syncthreads();
   // ---- coalesced write-back
@@ -1326,6 +1338,9 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
 // Every workgroup recomputes the scalars from the same words; workgroup 0 publishes the
 // next state into the other parity slot.  uy_src: the u.y word (folded by k_cam_schur's
 // extra workgroup, or all-reduced in a multi-rank job).
+// COARSE (two-level preconditioner, ba_coarse.hpp): the kernel stops after r and zJ = M_J^-1 r and leaves the
+// aggregate's restricted residual in rc; z, the dot products and vtil are finished by k_pcg_coarse.
+template <bool COARSE>
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __restrict__ uy_src,
            const double* __restrict__ Hccd, const double* __restrict__ Minv, const double* __restrict__ cs,
@@ -1333,7 +1348,7 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
            double* __restrict__ x, double* __restrict__ r, double* __restrict__ p, double* __restrict__ s,
            double* __restrict__ z, double* __restrict__ vtil, double* __restrict__ partV, int nblkV,
            PcgState* __restrict__ st, long long* __restrict__ host_flag, long long flag_base,
-           const double* __restrict__ verdict) {
+           const double* __restrict__ verdict, double* __restrict__ rc) {
   // LDS image of the workgroup's cameras: Hccd | Minv | z p s r x | part6[NPART] | cs
   __shared__ double l_h[21 * VC], l_mi[21 * VC], l_v[5][6 * VC], l_p6[NPART][6 * VC], l_cs[CS * VC];
   BA_STAMP(2, 0); BA_STAMP(2, 1);
@@ -1393,6 +1408,7 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
   const double alpha = gamma / denom;
   __syncthreads();                                      // the LDS image is complete
   double acc[2] = {0, 0};
+  double rsum[6] = {0, 0, 0, 0, 0, 0};
   const int t = threadIdx.x;
   if (live) {
     const double* M = l_cs + CS * t + 12;
@@ -1426,15 +1442,27 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
       rr[q] -= alpha * ss[q];
     }
     sym6_mul(mi, rr, zz);
-    sym6_mul(h, zz, hz);
+    if (!COARSE) sym6_mul(h, zz, hz);
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
       l_v[0][6 * t + q] = zz[q]; l_v[1][6 * t + q] = pp[q]; l_v[2][6 * t + q] = ss[q];
       l_v[3][6 * t + q] = rr[q]; l_v[4][6 * t + q] = xx[q];
-      acc[0] += rr[q] * zz[q];
-      acc[1] += zz[q] * hz[q];
+      if (!COARSE) {
+        acc[0] += rr[q] * zz[q];
+        acc[1] += zz[q] * hz[q];
+      } else {
+        rsum[q] = rr[q];
+      }
     }
-    write_vtil(M, zz, vtil + TA * c + 12);
+    if (!COARSE) write_vtil(M, zz, vtil + TA * c + 12);
+  }
+  if (COARSE) {                                         // restricted residual of this aggregate (= this workgroup)
+#pragma unroll
+    for (int q = 0; q < 6; ++q) rsum[q] = wave_total_dpp(rsum[q]);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) rc[6 * blockIdx.x + q] = rsum[q];
+    }
   }
   __syncthreads();
   {                                                     // the five vectors back, coalesced (fixed camera: unchanged image)
@@ -1446,9 +1474,11 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
 #pragma unroll
   for (int q = 0; q < 2; ++q) acc[q] = wave_total_dpp(acc[q]);
   if (threadIdx.x == 0) {
-    double* pv = partV + (size_t)((k + 1) & 1) * 2 * nblkV;
-    pv[2 * blockIdx.x] = acc[0];
-    pv[2 * blockIdx.x + 1] = acc[1];
+    if (!COARSE) {
+      double* pv = partV + (size_t)((k + 1) & 1) * 2 * nblkV;
+      pv[2 * blockIdx.x] = acc[0];
+      pv[2 * blockIdx.x + 1] = acc[1];
+    }
     if (blockIdx.x == 0) {
       PcgState o = sin;
       o.gamma_prev = gamma; o.alpha_prev = alpha;

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BA_HIP_LIB") or os.path.join(_HERE, "libba_hip.so")   # BA_HIP_LIB: another build of the same ABI
 
 LOSS = {"linear": 0, "huber": 1}
-PRECOND = {"jacobi": 0, "schur_jacobi": 1}
+PRECOND = {"jacobi": 0, "schur_jacobi": 1, "two_level": 2}
 STATUS_NAMES = {0: "max_iters", 1: "ftol", 2: "xtol", 3: "gtol"}
 PROFILE_SLOTS = 16
 K_RESIDUAL, K_LINEARIZE_CAM, K_LINEARIZE_PT, K_POINT_INVERT, K_SCHUR_PT, K_SCHUR_CAM = 1, 2, 3, 4, 5, 6

@@ -41,7 +41,14 @@ enum ba_status {
 };
 
 enum ba_loss { BA_LOSS_LINEAR = 0, BA_LOSS_HUBER = 1 };
-enum ba_precond { BA_PRECOND_JACOBI = 0, BA_PRECOND_SCHUR_JACOBI = 1 };
+/* JACOBI: blocks of Hcc + lambda D.  SCHUR_JACOBI (default): the diagonal blocks of the reduced camera matrix S.
+ * TWO_LEVEL: Schur-Jacobi plus an additive coarse correction P E^-1 P^T over aggregates of 16 consecutive cameras,
+ * E = P^T S P, for band-structured problems (sequential captures such as BASELINE config 5, where block
+ * preconditioners leave the drift modes along the chain): 2-5x fewer PCG iterations at equal damping; the coarse
+ * matrix is rebuilt and inverted per damped system, which only pays off when a solve spends hundreds of PCG
+ * iterations per LM iteration.  ba_solve returns BA_ERR_STATE when ba_set_problem found no band
+ * structure (mean camera span of a track above Nc / 8) or the job has several ranks. */
+enum ba_precond { BA_PRECOND_JACOBI = 0, BA_PRECOND_SCHUR_JACOBI = 1, BA_PRECOND_TWO_LEVEL = 2 };
 
 /* Solver knobs.  The reference's literals at src/bundle_adjuster.py:170-174 are
  * loss='huber' (f_scale 1), xtol = ftol = 1e-5, max_nfev = 50. */

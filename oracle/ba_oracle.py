@@ -403,14 +403,76 @@ class SchurOperator:
         return -np.einsum('pij,pj->pi', self.Hppinv, self.bp + u)
 
 
+AGG = 16          # cameras per coarse aggregate (= one camera-vector workgroup of the device, csrc/ba_coarse.hpp)
+
+
+def coarse_matrix(op, fixed_cam=-1):
+    """E = P^T S P of the two-level preconditioner (csrc/ba_coarse.hpp): P piecewise constant over aggregates of AGG
+    consecutive cameras, one coarse unknown per parameter; the fixed camera is left out.  Built from the blocks like
+    the device does: sum of Hccd over an aggregate minus sum_p U_{p,a}^T Hpp^-1 U_{p,b}, U_{p,a} = sum of the point's
+    W_o^T over its observations in aggregate a.  Returns E (6 Na, 6 Na)."""
+    nc = op.Hccd.shape[0]
+    na = (nc + AGG - 1) // AGG
+    agg_of_obs = op.cam_idx // AGG
+    free = op.cam_idx != fixed_cam
+    # W_o^T (3x6) per observation, summed per (point, aggregate)
+    key = op.pt_idx.astype(np.int64) * na + agg_of_obs
+    uniq, inv = np.unique(key[free], return_inverse=True)
+    U = np.zeros((uniq.shape[0], 3, 6))
+    np.add.at(U, inv, np.transpose(op.W[free], (0, 2, 1)))
+    pt_of = (uniq // na).astype(np.int64)
+    ag_of = (uniq % na).astype(np.int64)
+    E = np.zeros((na, 6, na, 6))
+    for c in range(nc):
+        if c != fixed_cam:
+            E[c // AGG, :, c // AGG, :] += op.Hccd[c]
+    T = np.einsum('rkl,rlj->rkj', op.Hppinv[pt_of], U)                      # Hinv U per (point, aggregate)
+    # pairs of entries of the same point
+    order = np.argsort(pt_of, kind='stable')
+    starts = np.flatnonzero(np.r_[True, pt_of[order][1:] != pt_of[order][:-1], True])
+    for s0, s1 in zip(starts[:-1], starts[1:]):
+        idx = order[s0:s1]
+        for i in idx:
+            for j in idx:
+                E[ag_of[i], :, ag_of[j], :] -= U[i].T @ T[j]
+    E = E.reshape(6 * na, 6 * na)
+    d = np.diag(E).copy()
+    bad = ~(d > 0)
+    E[bad, bad] = 1.0                                                       # (an aggregate holding only the fixed camera)
+    return E
+
+
+def two_level_apply(Minv, Einv, fixed_cam=-1):
+    """r (Nc,6) -> M_J^-1 r + P E^-1 P^T r."""
+    nc = Minv.shape[0]
+    na = (nc + AGG - 1) // AGG
+    agg = np.arange(nc) // AGG
+
+    def apply(r):
+        rr = r.copy()
+        if fixed_cam >= 0:
+            rr[fixed_cam] = 0
+        rc = np.zeros((na, 6))
+        np.add.at(rc, agg, rr)
+        zc = (Einv @ rc.ravel()).reshape(na, 6)
+        z = np.einsum('cij,cj->ci', Minv, r) + zc[agg]
+        if fixed_cam >= 0:
+            z[fixed_cam] = np.einsum('ij,j->i', Minv[fixed_cam], r[fixed_cam])
+        return z
+    return apply
+
+
 def pcg(op, rhs, Minv, tol, max_iters, min_iters=0):
-    """Preconditioned CG on S x = rhs with block-Jacobi Minv (Nc,6,6).
+    """Preconditioned CG on S x = rhs with block-Jacobi Minv (Nc,6,6), or any callable r -> M^-1 r.
     Stops when sqrt(rz / rz0) <= tol (after min_iters) or at max_iters.
     Returns x (Nc,6), iterations, final residual vector."""
+    if not callable(Minv):
+        blocks = Minv
+        Minv = lambda r_: np.einsum('cij,cj->ci', blocks, r_)          # noqa: E731
     nc = rhs.shape[0]
     x = np.zeros((nc, 6))
     r = rhs.copy()
-    z = np.einsum('cij,cj->ci', Minv, r)
+    z = Minv(r)
     p = z.copy()
     rz = float((r * z).sum())
     rz0 = rz
@@ -425,7 +487,7 @@ def pcg(op, rhs, Minv, tol, max_iters, min_iters=0):
         alpha = rz / pq
         x += alpha * p
         r -= alpha * q
-        z = np.einsum('cij,cj->ci', Minv, r)
+        z = Minv(r)
         rz_new = float((r * z).sum())
         it += 1
         if it >= min_iters and rz_new <= tol * tol * rz0:
@@ -462,10 +524,12 @@ def lm_solve(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam=-1, loss='linear',
             break
         op = SchurOperator(ne, cam_idx, pt_idx, lam, fixed_cam)
         rhs = op.rhs()
-        D = op.schur_diag_blocks() if precond == 'schur_jacobi' else op.Hccd.copy()
+        D = op.Hccd.copy() if precond == 'jacobi' else op.schur_diag_blocks()
         if fixed_cam >= 0:
             D[fixed_cam] = np.eye(6)
         Minv = np.linalg.inv(D)
+        if precond == 'two_level':
+            Minv = two_level_apply(Minv, np.linalg.inv(coarse_matrix(op, fixed_cam)), fixed_cam)
         dc, k, rfin = pcg(op, rhs, Minv, pcg_tol, pcg_max_iters)
         pcg_total += k
         dp = op.back_substitute(dc)
