@@ -10,10 +10,15 @@ namespace ba {
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
 constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
 
+// With every row enabled (ROW_MASK 0xf) the "lanes without a source read 0" rule is the instruction's own
+// bound_ctrl:1, so no zeroed destination has to be set up in front of each move (2 of the 5 instructions of a
+// 64-bit reduction step; the 27-sum kernels spend a third of their vector instructions in these steps).  The
+// broadcast steps enable only some rows: the others must keep a 0, which is the `old` operand.
 template <int CTRL, int ROW_MASK>
 __device__ inline double dpp_f64(double src) {   // lanes without a source read 0.0
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), CTRL, ROW_MASK, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), CTRL, ROW_MASK, 0xf, false);
+  constexpr bool all_rows = ROW_MASK == 0xf;
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), CTRL, ROW_MASK, 0xf, all_rows);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), CTRL, ROW_MASK, 0xf, all_rows);
   return __hiloint2double(hi, lo);
 }
 

@@ -1711,6 +1711,12 @@ extern "C" int ba_time_kernel(ba_handle* h, int slot, int reps, double* mean_us)
 
 // --------------------------------------------------------------- diagnostic build only
 #ifdef BA_STAMPS
+extern "C" int ba_debug_mode(ba_handle* h, int mode) {
+  if (!h) return fail(BA_ERR_INVALID, "null handle");
+  if (set_device(h)) return BA_ERR_HIP;
+  HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_mode), &mode, sizeof(int)));
+  return BA_OK;
+}
 // copy the stamps of the last launch of kind 0 (PCG point pass), 1 (PCG camera pass), 2 (k_pcg_step)
 extern "C" int ba_debug_stamps(ba_handle* h, int kind, unsigned long long* out, int n_blocks) {
   if (!h || !out || kind < 0 || kind > 2 || n_blocks < 1 || n_blocks > STAMP_BLOCKS) return fail(BA_ERR_INVALID, "bad argument");

@@ -39,6 +39,7 @@ namespace ba {
 #ifdef BA_STAMPS
 constexpr int STAMP_BLOCKS = 8192;
 __device__ unsigned long long g_stamps[3][STAMP_BLOCKS * 8];
+__device__ int g_dbg_mode;      // diagnostic variants of the camera pass's gather (tools/stamp_timeline.py): 0 = product path
 #define BA_STAMP(kind, slot)                                                                              \
   do {                                                                                                    \
     if (threadIdx.x == 0 && blockIdx.x < STAMP_BLOCKS)                                                    \
@@ -436,9 +437,17 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
     while (i < end) {
       const int in = i + SEGL;
       const int pn = (in < end) ? c_pt[in] : 0;          // prefetch the next index
-      const int p = ROBUST ? (pf & IDX_MASK) : pf;
-      const double4 Xd = *(const double4*)(ptab + PT * (size_t)p);
-      const double4 Yd = *(const double4*)(ptab + PT * (size_t)p + 4);
+      int p = ROBUST ? (pf & IDX_MASK) : pf;
+#ifdef BA_STAMPS
+      const int dbg = g_dbg_mode;
+      if (dbg == 1) p = i % 100000;                          // no gather: consecutive records (coalesced)
+      if (dbg == 3) p = (p & ~7) | (lane & 7);               // gather whole 512-byte groups: 8 lanes share 4 lines
+#endif
+      double4 Xd = *(const double4*)(ptab + PT * (size_t)p);
+      double4 Yd = *(const double4*)(ptab + PT * (size_t)p + 4);
+#ifdef BA_STAMPS
+      if (dbg == 2) Yd = Xd;                                 // one 32-byte half of the record only
+#endif
       double2 wn = make_double2(1.0, 1.0);                 // next weight, only where it is not (1, 1)
       if (ROBUST && pn < 0) wn = c_w[in];
       const JT X0 = (JT)Xd.x, X1 = (JT)Xd.y, X2 = (JT)Xd.z, Y0 = (JT)Yd.x, Y1 = (JT)Yd.y, Y2 = (JT)Yd.z;

@@ -36,6 +36,12 @@ def main():
     lib.ba_debug_stamps.restype = C.c_int
     lib.ba_debug_stamps.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_int]
     s.set_problem(p)
+    mode = int(os.environ.get("BA_DBG_MODE", "0"))
+    if mode:
+        lib.ba_debug_mode.restype = C.c_int
+        lib.ba_debug_mode.argtypes = [C.c_void_p, C.c_int]
+        hb._check(lib.ba_debug_mode(s._h, mode))
+        print(f"camera-pass gather variant {mode} (results are meaningless; timing only)")
     s.solve(loss="huber", max_iters=3, ftol=0.0, xtol=0.0, gtol=0.0, pcg_tol=0.0, pcg_max_iters=3, pcg_min_iters=3)
     nblk = {0: min(8192, (p.n_pts + 511) // 512 + 64), 1: min(8192, ((p.n_cams + 3) // 4) * 8), 2: (p.n_cams + 15) // 16}
     for kind, (name, labels, slots) in STAGES.items():
