@@ -195,6 +195,12 @@ def main():
             raise SystemExit(3)
         comm_note = f"{transport}: communicator of {world} ranks initialised on {ranks_up} ranks, first all-reduce done"
     else:
+        if os.environ.get("BA_COMM_FORCE"):
+            # one GPU, but through the multi-rank control flow and a real RCCL communicator of one rank: what the fold
+            # kernels, the RCCL launches and the device-side decision cost per LM iteration (not a scaling number)
+            solver.comm_init(0, 1, hip_backend.comm_unique_id())
+            transport = "shm" if os.environ.get("BA_COMM") == "shm" else "rccl"
+            comm_note = f"{transport}: communicator of ONE rank forced (BA_COMM_FORCE), multi-rank control flow on one GPU"
         solver.set_problem(shard)
 
     # every stopping tolerance off so that exactly K iterations run; gtol is tiny but POSITIVE so that the

@@ -191,6 +191,9 @@ struct ba_handle {
   long long flag_base = 1, step_seq = 1;
   // comm
   int rank = 0, world = 1;
+  bool multi = false;          // the multi-rank control flow is on: world > 1, or a communicator of ONE rank was forced
+                               // (BA_COMM_FORCE=1: lets a single GPU execute every fold / all-reduce / decide step of the
+                               // multi-rank loop through the real RCCL library)
   ncclComm_t nccl = nullptr;
   // host-staged shared-memory transport (BA_COMM=shm): a test vehicle that lets several ranks
   // share ONE GPU (RCCL refuses that), so the multi-rank control flow can be exercised end to end
@@ -369,7 +372,8 @@ extern "C" int ba_comm_init(ba_handle* h, int rank, int world, const void* id128
   if (world < 1 || rank < 0 || rank >= world) return fail(BA_ERR_INVALID, "rank %d / world %d", rank, world);
   h->rank = rank;
   h->world = world;
-  if (world == 1) return BA_OK;
+  h->multi = world > 1 || getenv("BA_COMM_FORCE") != nullptr;
+  if (!h->multi) return BA_OK;
   if (!id128) return fail(BA_ERR_INVALID, "null id buffer");
   if (set_device(h)) return BA_ERR_HIP;
   { const char* e = getenv("BA_COMM"); if (e && strcmp(e, "shm") == 0) return shm_init(h, rank, world, id128); }
@@ -524,7 +528,7 @@ static int shm_allreduce(ba_handle* h, double* buf, size_t count, bool is_max) {
 }
 
 static int allreduce(ba_handle* h, double* buf, size_t count, bool is_max = false) {
-  if (h->world == 1) return BA_OK;
+  if (!h->multi) return BA_OK;
   Scope sc(h, BA_K_ALLREDUCE);
   if (h->shm) return shm_allreduce(h, buf, count, is_max);
   ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclDouble, is_max ? ncclMax : ncclSum, h->nccl, h->stream);
@@ -732,8 +736,8 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
       span_sum += hi - lo;
       ++tracks;
     }
-    bool want = tracks > 0 && span_sum / tracks <= Nc / 8.0 && h->world == 1;
-    if (const char* e = getenv("BA_TWO_LEVEL")) want = atoi(e) != 0 && h->world == 1;
+    bool want = tracks > 0 && span_sum / tracks <= Nc / 8.0 && !h->multi;
+    if (const char* e = getenv("BA_TWO_LEVEL")) want = atoi(e) != 0 && !h->multi;
     if (want && Nc >= 2 * VEC_CAMS && Np > 0 && No > 0) {
       std::vector<std::pair<int, int>> tmp;
       int bwa = 0;
@@ -971,7 +975,7 @@ static void launch_residual(ba_handle* h, int which, bool robust, double fscale,
 static void launch_scalars(ba_handle* h, bool with_step, int k = 0, double tol2 = 0.0, int min_iters = 0, long long seq = 0,
                            double cost_cur = 0.0, double lambda = 0.0) {
   Scope sc(h, BA_K_MISC);
-  const bool direct = with_step && h->world == 1;     // results straight into host-mapped memory + sequence word
+  const bool direct = with_step && !h->multi;         // results straight into host-mapped memory + sequence word
   BA_LAUNCH(k_scalars, dim3(1), dim3(1024), 0, h->stream, h->partR.p, NPART * h->Nc, h->partB.p,
                      (with_step && h->Np > 0) ? h->nblkP + h->nblkL : 0, h->partC.p, with_step ? h->nblkV : 0, k,
                      with_step ? (const PcgState*)h->st.p : (const PcgState*)nullptr, h->partV.p, h->nblkV, tol2, min_iters,
@@ -1154,7 +1158,7 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
 // the NPART partitions, then read "total + 0 + ... + 0" and stay the kernels they are on one rank.
 // An eighth of the bytes on the wire for two launch-floor kernels.  Single rank: nothing.
 static int fold_and_reduce(ba_handle* h, double* parts, size_t n_per_part, double* msg, size_t msg_count) {
-  if (h->world == 1) return BA_OK;
+  if (!h->multi) return BA_OK;
   {
     Scope sc(h, BA_K_MISC);
     BA_LAUNCH(k_fold_parts, dim3((unsigned)((n_per_part + 255) / 256)), dim3(256), 0, h->stream, parts, n_per_part, NPART);
@@ -1165,7 +1169,7 @@ static int exchange_partL(ba_handle* h, int buf) {
   return fold_and_reduce(h, h->partL[buf].p, 27 * (size_t)h->Nc, h->partL[buf].p, 27 * (size_t)h->Nc);
 }
 static int exchange_schur(ba_handle* h, bool with_diag) {
-  if (h->world == 1) return BA_OK;
+  if (!h->multi) return BA_OK;
   // the message starts at the u.y word in front of partition 0
   if (int rc = fold_and_reduce(h, p6_ptr(h), 6 * (size_t)h->Nc, uy_ptr(h), 2 + 6 * (size_t)h->Nc)) return rc;
   if (with_diag) return fold_and_reduce(h, h->partE.p, 21 * (size_t)h->Nc, h->partE.p, 21 * (size_t)h->Nc);
@@ -1434,7 +1438,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   sum->initial_cost = cost;
   // nothing to adjust.  Single rank only: a rank of a multi-rank job whose landmark shard is empty still has to
   // join every collective of the loop below (with zero partials), or the other ranks wait for it forever.
-  if (h->world == 1 && (h->Np == 0 || h->Nobs == 0)) {
+  if (!h->multi && (h->Np == 0 || h->Nobs == 0)) {
     sum->final_sse = sse; sum->final_cost = cost; sum->final_lambda = opts->initial_lambda;
     sum->seconds_total = now_s() - t_begin;
     h->profile = false;
@@ -1472,7 +1476,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       // max |gradient| = max(|bc|, |bp|): per-workgroup maxima come out of the point half (partG) and of
       // k_pcg_setup (partGc); single rank: the first PCG probe folds them into host-mapped memory
       gtol_pending = true;
-      if (h->world > 1) {
+      if (h->multi) {
         // bc is all-reduced (identical on every rank); bp is shard-local -> max over the ranks' partial maxima, then
         // the word goes to host-mapped memory ahead of the first probe (no copy, no stream synchronise)
         {
@@ -1498,7 +1502,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     h->flag_base += opts->pcg_max_iters + 8;
     auto launch_point_pass = [&](int kk) {
       launch_pt_schur(h, robust, 0, kk, tol2, opts->pcg_min_iters, base,
-                      (kk == 0 && gtol_pending && h->world == 1) ? h->d_scal_host + GMAX_HOST_SLOT : (double*)nullptr);
+                      (kk == 0 && gtol_pending && !h->multi) ? h->d_scal_host + GMAX_HOST_SLOT : (double*)nullptr);
     };
     auto launch_rest = [&](int kk) -> int {
       launch_cam_schur(h, robust, false, true, kk, tol2, opts->pcg_min_iters);
@@ -1563,7 +1567,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     if (debug_poison) BA_LAUNCH(k_poison, dim3(1), dim3(64), 0, h->stream, h->partR.p);
     const long long seq = ++h->step_seq;
     launch_scalars(h, true, k, tol2, opts->pcg_min_iters, seq, cost, lambda);
-    if (h->world > 1) {       // the six sums over ranks, then the verdict on the all-reduced block; same host-mapped mirror + word
+    if (h->multi) {           // the six sums over ranks, then the verdict on the all-reduced block; same host-mapped mirror + word
       if (int rc = allreduce(h, h->scal.p, 6)) return rc;
       Scope sc(h, BA_K_MISC);
       BA_LAUNCH(k_decide, dim3(1), dim3(64), 0, h->stream, h->scal.p, cost, lambda, h->d_scal_host, h->d_flags + 2, seq);

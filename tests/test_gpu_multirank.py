@@ -254,3 +254,37 @@ def test_bench_two_ranks_over_the_shm_transport_reports_its_transport(tmp_path):
     cfg = line["config"]
     assert line["n_gpus"] == 2 and cfg["world"] == 2 and cfg["transport"] == "shm" and cfg["ranks_in_communicator"] == 2
     assert line["steps"] == 4 and line["value"] > 0 and line["repeats"] == 2
+
+
+def test_real_rccl_communicator_of_one_rank_runs_the_whole_multi_rank_loop(monkeypatch):
+    """RCCL refuses two ranks on one device and only a one-GPU box is available, so until the driver's multi-GPU run the
+    library's ncclAllReduce call site would never execute.  BA_COMM_FORCE=1 makes ba_comm_init build a REAL RCCL
+    communicator of one rank and switches the solve onto the multi-rank control flow: every fold kernel, every
+    ncclAllReduce (linearisation partials, Schur product per PCG iteration, gradient maximum, step scalars), the
+    device-side decision kernel and ba_allgather_points run through librccl on the GPU.  With one rank an all-reduce is
+    a copy and the folded partial sums add up in the same order, so the result must equal the plain single-rank solve
+    bit for bit."""
+    from bundle_adjustment_amd import hip_backend
+    from bundle_adjustment_amd.synthetic import make_problem
+    p = make_problem(12, 1500, 5, seed=41, outlier_frac=0.02)
+    kw = dict(loss="huber", max_iters=15, ftol=1e-12, xtol=1e-12, gtol=1e-10, pcg_tol=1e-2)
+    with hip_backend.Solver(0) as s:
+        s.set_problem(p)
+        ref = s.solve(**kw)
+        cams_ref, pts_ref = s.get_params()
+    monkeypatch.delenv("BA_COMM", raising=False)
+    monkeypatch.setenv("BA_COMM_FORCE", "1")
+    uid = hip_backend.comm_unique_id()                        # ncclGetUniqueId
+    with hip_backend.Solver(0) as s:
+        s.comm_init(0, 1, uid)                                # ncclCommInitRank, world of one
+        s.set_problem(p)
+        r, sse, _ = s.residuals("huber")                      # first collective
+        out = s.solve(**kw)
+        cams, pts = s.get_params()
+        allpts = s.allgather_points(0, p.n_pts)
+        prof_out = s.solve(profile=1, **dict(kw, max_iters=2))
+        prof = s.profile()
+    for key in ("iterations", "accepted", "pcg_iterations", "initial_sse", "final_sse", "final_cost", "status"):
+        assert out[key] == ref[key], key
+    assert np.array_equal(cams, cams_ref) and np.array_equal(pts, pts_ref) and np.array_equal(allpts, pts_ref)
+    assert prof["allreduce"]["launches"] > 0 and prof_out["iterations"] == 2          # the collectives really ran
