@@ -118,6 +118,22 @@ def cpu_baseline_vectorised(prob, n_groups, budget_s=10.0):
                                     f"({t_sweep * 1e3:.1f} ms each), x ({n_groups}+1) sweeps per TRF iteration; LSMR not timed")
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner on file descriptor 1 when a communicator comes up; stdout must carry exactly one JSON
+    line, so the descriptor points at stderr while the transport is being set up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,7 +184,8 @@ def main():
         ok, err, uid = 1, "", None
         if rank == 0:                         # rank 0 ALWAYS reaches the broadcast, with or without an id
             try:
-                uid = hip_backend.comm_unique_id()
+                with _stdout_to_stderr():
+                    uid = hip_backend.comm_unique_id()
             except hip_backend.BAHipError as e:
                 ok, err = 0, str(e)
         box = [(ok, uid)]
@@ -176,9 +193,10 @@ def main():
         ok0, uid = box[0]
         if ok0:
             try:
-                solver.comm_init(rank, world, uid)
-                solver.set_problem(shard)
-                solver.residuals("linear", want_vector=False)        # first collective: proves the transport works
+                with _stdout_to_stderr():
+                    solver.comm_init(rank, world, uid)
+                    solver.set_problem(shard)
+                    solver.residuals("linear", want_vector=False)        # first collective: proves the transport works
             except hip_backend.BAHipError as e:
                 ok, err = 0, str(e)
         else:
@@ -198,7 +216,10 @@ def main():
         if os.environ.get("BA_COMM_FORCE"):
             # one GPU, but through the multi-rank control flow and a real RCCL communicator of one rank: what the fold
             # kernels, the RCCL launches and the device-side decision cost per LM iteration (not a scaling number)
-            solver.comm_init(0, 1, hip_backend.comm_unique_id())
+            with _stdout_to_stderr():
+                solver.comm_init(0, 1, hip_backend.comm_unique_id())
+                solver.set_problem(shard)
+                solver.residuals("linear", want_vector=False)
             transport = "shm" if os.environ.get("BA_COMM") == "shm" else "rccl"
             comm_note = f"{transport}: communicator of ONE rank forced (BA_COMM_FORCE), multi-rank control flow on one GPU"
         solver.set_problem(shard)

@@ -275,6 +275,27 @@ def test_c5_full_size_l2_fallback(solver):
     assert np.sqrt(out["final_sse"] / p.n_obs) < 0.75
 
 
+def test_c5_full_size_fp32_jacobian_mode(solver):
+    """BASELINE config 5 AS SPECIFIED on one GPU: the full-size BAL-like problem (1723 cams / 156 502 pts) in its
+    precision mode -- fp32 Jacobian blocks in the PCG passes, fp64 accumulation and solve.  The quasi-Newton operator is
+    the only thing fp32 touches, so the descent must follow the fp64 run: same accepted steps, costs equal to fp32
+    operator accuracy, and the residual vector of the result (fp64 kernel) must agree with the oracle."""
+    p = make_bal_like(seed=0)
+    kw = dict(loss="huber", max_iters=10, ftol=1e-9, xtol=1e-12, gtol=0.0, pcg_tol=0.1, pcg_max_iters=400)
+    solver.set_problem(p)
+    ref = solver.solve(**kw)
+    solver.set_problem(p)
+    out = solver.solve(jacobian_precision=1, **kw)
+    cams, pts = solver.get_params()
+    assert out["accepted"] == out["iterations"] and ref["accepted"] == ref["iterations"]
+    assert out["final_cost"] < 0.05 * out["initial_cost"]
+    assert abs(out["final_cost"] - ref["final_cost"]) <= 2e-3 * ref["final_cost"], (out["final_cost"], ref["final_cost"])
+    assert np.sqrt(out["final_sse"] / p.n_obs) < 0.75
+    r, sse, _ = solver.residuals("huber")
+    assert np.abs(r - o.residuals(cams, pts, p.cam_idx, p.pt_idx, p.uv, p.K4)).max() <= 1e-9
+    assert abs(sse - out["final_sse"]) <= 1e-9 * sse
+
+
 def test_fp32_jacobian_mode_reaches_the_fp64_solution(solver):
     """BASELINE config 5's precision mode: Jacobian blocks of the PCG passes in fp32, every sum,
     the gradient, the cost and the update in fp64.  Only the quasi-Newton operator changes, so the
