@@ -33,6 +33,7 @@
 #include "ba_kernels.hpp"
 #include "ba_triangulate.hpp"
 #include "ba_coarse.hpp"
+#include "ba_small.hpp"
 
 using namespace ba;
 
@@ -169,6 +170,7 @@ struct ba_handle {
   DBuf<double> gvec, x, r, p, s, z, vin, scal, rbuf, gather;
   DBuf<PcgState> st;
   DBuf<double> tri;            // staging of ba_triangulate
+  DBuf<char> small_out;        // k_small_lm: ba_summary | int cur | trace records
   // two-level preconditioner for band-structured problems (ba_coarse.hpp): structures built by ba_set_problem
   bool two_level_ok = false;   // this problem has them
   bool two_level = false;      // the current solve uses them
@@ -330,6 +332,7 @@ extern "C" int ba_destroy(ba_handle* h) {
   for (auto b : db) b->release();
   h->st.release();
   h->tri.release();
+  h->small_out.release();
   h->run_beg.release(); h->run_pt.release(); h->run_agg.release(); h->run_pairs.release();
   h->coarseU.release(); h->coarseE.release(); h->coarseEinv.release(); h->coarse_rc.release(); h->coarse_info.release();
   h->coarseEint.release();
@@ -1404,6 +1407,56 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   }
   return rc;
 }
+// Sliding-window-sized problems (ba_small.hpp): the whole LM loop in one kernel launch, dense Cholesky of the reduced
+// system instead of PCG.  Same options, summary and trace as the multi-kernel path.
+static bool small_applies(const ba_handle* h, const ba_options* opts) {
+  return opts->small_solver == 0 && !h->multi && h->Nc <= SMALL_MAX_CAMS && h->Np > 0 && h->Nobs > 0 && h->Nobs <= 65536 &&
+         opts->max_iters >= 1 && getenv("BA_NO_SMALL_SOLVER") == nullptr;
+}
+static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
+  const double t_begin = now_s();
+  const size_t off_cur = sizeof(ba_summary), off_trace = 256;
+  const size_t bytes = off_trace + sizeof(ba_iter_record) * (size_t)opts->max_iters;
+  HIPCHECK(h->small_out.alloc(bytes));
+  HIPCHECK(hipMemsetAsync(h->small_out.p, 0, off_trace, h->stream));
+  SmallArgs A;
+  for (int k = 0; k < 2; ++k) { A.cams[k] = h->cams[k].p; A.cs[k] = h->cs[k].p; A.ptab[k] = h->ptab[k].p; }
+  A.offk = h->offk.p; A.c_pt = h->c_pt.p; A.c_uv = h->c_uv.p;
+  A.pt_off = h->pt_off.p; A.p_cam = h->p_cam.p; A.p_uv = h->p_uv.p;
+  A.Hpp = h->Hpp[h->pb].p; A.bp = h->bp[h->pb].p; A.Hppinv = h->Hppinv[h->pb].p; A.y0 = h->y0[h->pb].p;
+  A.n_cams = h->Nc; A.n_pts = h->Np; A.fixed_cam = h->fixed; A.robust = opts->loss == BA_LOSS_HUBER;
+  A.fx = h->K4[0]; A.fy = h->K4[1]; A.cx = h->K4[2]; A.cy = h->K4[3]; A.hub_c = opts->f_scale;
+  A.max_iters = opts->max_iters; A.ftol = opts->ftol; A.xtol = opts->xtol; A.gtol = opts->gtol; A.lambda0 = opts->initial_lambda;
+  A.cur = h->cur;
+  A.summary = (ba_summary*)h->small_out.p;
+  A.cur_out = (int*)(h->small_out.p + off_cur);
+  A.trace = (ba_iter_record*)(h->small_out.p + off_trace);
+  {
+    Scope sc(h, BA_K_MISC);
+    BA_LAUNCH(k_small_lm, dim3(1), dim3(SMALL_THREADS), 0, h->stream, A);
+  }
+  int cur_out = h->cur;
+  HIPCHECK(hipMemcpyAsync(sum, h->small_out.p, sizeof(ba_summary), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipMemcpyAsync(&cur_out, h->small_out.p + off_cur, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  BA_SYNC(h);
+  if (sum->status == BA_ERR_NUMERIC)
+    return fail(BA_ERR_NUMERIC, sum->iterations == 0 ? "non-finite cost at the initial parameters"
+                                                     : "non-finite cost / gradient during the solve (LM iteration %d)", sum->iterations);
+  if (sum->iterations > 0) {
+    h->trace.resize((size_t)sum->iterations);
+    HIPCHECK(hipMemcpy(h->trace.data(), h->small_out.p + off_trace, sizeof(ba_iter_record) * (size_t)sum->iterations, hipMemcpyDeviceToHost));
+  }
+  h->cur = cur_out;
+  // the multi-kernel entry points read the packed camera table of the current set: rebuild it from the result
+  BA_LAUNCH(k_cam_prepare, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->cams[h->cur].p, h->cs[h->cur].p, h->camA[h->cur].p, h->Nc);
+  BA_SYNC(h);
+  h->linearized = false;
+  sum->seconds_total = now_s() - t_begin;
+  const double per = sum->iterations ? sum->seconds_total / sum->iterations : 0.0;
+  for (auto& r : h->trace) r.seconds = per;
+  return BA_OK;
+}
+
 static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   if (!h->have_params) return fail(BA_ERR_STATE, "ba_set_problem / ba_set_params first");
   if (opts->loss != BA_LOSS_LINEAR && opts->loss != BA_LOSS_HUBER) return fail(BA_ERR_INVALID, "unknown loss");
@@ -1415,6 +1468,11 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   if (set_device(h)) return BA_ERR_HIP;
   memset(sum, 0, sizeof *sum);
   h->trace.clear();
+  if (small_applies(h, opts)) {
+    if (opts->loss != BA_LOSS_LINEAR && opts->loss != BA_LOSS_HUBER) return fail(BA_ERR_INVALID, "unknown loss");
+    if (set_device(h)) return BA_ERR_HIP;
+    return small_solve(h, opts, sum);
+  }
   roctx_load();
   Range r_solve("ba_solve");
   const bool robust = opts->loss == BA_LOSS_HUBER;

@@ -8,7 +8,9 @@ from bundle_adjustment_amd import hip_backend
 from bundle_adjustment_amd.synthetic import make_problem
 
 pytestmark = pytest.mark.gpu
-KW = dict(loss="huber", max_iters=30, ftol=1e-10, xtol=1e-10, gtol=1e-12)
+# small_solver=1: these problems have 8 cameras or fewer and would otherwise go to the single-launch direct solver
+# (tests/test_gpu_small.py); the failure paths under test are the multi-kernel loop's
+KW = dict(loss="huber", max_iters=30, ftol=1e-10, xtol=1e-10, gtol=1e-12, small_solver=1)
 
 
 def test_refused_kernel_launch_is_reported_with_its_name(monkeypatch):
