@@ -33,6 +33,13 @@ __device__ inline double wave_scan_sum_dpp(double x) {
   return x;
 }
 // total of the wave, uniform in every lane
+// value of lane `src` (the same in every lane: it goes through a scalar register) in all lanes
+__device__ inline double readlane_f64(double v, int src) {
+  const int s = __builtin_amdgcn_readfirstlane(src);
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), s), hi = __builtin_amdgcn_readlane(__double2hiint(v), s);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ inline double wave_total_dpp(double x) {
   x = wave_scan_sum_dpp(x);
   const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63);

@@ -170,7 +170,12 @@ struct ba_handle {
   DBuf<double> gvec, x, r, p, s, z, vin, scal, rbuf, gather;
   DBuf<PcgState> st;
   DBuf<double> tri;            // staging of ba_triangulate
-  DBuf<char> small_out;        // k_small_lm: ba_summary | int cur | trace records
+  char* h_small = nullptr;     // k_small_lm's results, host-mapped: ba_summary | int cur | trace records
+  char* d_small_host = nullptr;
+  size_t h_small_bytes = 0;
+  long long small_seq = 0;     // sequence number of h_flags[4], which k_small_lm publishes when its results are written
+  DBuf<double> small_V, small_gS;   // k_small_lm: V = W L (49 x 3 Np_pad, zero where unwritten), per-wave partial V V^T
+  int small_np_pad = -1;
   // two-level preconditioner for band-structured problems (ba_coarse.hpp): structures built by ba_set_problem
   bool two_level_ok = false;   // this problem has them
   bool two_level = false;      // the current solve uses them
@@ -332,13 +337,16 @@ extern "C" int ba_destroy(ba_handle* h) {
   for (auto b : db) b->release();
   h->st.release();
   h->tri.release();
-  h->small_out.release();
+  h->small_V.release();
+  h->small_gS.release();
+  h->small_np_pad = -1;
   h->run_beg.release(); h->run_pt.release(); h->run_agg.release(); h->run_pairs.release();
   h->coarseU.release(); h->coarseE.release(); h->coarseEinv.release(); h->coarse_rc.release(); h->coarse_info.release();
   h->coarseEint.release();
   h->verdict.release();
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->h_flags) (void)hipHostFree(h->h_flags);
+  if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return BA_OK;
@@ -1417,39 +1425,63 @@ static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   const double t_begin = now_s();
   const size_t off_cur = sizeof(ba_summary), off_trace = 256;
   const size_t bytes = off_trace + sizeof(ba_iter_record) * (size_t)opts->max_iters;
-  HIPCHECK(h->small_out.alloc(bytes));
-  HIPCHECK(hipMemsetAsync(h->small_out.p, 0, off_trace, h->stream));
+  if (h->h_small_bytes < bytes) {
+    if (h->h_small) { BA_SYNC(h); (void)hipHostFree(h->h_small); h->h_small = nullptr; h->h_small_bytes = 0; }
+    HIPCHECK(hipHostMalloc((void**)&h->h_small, bytes, hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHECK(hipHostGetDevicePointer((void**)&h->d_small_host, h->h_small, 0));
+    h->h_small_bytes = bytes;
+  }
+  memset(h->h_small, 0, off_trace);
   SmallArgs A;
-  for (int k = 0; k < 2; ++k) { A.cams[k] = h->cams[k].p; A.cs[k] = h->cs[k].p; A.ptab[k] = h->ptab[k].p; }
+  for (int k = 0; k < 2; ++k) { A.cams[k] = h->cams[k].p; A.cs[k] = h->cs[k].p; A.ptab[k] = h->ptab[k].p; A.camA[k] = h->camA[k].p; }
   A.offk = h->offk.p; A.c_pt = h->c_pt.p; A.c_uv = h->c_uv.p;
   A.pt_off = h->pt_off.p; A.p_cam = h->p_cam.p; A.p_uv = h->p_uv.p;
-  A.Hpp = h->Hpp[h->pb].p; A.bp = h->bp[h->pb].p; A.Hppinv = h->Hppinv[h->pb].p; A.y0 = h->y0[h->pb].p;
+  A.Hpp = h->Hpp[h->pb].p; A.bp = h->bp[h->pb].p; A.Lf = h->Hppinv[h->pb].p; A.y0 = h->y0[h->pb].p;
+  A.Np_pad = (h->Np + 15) & ~15;
+  A.Kp = 3 * A.Np_pad;
+  if (h->small_np_pad != A.Np_pad) {                      // columns of padding points and rows past 6 Nc stay zero for good
+    const size_t nv = (size_t)SMALL_VROWS * A.Kp;
+    HIPCHECK(h->small_V.alloc(nv));
+    HIPCHECK(h->small_gS.alloc((size_t)SMALL_WAVES * SMALL_TILES * 256 + 16));      // + 16 words of diagnostic stamps
+    HIPCHECK(hipMemsetAsync(h->small_V.p, 0, nv * sizeof(double), h->stream));
+    h->small_np_pad = A.Np_pad;
+  }
+  A.V = h->small_V.p; A.gS = h->small_gS.p;
   A.n_cams = h->Nc; A.n_pts = h->Np; A.fixed_cam = h->fixed; A.robust = opts->loss == BA_LOSS_HUBER;
   A.fx = h->K4[0]; A.fy = h->K4[1]; A.cx = h->K4[2]; A.cy = h->K4[3]; A.hub_c = opts->f_scale;
   A.max_iters = opts->max_iters; A.ftol = opts->ftol; A.xtol = opts->xtol; A.gtol = opts->gtol; A.lambda0 = opts->initial_lambda;
   A.cur = h->cur;
-  A.summary = (ba_summary*)h->small_out.p;
-  A.cur_out = (int*)(h->small_out.p + off_cur);
-  A.trace = (ba_iter_record*)(h->small_out.p + off_trace);
+  A.summary = (ba_summary*)h->d_small_host;
+  A.cur_out = (int*)(h->d_small_host + off_cur);
+  A.trace = (ba_iter_record*)(h->d_small_host + off_trace);
+  A.host_flag = h->d_flags + 4;
+  A.stamps = getenv("BA_SMALL_STAMPS") ? (long long*)(h->small_gS.p + (size_t)SMALL_WAVES * SMALL_TILES * 256) : nullptr;   // device memory: a host store would stall the wave
+  A.seq = ++h->small_seq;
   {
     Scope sc(h, BA_K_MISC);
     BA_LAUNCH(k_small_lm, dim3(1), dim3(SMALL_THREADS), 0, h->stream, A);
   }
-  int cur_out = h->cur;
-  HIPCHECK(hipMemcpyAsync(sum, h->small_out.p, sizeof(ba_summary), hipMemcpyDeviceToHost, h->stream));
-  HIPCHECK(hipMemcpyAsync(&cur_out, h->small_out.p + off_cur, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  BA_SYNC(h);
+  // the kernel's last act is a system-scope release of the sequence word: summary, parameter set and trace are in host
+  // memory by then, and whatever the caller queues next on the stream is ordered behind the kernel as usual
+  if (int rc = wait_flag(h, 4, A.seq)) return rc;
+  memcpy(sum, h->h_small, sizeof(ba_summary));
   if (sum->status == BA_ERR_NUMERIC)
     return fail(BA_ERR_NUMERIC, sum->iterations == 0 ? "non-finite cost at the initial parameters"
                                                      : "non-finite cost / gradient during the solve (LM iteration %d)", sum->iterations);
   if (sum->iterations > 0) {
     h->trace.resize((size_t)sum->iterations);
-    HIPCHECK(hipMemcpy(h->trace.data(), h->small_out.p + off_trace, sizeof(ba_iter_record) * (size_t)sum->iterations, hipMemcpyDeviceToHost));
+    memcpy(h->trace.data(), h->h_small + off_trace, sizeof(ba_iter_record) * (size_t)sum->iterations);
   }
-  h->cur = cur_out;
-  // the multi-kernel entry points read the packed camera table of the current set: rebuild it from the result
-  BA_LAUNCH(k_cam_prepare, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->cams[h->cur].p, h->cs[h->cur].p, h->camA[h->cur].p, h->Nc);
-  BA_SYNC(h);
+  memcpy(&h->cur, h->h_small + off_cur, sizeof(int));
+  if (A.stamps) {
+    long long st[16];
+    HIPCHECK(hipMemcpy(st, A.stamps, sizeof st, hipMemcpyDeviceToHost));
+    static const char* names[] = {"C1 camera half", "P1 point half + V", "G  [V;z][V;z]^T (MFMA)", "S, g from the tiles", "Cholesky + solves (1 wave)",
+                                  "camera update", "P2 back substitution", "C3 trial cost"};
+    for (int k = 0; k < 8; ++k) fprintf(stderr, "[k_small_lm, LM iteration 2] %-28s %7.2f us\n", names[k], (st[k + 1] - st[k]) * 0.01);
+    fprintf(stderr, "[k_small_lm] wave 0: factor %.2f us, forward %.2f us, backward %.2f us\n", (st[13] - st[4]) * 0.01, (st[14] - st[13]) * 0.01, (st[5] - st[14]) * 0.01);
+    fprintf(stderr, "[k_small_lm] shader clock over the iteration: %.2f GHz\n", (double)(st[10] - st[9]) / ((st[8] - st[0]) * 10.0));
+  }
   h->linearized = false;
   sum->seconds_total = now_s() - t_begin;
   const double per = sum->iterations ? sum->seconds_total / sum->iterations : 0.0;
@@ -1468,11 +1500,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   if (set_device(h)) return BA_ERR_HIP;
   memset(sum, 0, sizeof *sum);
   h->trace.clear();
-  if (small_applies(h, opts)) {
-    if (opts->loss != BA_LOSS_LINEAR && opts->loss != BA_LOSS_HUBER) return fail(BA_ERR_INVALID, "unknown loss");
-    if (set_device(h)) return BA_ERR_HIP;
-    return small_solve(h, opts, sum);
-  }
+  if (small_applies(h, opts)) return small_solve(h, opts, sum);
   roctx_load();
   Range r_solve("ba_solve");
   const bool robust = opts->loss == BA_LOSS_HUBER;

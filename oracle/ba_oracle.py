@@ -501,9 +501,11 @@ def pcg(op, rhs, Minv, tol, max_iters, min_iters=0):
 
 def lm_solve(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam=-1, loss='linear',
              max_iters=50, ftol=1e-10, xtol=1e-10, gtol=1e-10, lam0=1e-4,
-             pcg_tol=1e-1, pcg_max_iters=200, precond='schur_jacobi', verbose=False):
+             pcg_tol=1e-1, pcg_max_iters=200, precond='schur_jacobi', verbose=False, linear_solver='pcg'):
     """CPU mirror of the device LM / Schur / PCG loop (same formulas, same update
     rules, same stopping tests) -- see ba_solve in bundle_adjustment_amd/csrc/ba_hip.hip.
+    linear_solver='dense' solves the explicit reduced system (schur_dense) exactly instead, as the
+    single-launch solver for window-sized problems does (csrc/ba_small.hpp).
     Returns dict(cams, pts, iterations, accepted, sse0, sse, cost0, cost, pcg_iters,
     history)."""
     cams = np.array(cams, dtype=np.float64).reshape(-1, 6)
@@ -530,7 +532,11 @@ def lm_solve(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam=-1, loss='linear',
         Minv = np.linalg.inv(D)
         if precond == 'two_level':
             Minv = two_level_apply(Minv, np.linalg.inv(coarse_matrix(op, fixed_cam)), fixed_cam)
-        dc, k, rfin = pcg(op, rhs, Minv, pcg_tol, pcg_max_iters)
+        if linear_solver == 'dense':
+            S_, g_, _, _ = schur_dense(ne, cam_idx, pt_idx, lam, fixed_cam)
+            dc, k, rfin = np.linalg.solve(S_, g_).reshape(-1, 6), 0, np.zeros_like(rhs)
+        else:
+            dc, k, rfin = pcg(op, rhs, Minv, pcg_tol, pcg_max_iters)
         pcg_total += k
         dp = op.back_substitute(dc)
         # model decrease of the damped, inexactly solved system (LM section)

@@ -64,6 +64,61 @@ def test_small_solver_converged_rmse_matches_scipy_goldens(name):
     assert abs(out["final_cost"] - float(g["res_cost"])) <= 1e-8 * float(g["res_cost"])
 
 
+def _with_duplicates(p, n_dup, seed):
+    """n_dup extra observations that repeat an existing (camera, point) pair with a slightly different pixel."""
+    rng = np.random.default_rng(seed)
+    pick = rng.choice(p.n_obs, n_dup, replace=False)
+    return type(p)(p.cams, p.pts, np.concatenate([p.cam_idx, p.cam_idx[pick]]), np.concatenate([p.pt_idx, p.pt_idx[pick]]),
+                   np.concatenate([p.uv, p.uv[pick] + rng.normal(0, 0.5, (n_dup, 2))]), p.K4, p.fixed_cam)
+
+
+@pytest.mark.parametrize("n_cams,n_pts,k,loss,dups", [
+    (2, 37, 2, "huber", 0),         # 12 + 1 rows: 1 tile row
+    (3, 130, 3, "linear", 5),       # 18 + 1 rows: 2 tile rows; repeated (camera, point) pairs add up inside V
+    (5, 333, 4, "huber", 0),        # 30 + 1 rows; a point count that is no multiple of 16
+    (6, 700, 4, "linear", 9),       # 36 + 1 rows: 3 tile rows; more points than threads
+    (7, 256, 5, "huber", 0),        # 42 + 1 rows
+    (8, 513, 6, "linear", 0),       # 48 + 1 rows: the z row alone in tile row 3
+])
+def test_small_solver_follows_the_oracles_dense_lm_step_by_step(n_cams, n_pts, k, loss, dups):
+    """Every LM iteration of k_small_lm against the oracle's LM with the explicit reduced system solved exactly
+    (oracle lm_solve(linear_solver='dense')): trial cost, gain ratio, damping and acceptance per iteration, then the
+    final parameters.  fp64 throughout; the device forms S with fp64 MFMA tiles and a Cholesky factorisation, numpy with
+    LAPACK's LU -- agreement to 1e-9 relative per iteration is what the two orders of summation leave."""
+    p = make_problem(n_cams, n_pts, min(k, n_cams), seed=17 + n_cams, outlier_frac=0.03 if loss == "huber" else 0.0)
+    if dups:
+        p = _with_duplicates(p, dups, seed=n_cams)
+    iters = 6
+    ref = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, fixed_cam=p.fixed_cam, loss=loss, max_iters=iters,
+                     ftol=0.0, xtol=0.0, gtol=0.0, linear_solver="dense")
+    with hip_backend.Solver(0) as s:
+        s.set_problem(p)
+        out = s.solve(loss=loss, max_iters=iters, ftol=0.0, xtol=0.0, gtol=0.0)
+        tr = s.trace()
+        cams, pts = s.get_params()
+    assert out["pcg_iterations"] == 0 and out["iterations"] == iters == len(ref["history"])
+    for t, h in zip(tr, ref["history"]):
+        assert abs(t["cost"] - h["cost"]) <= 1e-9 * h["cost"]
+        assert abs(t["cost_trial"] - h["cost_new"]) <= 1e-9 * h["cost_new"], (t, h)
+        assert abs(t["damping"] - h["lam"]) <= 1e-6 * h["lam"]
+        assert bool(t["accepted"]) == bool(h["rho"] > 0)
+        assert abs(t["step_norm"] - h["step"]) <= 1e-7 * max(h["step"], 1e-12)
+    assert abs(out["final_cost"] - ref["cost"]) <= 1e-9 * ref["cost"]
+    assert np.abs(cams - ref["cams"]).max() <= 1e-7 * max(1.0, np.abs(ref["cams"]).max())
+    assert np.abs(pts - ref["pts"]).max() <= 1e-7 * max(1.0, np.abs(ref["pts"]).max())
+
+
+def test_small_solver_with_only_the_fixed_camera():
+    """One keyframe, fixed: nothing but points move, each onto the ray of its single observation (cost -> 0)."""
+    p = make_problem(1, 40, 1, seed=18)
+    with hip_backend.Solver(0) as s:
+        s.set_problem(p)
+        out = s.solve(max_iters=8, ftol=0.0, xtol=0.0, gtol=0.0)
+        cams, _ = s.get_params()
+    assert out["pcg_iterations"] == 0 and out["final_cost"] <= 1e-12 * out["initial_cost"]
+    assert np.array_equal(cams, p.cams)
+
+
 def test_small_solver_is_bit_reproducible_and_honours_the_options():
     p = make_problem(8, 1200, 5, seed=9, outlier_frac=0.02)
     with hip_backend.Solver(0) as s:

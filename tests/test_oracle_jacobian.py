@@ -66,3 +66,18 @@ def test_right_jacobian_series_is_continuous():
         b, d = (1 - np.cos(t)) / t**2 if t > 1e-6 else 0.5, (t - np.sin(t)) / t**3 if t > 1e-3 else 1 / 6
         rx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]]) * t
         np.testing.assert_allclose(M, np.eye(3) - b * rx + d * rx @ rx, atol=1e-9)
+
+
+def test_dense_and_matrix_free_reduced_systems_give_the_same_lm_trajectory():
+    """oracle lm_solve(linear_solver='dense') -- the checker of the single-launch window solver (csrc/ba_small.hpp) --
+    against the same loop with the matrix-free operator and PCG driven to round-off: the explicit Schur complement and
+    its right-hand side are the operator's, so every trial cost agrees."""
+    from bundle_adjustment_amd.synthetic import make_problem
+    p = make_problem(4, 60, 3, seed=1, outlier_frac=0.05)
+    kw = dict(fixed_cam=0, loss="huber", max_iters=5, ftol=0.0, xtol=0.0, gtol=0.0)
+    a = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, linear_solver="dense", **kw)
+    b = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, pcg_tol=1e-13, pcg_max_iters=2000, **kw)
+    assert a["pcg_iters"] == 0 and b["pcg_iters"] > 0
+    for ha, hb in zip(a["history"], b["history"]):
+        assert abs(ha["cost_new"] - hb["cost_new"]) <= 1e-10 * hb["cost_new"]
+        assert abs(ha["step"] - hb["step"]) <= 1e-8 * hb["step"]
