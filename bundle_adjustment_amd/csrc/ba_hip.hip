@@ -1418,7 +1418,8 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
 // Sliding-window-sized problems (ba_small.hpp): the whole LM loop in one kernel launch, dense Cholesky of the reduced
 // system instead of PCG.  Same options, summary and trace as the multi-kernel path.
 static bool small_applies(const ba_handle* h, const ba_options* opts) {
-  return opts->small_solver == 0 && !h->multi && h->Nc <= SMALL_MAX_CAMS && h->Np > 0 && h->Nobs > 0 && h->Nobs <= 65536 &&
+  static const long max_obs = [] { const char* e = getenv("BA_SMALL_MAX_OBS"); return e ? atol(e) : (long)SMALL_DEFAULT_MAX_OBS; }();
+  return opts->small_solver == 0 && !h->multi && h->Nc <= SMALL_MAX_CAMS && h->Np > 0 && h->Nobs > 0 && h->Nobs <= max_obs &&
          opts->max_iters >= 1 && getenv("BA_NO_SMALL_SOLVER") == nullptr;
 }
 static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {

@@ -35,6 +35,8 @@ namespace ba {
 constexpr int SMALL_MAX_CAMS = 8;
 constexpr int SMALL_N = 6 * SMALL_MAX_CAMS;       // reduced system dimension bound
 constexpr int SMALL_THREADS = 512;
+constexpr int SMALL_DEFAULT_MAX_OBS = 6144;      // ba_solve dispatches here up to this many observations (BA_SMALL_MAX_OBS);
+                                                  // measured crossover with the multi-kernel path: ~6 k (tools/small_crossover.py)
 constexpr int SMALL_WAVES = SMALL_THREADS / 64;
 constexpr int SMALL_VROWS = 64;                   // rows of V: 6 Nc camera rows, then z = L^T bp, zero up to the tile edge
 constexpr int SMALL_TILES = 9;                    // 16x16 tiles (ti <= tj) of the 49 x 49 product that are needed

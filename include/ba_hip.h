@@ -68,9 +68,10 @@ typedef struct ba_options {
   int32_t reserved0;       /* must be 0 */
   int32_t profile;         /* 1 = bracket every kernel with HIP events (see ba_get_profile) */
   int32_t verbose;
-  int32_t small_solver;    /* 0 = problems of at most 8 cameras on one rank (the reference's sliding window, window_size 5) are
-                              solved by the single-launch direct solver (csrc/ba_small.hpp: dense Cholesky of the reduced
-                              system, whole LM loop in one workgroup); 1 = always the multi-kernel LM / Schur / PCG path */
+  int32_t small_solver;    /* 0 = problems of at most 8 cameras and 6144 observations on one rank (the reference's sliding
+                              window, src/pipeline.py:39 window_size 5) are solved by the single-launch window solver
+                              (csrc/ba_small.hpp: whole LM loop in one kernel, reduced system formed by fp64 MFMA and
+                              factorised exactly); 1 = always the multi-kernel LM / Schur / PCG path */
 } ba_options;
 
 typedef struct ba_summary {
