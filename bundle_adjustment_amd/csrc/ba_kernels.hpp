@@ -687,22 +687,27 @@ constexpr int FILL_BATCH = 9;
 #ifndef BA_FILL_DMA
 #define BA_FILL_DMA 1
 #endif
-template <int BLOCK>
-__device__ inline void fill_cam_table(double* __restrict__ tab, const double* __restrict__ camA, int lo, int n) {
+// The copy in two halves: fill_cam_table_issue starts it, fill_cam_table_wait ends it (wait + workgroup barrier); what a
+// kernel does in between overlaps the copy's round trips.  SKIP_WAVE0: wave 0 has other work in between (the PCG probe)
+// and takes no share of the copy -- its probe loads would otherwise queue behind its share.
+template <int BLOCK, bool SKIP_WAVE0 = false>
+__device__ inline void fill_cam_table_issue(double* __restrict__ tab, const double* __restrict__ camA, int lo, int n) {
   const double2* src = (const double2*)(camA + TA * (size_t)lo);
   const int total = n * TA / 2;
 #if BA_FILL_DMA
   // LDS-DMA (global_load_lds_dwordx4, gfx950): 16 bytes per lane straight into LDS at (wave-uniform base) + lane * 16,
   // no staging registers and no ds_write issue slots; a wave copies whole 1 KB pieces, the lanes past the end of the
   // table sit out (an inactive lane neither loads nor stores).  The copy is invisible to the compiler: the explicit
-  // vmcnt(0) keeps every later LDS read behind it.
+  // vmcnt(0) of fill_cam_table_wait keeps every later LDS read behind it.
   {
     // Every workgroup copies the same table at the same time: each starts at a different piece, so that the
     // workgroups of an XCD are not all on the same L2 channel at any moment.
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int NW = BLOCK / 64 - (SKIP_WAVE0 ? 1 : 0);
+    const int wave = (int)(threadIdx.x >> 6) - (SKIP_WAVE0 ? 1 : 0), lane = threadIdx.x & 63;
+    if (SKIP_WAVE0 && wave < 0) return;
     const int npieces = (total + 63) / 64;
     const int rot = (int)((blockIdx.x * 37u) % (unsigned)npieces);
-    for (int q = wave; q < npieces; q += BLOCK / 64) {
+    for (int q = wave; q < npieces; q += NW) {
       int piece = q + rot;
       if (piece >= npieces) piece -= npieces;
       const int i = piece * 64 + lane;
@@ -710,8 +715,6 @@ __device__ inline void fill_cam_table(double* __restrict__ tab, const double* __
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i),
                                          (__attribute__((address_space(3))) void*)(tab + piece * 128), 16, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
     return;
   }
 #endif
@@ -728,17 +731,27 @@ __device__ inline void fill_cam_table(double* __restrict__ tab, const double* __
       if (i < total) ((double2*)tab)[i] = v[u];
     }
   }
+}
+__device__ inline void fill_cam_table_wait() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 }
+template <int BLOCK>
+__device__ inline void fill_cam_table(double* __restrict__ tab, const double* __restrict__ camA, int lo, int n) {
+  fill_cam_table_issue<BLOCK>(tab, camA, lo, n);
+  fill_cam_table_wait();
+}
 // deterministic workgroup sum of N values held by every wave's lane 0 -> thread 0
-template <int N, int BLOCK>
-__device__ inline void block_combine(double (&v)[N], double* __restrict__ sm) {
+template <int N, int BLOCK, int M>
+__device__ inline void block_combine(double (&v)[M], double* __restrict__ sm) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (lane == 0) {
 #pragma unroll
     for (int q = 0; q < N; ++q) sm[wv * N + q] = v[q];
   }
-  __syncthreads();
+  // Only the LDS words above cross this barrier.  __syncthreads() would also wait for every global store the wave has
+  // in flight (the point records just written: a round trip to L2 nobody in this workgroup needs).
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int q = 0; q < N; ++q) {
@@ -992,22 +1005,27 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
     beg0 = pt_off[p0];
     end0 = pt_off[p0 + 1];
   }
+  const bool use_lds = ALL_LDS || (size_t)win.y * TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
+  bool table_ready = !use_lds;
+  // The table copy starts BEFORE the PCG verdict is known: the copy does not depend on it (the previous kernel of the
+  // stream wrote the table), and its round trips hide the probe's.  A launch that turns out to be past the end of PCG
+  // pays for a copy it does not use -- one launch per LM iteration against a round trip saved in every working one.
+  __shared__ int s_fin;
+  if (use_lds) fill_cam_table_issue<PT_THREADS, MODE == 0>(tab, camA, win.x, win.y);
   if (MODE == 0) {
-    // wave 0 sums the vector kernel's partials and decides for the workgroup (the other waves would wait at
-    // the table-fill barrier anyway)
-    __shared__ int s_fin;
+    // wave 0 sums the vector kernel's partials and decides for the workgroup while the other waves copy
     if (threadIdx.x < 64) {
       const bool fin = pcg_probe(kit, st, partV, nblkV, tol2, min_iters, host_flag, flag_base, verdict, partG, nG, partGc, nGc, gmax_out);
       if (threadIdx.x == 0) s_fin = fin ? 1 : 0;
     }
-    __syncthreads();
-    if (s_fin) return;
     BA_STAMP(0, 2);
+    if (!use_lds) {
+      __syncthreads();
+      if (s_fin) return;
+    }
   }
-  const bool use_lds = ALL_LDS || (size_t)win.y * TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
   const int sub = threadIdx.x % LANES;
   double acc[4] = {0, 0, 0, 0};
-  bool table_ready = !use_lds;
   for (int sb = sb0; sb < send; sb += PT_THREADS / LANES) {
     const int sl = sb + threadIdx.x / LANES;
     int p = -1, j = 0, end = 0, c = 0, cn = 0;   // ROBUST: p_cam is the flagged copy
@@ -1037,7 +1055,11 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
         }
       }
     }
-    if (!table_ready) { fill_cam_table<PT_THREADS>(tab, camA, win.x, win.y); table_ready = true; }
+    if (!table_ready) {
+      fill_cam_table_wait();
+      table_ready = true;
+      if (MODE == 0 && s_fin) return;
+    }
     if (MODE == 0 && sb == sb0) BA_STAMP(0, 3);
     if (p >= 0) {
       while (j < end) {
@@ -1092,10 +1114,15 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
       }
     }
   }
+  if (!table_ready) {                      // a workgroup without a single slot: the copy must still land before it leaves
+    fill_cam_table_wait();
+    if (MODE == 0 && s_fin) return;
+  }
   if (MODE == 0) BA_STAMP(0, 5);
+  constexpr int NACC = MODE == 0 ? 1 : 4;          // the PCG pass carries one sum (u . y), the back substitution four
 #pragma unroll
-  for (int q = 0; q < 4; ++q) acc[q] = wave_total_dpp(acc[q]);
-  block_combine<4, PT_THREADS>(acc, sm);
+  for (int q = 0; q < NACC; ++q) acc[q] = wave_total_dpp(acc[q]);
+  block_combine<NACC, PT_THREADS, 4>(acc, sm);
   if (threadIdx.x == 0) {
     if (MODE == 0) partA[wk.blk_base + rb] = acc[0];
     else { for (int q = 0; q < 4; ++q) partB[4 * (wk.blk_base + rb) + q] = acc[q]; }
