@@ -1,0 +1,530 @@
+// The solve step for the BAL 9-parameter camera [rvec | t | f k1 k2] (BASELINE config 5 is stated
+// on a BAL problem).  The reference has no counterpart: its only camera is cv2.projectPoints(..., distCoeffs=None)
+// (src/bundle_adjuster.py:67) with one shared K.  Same algorithm as ba_solve -- LM, Schur complement on the cameras,
+// matrix-free PCG, IRLS Huber, every sum in a fixed order -- with 9x9 camera blocks:
+//
+//   camera model   P = R(rvec) X + t,  p = -P.xy / P.z,  proj = f (1 + k1 |p|^2 + k2 |p|^4) p,  residual = uv - proj
+//   blocks         A = d proj / d P (2x3, full: the radial term couples x and y),  B = A R
+//                  Jp = -B;  Jc = [ (B_row x X) M | -A | -rad p | -f n2 p | -f n2^2 p ]     (M: right Jacobian of SO(3))
+//
+// These are first-version kernels: correct, deterministic, resident on the device, but written for clarity, not tuned
+// like the 6-parameter family in ba_kernels.hpp (no LDS camera table, one thread per point, one workgroup for the
+// camera-vector algebra).  Camera-major passes reuse that family's (camera, partition) wave mapping and its wave sums;
+// the host loop (ba_solve_bal in ba_hip.hip) mirrors oracle.lm_solve(model='bal', precond='jacobi') line by line.
+#pragma once
+#include "ba_kernels.hpp"
+
+namespace ba {
+
+constexpr int BC = 9;                 // parameters per BAL camera
+constexpr int BH = 45;                // packed upper triangle of a 9x9 block
+constexpr int BLIN = BH + BC + 2;     // running sums of the camera half: Hcc | bc | sum r^2 | sum rho-term
+constexpr int BAL_VEC_THREADS = 1024; // the camera-vector kernels are ONE workgroup
+constexpr int BAL_PT_THREADS = 256;
+
+__host__ __device__ constexpr int U9(int a, int b) { return a * 9 - a * (a - 1) / 2 + (b - a); }   // a <= b
+
+struct BalObs {
+  double r0, r1;          // residual
+  double A[6];            // d proj / d P, rows (u, v)
+  double B[6];            // A R
+  double p0, p1, n2, rad, f;
+};
+
+__device__ inline void bal_obs(const double* __restrict__ cs, double f, double k1, double k2, double X0, double X1, double X2,
+                               double u, double v, BalObs& g) {
+  const double Px = cs[0] * X0 + cs[1] * X1 + cs[2] * X2 + cs[9];
+  const double Py = cs[3] * X0 + cs[4] * X1 + cs[5] * X2 + cs[10];
+  const double Pz = cs[6] * X0 + cs[7] * X1 + cs[8] * X2 + cs[11];
+  const double iz = (Pz != 0.0) ? 1.0 / Pz : 1.0;             // guarded like K1 (obs_project)
+  const double p0 = -Px * iz, p1 = -Py * iz;
+  const double n2 = p0 * p0 + p1 * p1;
+  const double rad = 1.0 + n2 * (k1 + k2 * n2), drad = k1 + 2.0 * k2 * n2;
+  g.p0 = p0; g.p1 = p1; g.n2 = n2; g.rad = rad; g.f = f;
+  g.r0 = u - f * rad * p0;
+  g.r1 = v - f * rad * p1;
+  const double d00 = f * (rad + 2.0 * drad * p0 * p0), d01 = f * 2.0 * drad * p0 * p1, d11 = f * (rad + 2.0 * drad * p1 * p1);
+  // d p / d P = [-iz 0 Px iz^2; 0 -iz Py iz^2] = -iz [1 0 p0; 0 1 p1]
+  g.A[0] = -iz * d00; g.A[1] = -iz * d01; g.A[2] = -iz * (d00 * p0 + d01 * p1);
+  g.A[3] = -iz * d01; g.A[4] = -iz * d11; g.A[5] = -iz * (d01 * p0 + d11 * p1);
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g.B[3 * r + k] = g.A[3 * r] * cs[k] + g.A[3 * r + 1] * cs[3 + k] + g.A[3 * r + 2] * cs[6 + k];
+}
+
+// the two rows of Jc (9 each) at one observation
+__device__ inline void bal_cam_rows(const double* __restrict__ cs, const BalObs& g, double X0, double X1, double X2,
+                                    double (&J0)[BC], double (&J1)[BC]) {
+  const double* M = cs + 12;
+  const double a0 = g.B[1] * X2 - g.B[2] * X1, a1 = g.B[2] * X0 - g.B[0] * X2, a2 = g.B[0] * X1 - g.B[1] * X0;   // B_0 x X
+  const double b0 = g.B[4] * X2 - g.B[5] * X1, b1 = g.B[5] * X0 - g.B[3] * X2, b2 = g.B[3] * X1 - g.B[4] * X0;   // B_1 x X
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    J0[q] = a0 * M[q] + a1 * M[3 + q] + a2 * M[6 + q];
+    J1[q] = b0 * M[q] + b1 * M[3 + q] + b2 * M[6 + q];
+    J0[3 + q] = -g.A[q];
+    J1[3 + q] = -g.A[3 + q];
+  }
+  J0[6] = -g.rad * g.p0;             J1[6] = -g.rad * g.p1;
+  J0[7] = -g.f * g.n2 * g.p0;        J1[7] = -g.f * g.n2 * g.p1;
+  J0[8] = -g.f * g.n2 * g.n2 * g.p0; J1[8] = -g.f * g.n2 * g.n2 * g.p1;
+}
+
+__device__ inline void bal_weights(bool robust, const BalObs& g, double hub_c, double& w0, double& w1, double& rho) {
+  w0 = 1.0; w1 = 1.0;
+  rho = g.r0 * g.r0 + g.r1 * g.r1;
+  if (robust) { double t0, t1; huber(g.r0, hub_c, t0, w0); huber(g.r1, hub_c, t1, w1); rho = t0 + t1; }
+}
+
+// ---- K2, camera half: partL[(k Nc + c) BLIN + q] = sums over partition k of camera c
+template <bool ROBUST>
+__global__ void __launch_bounds__(64 * WPB)
+k_bal_lin_cam(const double* __restrict__ cs, const double* __restrict__ intr, const double* __restrict__ ptab,
+              const int* __restrict__ offk, const int* __restrict__ c_pt, const double2* __restrict__ c_uv, double hub_c,
+              int n_cams, int band, int fixed_cam, double* __restrict__ partL) {
+  Seg s;
+  if (!cam_segment(offk, n_cams, band, s)) return;
+  const double* cam = cs + CS * s.c;
+  const double f = intr[3 * s.c], k1 = intr[3 * s.c + 1], k2 = intr[3 * s.c + 2];
+  double acc[BLIN];
+#pragma unroll
+  for (int q = 0; q < BLIN; ++q) acc[q] = 0.0;
+  for (int i = s.beg + s.lane; i < s.end; i += 64) {
+    const double4 X = *(const double4*)(ptab + PT * (size_t)c_pt[i]);
+    const double2 uv = c_uv[i];
+    BalObs g;
+    bal_obs(cam, f, k1, k2, X.x, X.y, X.z, uv.x, uv.y, g);
+    double w0, w1, rho;
+    bal_weights(ROBUST, g, hub_c, w0, w1, rho);
+    acc[BH + BC] += g.r0 * g.r0 + g.r1 * g.r1;
+    acc[BH + BC + 1] += rho;
+    if (s.c != fixed_cam) {
+      double J0[BC], J1[BC];
+      bal_cam_rows(cam, g, X.x, X.y, X.z, J0, J1);
+#pragma unroll
+      for (int a = 0; a < BC; ++a) {
+        const double wa0 = w0 * J0[a], wa1 = w1 * J1[a];
+#pragma unroll
+        for (int b = a; b < BC; ++b) acc[U9(a, b)] += wa0 * J0[b] + wa1 * J1[b];
+        acc[BH + a] += wa0 * g.r0 + wa1 * g.r1;
+      }
+    }
+  }
+  wave_store_sums<BLIN>(acc, s.lane, partL + ((size_t)s.k * n_cams + s.c) * BLIN);
+}
+
+// ---- K2, point half (thread = point): Hpp (6 packed), bp (3), block maximum of |bp|
+template <bool ROBUST>
+__global__ void __launch_bounds__(BAL_PT_THREADS)
+k_bal_lin_pt(const double* __restrict__ cs, const double* __restrict__ intr, const double* __restrict__ ptab,
+             const int* __restrict__ pt_off, const int* __restrict__ p_cam, const double2* __restrict__ p_uv, double hub_c,
+             int n_pts, double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ partG) {
+  __shared__ double sm[BAL_PT_THREADS / 64];
+  const int p = blockIdx.x * BAL_PT_THREADS + threadIdx.x;
+  double gm = 0.0;
+  if (p < n_pts) {
+    const double4 X = *(const double4*)(ptab + PT * (size_t)p);
+    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = pt_off[p]; j < pt_off[p + 1]; ++j) {
+      const int c = p_cam[j];
+      const double2 uv = p_uv[j];
+      BalObs g;
+      bal_obs(cs + CS * (size_t)c, intr[3 * c], intr[3 * c + 1], intr[3 * c + 2], X.x, X.y, X.z, uv.x, uv.y, g);
+      double w0, w1, rho;
+      bal_weights(ROBUST, g, hub_c, w0, w1, rho);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const double wa0 = w0 * g.B[q], wa1 = w1 * g.B[3 + q];          // Jp = -B: Jp^T w Jp = B^T w B
+#pragma unroll
+        for (int r = q; r < 3; ++r) a[U3(q, r)] += wa0 * g.B[r] + wa1 * g.B[3 + r];
+        a[6 + q] -= wa0 * g.r0 + wa1 * g.r1;                              // Jp^T w r
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) Hpp[6 * (size_t)p + q] = a[q];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { bp[3 * (size_t)p + q] = a[6 + q]; gm = nanmax(gm, fabs(a[6 + q])); }
+  }
+  gm = wave_nanmax(gm);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = gm;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = 0.0;
+    for (int w = 0; w < BAL_PT_THREADS / 64; ++w) m = nanmax(m, sm[w]);
+    partG[blockIdx.x] = m;
+  }
+}
+
+// ---- point pass of the Schur product (thread = point).  u = sum_o Jp^T w (Jc v_c);
+//   MODE 0 (PCG): y = Hppinv u into the point record's y slot.
+//   MODE 1 (back substitution, v = dc): dp = -(y0 + Hppinv u), trial point, partB[block][4] = bp.dp, sum Dp dp^2, |dp|^2, |X|^2
+template <bool ROBUST, int MODE>
+__global__ void __launch_bounds__(BAL_PT_THREADS)
+k_bal_pt_schur(const double* __restrict__ cs, const double* __restrict__ intr, double* __restrict__ ptab,
+               const int* __restrict__ pt_off, const int* __restrict__ p_cam, const double2* __restrict__ p_uv, double hub_c,
+               int n_pts, int fixed_cam, const double* __restrict__ vec, const double* __restrict__ Hppinv,
+               const double* __restrict__ y0, const double* __restrict__ Hpp, const double* __restrict__ bp,
+               double* __restrict__ ptab_trial, double* __restrict__ partB) {
+  __shared__ double sm[4 * (BAL_PT_THREADS / 64)];
+  const int p = blockIdx.x * BAL_PT_THREADS + threadIdx.x;
+  double acc[4] = {0, 0, 0, 0};
+  if (p < n_pts) {
+    const double4 X = *(const double4*)(ptab + PT * (size_t)p);
+    double u[3] = {0, 0, 0};
+    for (int j = pt_off[p]; j < pt_off[p + 1]; ++j) {
+      const int c = p_cam[j];
+      if (c == fixed_cam) continue;
+      const double2 uv = p_uv[j];
+      const double* cam = cs + CS * (size_t)c;
+      BalObs g;
+      bal_obs(cam, intr[3 * c], intr[3 * c + 1], intr[3 * c + 2], X.x, X.y, X.z, uv.x, uv.y, g);
+      double w0, w1, rho;
+      bal_weights(ROBUST, g, hub_c, w0, w1, rho);
+      double J0[BC], J1[BC];
+      bal_cam_rows(cam, g, X.x, X.y, X.z, J0, J1);
+      const double* v = vec + BC * (size_t)c;
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int q = 0; q < BC; ++q) { s0 += J0[q] * v[q]; s1 += J1[q] * v[q]; }
+      s0 *= w0; s1 *= w1;
+      u[0] -= g.B[0] * s0 + g.B[3] * s1;                      // Jp^T (.), Jp = -B
+      u[1] -= g.B[1] * s0 + g.B[4] * s1;
+      u[2] -= g.B[2] * s0 + g.B[5] * s1;
+    }
+    double hi[6], yy[3];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) hi[q] = Hppinv[6 * (size_t)p + q];
+    sym3_mul(hi, u, yy);
+    if (MODE == 0) {
+      double* o = ptab + PT * (size_t)p + 4;
+      o[0] = yy[0]; o[1] = yy[1]; o[2] = yy[2];
+    } else {
+      const double d0 = -(y0[3 * (size_t)p] + yy[0]), d1 = -(y0[3 * (size_t)p + 1] + yy[1]), d2 = -(y0[3 * (size_t)p + 2] + yy[2]);
+      double* o = ptab_trial + PT * (size_t)p;
+      o[0] = X.x + d0; o[1] = X.y + d1; o[2] = X.z + d2;
+      const double D0 = fmax(Hpp[6 * (size_t)p], DIAG_FLOOR), D1 = fmax(Hpp[6 * (size_t)p + 3], DIAG_FLOOR),
+                   D2 = fmax(Hpp[6 * (size_t)p + 5], DIAG_FLOOR);
+      acc[0] = bp[3 * (size_t)p] * d0 + bp[3 * (size_t)p + 1] * d1 + bp[3 * (size_t)p + 2] * d2;
+      acc[1] = D0 * d0 * d0 + D1 * d1 * d1 + D2 * d2 * d2;
+      acc[2] = d0 * d0 + d1 * d1 + d2 * d2;
+      acc[3] = X.x * X.x + X.y * X.y + X.z * X.z;
+    }
+  }
+  if (MODE == 1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = wave_total_dpp(acc[q]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sm[(threadIdx.x >> 6) * 4 + q] = acc[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      double a = 0.0;
+      for (int w = 0; w < BAL_PT_THREADS / 64; ++w) a += sm[w * 4 + threadIdx.x];
+      partB[4 * (size_t)blockIdx.x + threadIdx.x] = a;
+    }
+  }
+}
+
+// ---- camera pass of the Schur product: part9[(k Nc + c) 9 + q] = sum over partition k of Jc^T w (Jp y_p), y in the point record
+template <bool ROBUST>
+__global__ void __launch_bounds__(64 * WPB)
+k_bal_cam_schur(const double* __restrict__ cs, const double* __restrict__ intr, const double* __restrict__ ptab,
+                const int* __restrict__ offk, const int* __restrict__ c_pt, const double2* __restrict__ c_uv, double hub_c,
+                int n_cams, int band, int fixed_cam, double* __restrict__ part9) {
+  Seg s;
+  if (!cam_segment(offk, n_cams, band, s)) return;
+  const double* cam = cs + CS * s.c;
+  const double f = intr[3 * s.c], k1 = intr[3 * s.c + 1], k2 = intr[3 * s.c + 2];
+  double acc[BC];
+#pragma unroll
+  for (int q = 0; q < BC; ++q) acc[q] = 0.0;
+  if (s.c != fixed_cam) {
+    for (int i = s.beg + s.lane; i < s.end; i += 64) {
+      const double* rec = ptab + PT * (size_t)c_pt[i];
+      const double4 X = *(const double4*)rec;
+      const double y0 = rec[4], y1 = rec[5], y2 = rec[6];
+      const double2 uv = c_uv[i];
+      BalObs g;
+      bal_obs(cam, f, k1, k2, X.x, X.y, X.z, uv.x, uv.y, g);
+      double w0, w1, rho;
+      bal_weights(ROBUST, g, hub_c, w0, w1, rho);
+      double J0[BC], J1[BC];
+      bal_cam_rows(cam, g, X.x, X.y, X.z, J0, J1);
+      const double t0 = -w0 * (g.B[0] * y0 + g.B[1] * y1 + g.B[2] * y2);       // w (Jp y), Jp = -B
+      const double t1 = -w1 * (g.B[3] * y0 + g.B[4] * y1 + g.B[5] * y2);
+#pragma unroll
+      for (int q = 0; q < BC; ++q) acc[q] += J0[q] * t0 + J1[q] * t1;
+    }
+  }
+  wave_store_sums<BC>(acc, s.lane, part9 + ((size_t)s.k * n_cams + s.c) * BC);
+}
+
+// ---- camera-vector algebra, one workgroup.  Deterministic workgroup sum: wave sums by DPP, the waves in order.
+template <int N>
+__device__ inline void bal_block_sum(double (&v)[N], double* __restrict__ sm /* [16][N] */) {
+#pragma unroll
+  for (int q = 0; q < N; ++q) v[q] = wave_total_dpp(v[q]);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();                               // sm may still be read from the previous sum
+  if (lane == 0) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) sm[wv * N + q] = v[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    double a = 0.0;
+    for (int w = 0; w < BAL_VEC_THREADS / 64; ++w) a += sm[w * N + q];
+    v[q] = a;
+  }
+}
+
+__device__ inline void sym9_mul(const double* __restrict__ h /* packed 45 */, const double* __restrict__ v, double* __restrict__ o) {
+#pragma unroll
+  for (int a = 0; a < BC; ++a) {
+    double s = 0.0;
+#pragma unroll
+    for (int b = 0; b < BC; ++b) s += h[a <= b ? U9(a, b) : U9(b, a)] * v[b];
+    o[a] = s;
+  }
+}
+
+// Linearisation -> damped blocks and their inverses (block-Jacobi preconditioner).  relin: fold the camera half's
+// partition sums into HccBc first (a rejected step only re-damps).  Also the initial cost of this linearisation.
+__global__ void __launch_bounds__(BAL_VEC_THREADS)
+k_bal_prep(const double* __restrict__ partL, int relin, double lambda, int n_cams, int fixed_cam, double* __restrict__ HccBc,
+           double* __restrict__ Hd, double* __restrict__ Minv, double* __restrict__ out /* [0] sse, [1] rho-sum (relin only) */) {
+  __shared__ double sm[(BAL_VEC_THREADS / 64) * 2];
+  double cs2[2] = {0.0, 0.0};
+  for (int c = threadIdx.x; c < n_cams; c += BAL_VEC_THREADS) {
+    double h[BH + BC];
+    if (relin) {
+      double e[2] = {0.0, 0.0};
+#pragma unroll
+      for (int q = 0; q < BH + BC; ++q) h[q] = 0.0;
+      for (int k = 0; k < NPART; ++k) {
+        const double* src = partL + ((size_t)k * n_cams + c) * BLIN;
+#pragma unroll
+        for (int q = 0; q < BH + BC; ++q) h[q] += src[q];
+        e[0] += src[BH + BC]; e[1] += src[BH + BC + 1];
+      }
+#pragma unroll
+      for (int q = 0; q < BH + BC; ++q) HccBc[(size_t)c * (BH + BC) + q] = h[q];
+      cs2[0] += e[0]; cs2[1] += e[1];
+    } else {
+#pragma unroll
+      for (int q = 0; q < BH; ++q) h[q] = HccBc[(size_t)c * (BH + BC) + q];
+    }
+    // damped block, its Cholesky factor and inverse (dense 9x9 in private memory; once per damping change)
+    double Lm[BC][BC], Li[BC][BC];
+    for (int a = 0; a < BC; ++a)
+      for (int b = 0; b < BC; ++b) Lm[a][b] = h[a <= b ? U9(a, b) : U9(b, a)];
+    for (int a = 0; a < BC; ++a) Lm[a][a] += lambda * fmax(Lm[a][a], DIAG_FLOOR);
+    if (c == fixed_cam)
+      for (int a = 0; a < BC; ++a)
+        for (int b = 0; b < BC; ++b) Lm[a][b] = (a == b) ? 1.0 : 0.0;
+    for (int a = 0; a < BC; ++a)
+      for (int b = a; b < BC; ++b) Hd[(size_t)c * BH + U9(a, b)] = Lm[a][b];
+    for (int j = 0; j < BC; ++j) {                       // Cholesky, lower triangle in place
+      double d = Lm[j][j];
+      for (int k = 0; k < j; ++k) d -= Lm[j][k] * Lm[j][k];
+      d = sqrt(fmax(d, DIAG_FLOOR));
+      Lm[j][j] = d;
+      for (int i = j + 1; i < BC; ++i) {
+        double s = Lm[i][j];
+        for (int k = 0; k < j; ++k) s -= Lm[i][k] * Lm[j][k];
+        Lm[i][j] = s / d;
+      }
+    }
+    for (int j = 0; j < BC; ++j) {                       // Li = L^-1 (lower), column by column
+      for (int i = 0; i < BC; ++i) Li[i][j] = 0.0;
+      Li[j][j] = 1.0 / Lm[j][j];
+      for (int i = j + 1; i < BC; ++i) {
+        double s = 0.0;
+        for (int k = j; k < i; ++k) s -= Lm[i][k] * Li[k][j];
+        Li[i][j] = s / Lm[i][i];
+      }
+    }
+    for (int a = 0; a < BC; ++a)                         // (L L^T)^-1 = Li^T Li
+      for (int b = a; b < BC; ++b) {
+        double s = 0.0;
+        for (int k = b; k < BC; ++k) s += Li[k][a] * Li[k][b];
+        Minv[(size_t)c * BH + U9(a, b)] = s;
+      }
+  }
+  if (relin) {
+    bal_block_sum<2>(cs2, sm);
+    if (threadIdx.x == 0) { out[0] = cs2[0]; out[1] = cs2[1]; }
+  }
+}
+
+struct BalPcg {            // device-resident PCG state
+  double rz, rz0, pq, rz_new;
+  int iters, done;
+};
+
+// g = -(bc - W y0) from the camera pass on y0; r = g, z = Minv r, p = z, x = 0; rz0; max |gradient|
+__global__ void __launch_bounds__(BAL_VEC_THREADS)
+k_bal_pcg_init(const double* __restrict__ HccBc, const double* __restrict__ part9, const double* __restrict__ Minv,
+               const double* __restrict__ partG, int nG, int n_cams, int fixed_cam, double* __restrict__ x, double* __restrict__ r,
+               double* __restrict__ z, double* __restrict__ p, BalPcg* __restrict__ st, double* __restrict__ host_out /* [0] rz0, [1] gmax */,
+               long long* __restrict__ host_flag, long long seq) {
+  __shared__ double sm[(BAL_VEC_THREADS / 64) * 1];
+  __shared__ double smax[BAL_VEC_THREADS / 64];
+  double acc[1] = {0.0};
+  double gm = 0.0;
+  for (int c = threadIdx.x; c < n_cams; c += BAL_VEC_THREADS) {
+    double g[BC], zz[BC];
+    const double* bc = HccBc + (size_t)c * (BH + BC) + BH;
+#pragma unroll
+    for (int q = 0; q < BC; ++q) {
+      double wy = 0.0;
+      for (int k = 0; k < NPART; ++k) wy += part9[((size_t)k * n_cams + c) * BC + q];
+      g[q] = (c == fixed_cam) ? 0.0 : -(bc[q] - wy);
+      gm = nanmax(gm, fabs(bc[q]));
+    }
+    sym9_mul(Minv + (size_t)c * BH, g, zz);
+#pragma unroll
+    for (int q = 0; q < BC; ++q) {
+      x[(size_t)c * BC + q] = 0.0; r[(size_t)c * BC + q] = g[q]; z[(size_t)c * BC + q] = zz[q]; p[(size_t)c * BC + q] = zz[q];
+      acc[0] += g[q] * zz[q];
+    }
+  }
+  for (int b = threadIdx.x; b < nG; b += BAL_VEC_THREADS) gm = nanmax(gm, partG[b]);
+  bal_block_sum<1>(acc, sm);
+  gm = wave_nanmax(gm);
+  if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = gm;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = 0.0;
+    for (int w = 0; w < BAL_VEC_THREADS / 64; ++w) m = nanmax(m, smax[w]);
+    st->rz = acc[0]; st->rz0 = acc[0]; st->iters = 0; st->done = !(acc[0] > 0.0);
+    host_out[0] = acc[0]; host_out[1] = m;
+    publish_flag(host_flag, seq, 1);
+  }
+}
+
+// one PCG iteration on the camera vectors (oracle.pcg): q = S p from the two passes, alpha, x, r, z, rz, beta, p
+__global__ void __launch_bounds__(BAL_VEC_THREADS)
+k_bal_pcg_step(const double* __restrict__ Hd, const double* __restrict__ Minv, const double* __restrict__ part9, int n_cams,
+               int fixed_cam, double tol2, int min_iters, double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
+               double* __restrict__ p, double* __restrict__ q, BalPcg* __restrict__ st, long long* __restrict__ host_flag, long long seq) {
+  __shared__ double sm[(BAL_VEC_THREADS / 64) * 1];
+  double acc[1] = {0.0};
+  for (int c = threadIdx.x; c < n_cams; c += BAL_VEC_THREADS) {
+    double pv[BC], qv[BC];
+#pragma unroll
+    for (int a = 0; a < BC; ++a) pv[a] = p[(size_t)c * BC + a];
+    if (c == fixed_cam) {
+#pragma unroll
+      for (int a = 0; a < BC; ++a) qv[a] = pv[a];
+    } else {
+      sym9_mul(Hd + (size_t)c * BH, pv, qv);
+#pragma unroll
+      for (int a = 0; a < BC; ++a) {
+        double w = 0.0;
+        for (int k = 0; k < NPART; ++k) w += part9[((size_t)k * n_cams + c) * BC + a];
+        qv[a] -= w;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < BC; ++a) { q[(size_t)c * BC + a] = qv[a]; acc[0] += pv[a] * qv[a]; }
+  }
+  bal_block_sum<1>(acc, sm);
+  const double pq = acc[0], rz = st->rz, rz0 = st->rz0;
+  const int it0 = st->iters;
+  if (!(pq > 0.0)) {                                    // breakdown: leave x, r as they are (oracle: break)
+    __syncthreads();
+    if (threadIdx.x == 0) { st->done = 1; st->pq = pq; publish_flag(host_flag, seq, 2); }
+    return;
+  }
+  const double alpha = rz / pq;
+  acc[0] = 0.0;
+  for (int c = threadIdx.x; c < n_cams; c += BAL_VEC_THREADS) {
+    double rv[BC], zz[BC];
+#pragma unroll
+    for (int a = 0; a < BC; ++a) {
+      x[(size_t)c * BC + a] += alpha * p[(size_t)c * BC + a];
+      rv[a] = r[(size_t)c * BC + a] - alpha * q[(size_t)c * BC + a];
+      r[(size_t)c * BC + a] = rv[a];
+    }
+    sym9_mul(Minv + (size_t)c * BH, rv, zz);
+#pragma unroll
+    for (int a = 0; a < BC; ++a) { z[(size_t)c * BC + a] = zz[a]; acc[0] += rv[a] * zz[a]; }
+  }
+  bal_block_sum<1>(acc, sm);
+  const double rz_new = acc[0];
+  const int it = it0 + 1;
+  const bool done = it >= min_iters && rz_new <= tol2 * rz0;
+  if (!done) {
+    const double beta = rz_new / rz;
+    for (int c = threadIdx.x; c < n_cams; c += BAL_VEC_THREADS) {
+#pragma unroll
+      for (int a = 0; a < BC; ++a) p[(size_t)c * BC + a] = z[(size_t)c * BC + a] + beta * p[(size_t)c * BC + a];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    st->rz = rz_new; st->rz_new = rz_new; st->pq = pq; st->iters = it; st->done = done ? 1 : 0;
+    publish_flag(host_flag, seq, done ? 2 : 1);
+  }
+}
+
+// trial cameras = cameras + dc (rotation vector, translation, f, k1, k2 all additive); camera-side sums of the step:
+// out[0..4] = bc.dc, sum Dc dc^2, |dc|^2, |cams|^2, dc.r (the PCG residual left over: model term of an inexact step)
+__global__ void __launch_bounds__(BAL_VEC_THREADS)
+k_bal_update(const double* __restrict__ cams, const double* __restrict__ intr, const double* __restrict__ x,
+             const double* __restrict__ r, const double* __restrict__ HccBc, int n_cams, int fixed_cam,
+             double* __restrict__ cams_t, double* __restrict__ intr_t, double* __restrict__ cs_t, double* __restrict__ out) {
+  __shared__ double sm[(BAL_VEC_THREADS / 64) * 5];
+  double acc[5] = {0, 0, 0, 0, 0};
+  for (int c = threadIdx.x; c < n_cams; c += BAL_VEC_THREADS) {
+    const double* h = HccBc + (size_t)c * (BH + BC);
+    double cam[6];
+#pragma unroll
+    for (int a = 0; a < BC; ++a) {
+      const double d = (c == fixed_cam) ? 0.0 : x[(size_t)c * BC + a];
+      const double xv = a < 6 ? cams[6 * (size_t)c + a] : intr[3 * (size_t)c + a - 6];
+      if (a < 6) { cam[a] = xv + d; cams_t[6 * (size_t)c + a] = cam[a]; }
+      else intr_t[3 * (size_t)c + a - 6] = xv + d;
+      acc[0] += h[BH + a] * d;
+      if (c != fixed_cam) acc[1] += fmax(h[U9(a, a)], DIAG_FLOOR) * d * d;
+      acc[2] += d * d;
+      acc[3] += xv * xv;
+      acc[4] += d * r[(size_t)c * BC + a];
+    }
+    camera_state(cam, cs_t + CS * (size_t)c);
+  }
+  bal_block_sum<5>(acc, sm);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) out[q] = acc[q];
+  }
+}
+
+// step sums to the host: out_host[0..8] = camera side (5) | point side (4, partB blocks in order) ; [9], [10] = sse, rho-sum of the trial
+__global__ void __launch_bounds__(64)
+k_bal_step_sums(const double* __restrict__ cam5, const double* __restrict__ partB, int nB, const double* __restrict__ partR,
+                int n_cams, double* __restrict__ host_out, long long* __restrict__ host_flag, long long seq) {
+  double pb[4] = {0, 0, 0, 0}, e[2] = {0, 0};
+  for (int b = threadIdx.x; b < nB; b += 64) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pb[q] += partB[4 * (size_t)b + q];
+  }
+  for (int i = threadIdx.x; i < NPART * n_cams; i += 64) { e[0] += partR[2 * (size_t)i]; e[1] += partR[2 * (size_t)i + 1]; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) pb[q] = wave_total_dpp(pb[q]);
+  e[0] = wave_total_dpp(e[0]); e[1] = wave_total_dpp(e[1]);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) host_out[q] = cam5[q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) host_out[5 + q] = pb[q];
+    host_out[9] = e[0]; host_out[10] = e[1];
+    publish_flag(host_flag, seq, 1);
+  }
+}
+
+}  // namespace ba

@@ -34,6 +34,7 @@
 #include "ba_triangulate.hpp"
 #include "ba_coarse.hpp"
 #include "ba_small.hpp"
+#include "ba_bal.hpp"
 
 using namespace ba;
 
@@ -174,6 +175,10 @@ struct ba_handle {
   char* d_small_host = nullptr;
   size_t h_small_bytes = 0;
   long long small_seq = 0;     // sequence number of h_flags[4], which k_small_lm publishes when its results are written
+  // BAL 9-parameter path (ba_solve_bal, csrc/ba_bal.hpp)
+  DBuf<double> bal_intr[2], bal_partL, bal_HccBc, bal_Hd, bal_Minv, bal_part9, bal_x, bal_r, bal_z, bal_p, bal_q, bal_misc, bal_partB, bal_partG;
+  DBuf<char> bal_st;
+  long long bal_seq = 0;       // sequence number of h_flags[6]
   DBuf<double> small_V, small_gS;   // k_small_lm: V = W L (49 x 3 Np_pad, zero where unwritten), per-wave partial V V^T
   int small_np_pad = -1;
   // two-level preconditioner for band-structured problems (ba_coarse.hpp): structures built by ba_set_problem
@@ -338,6 +343,10 @@ extern "C" int ba_destroy(ba_handle* h) {
   h->st.release();
   h->tri.release();
   h->small_V.release();
+  { DBuf<double>* bb[] = {&h->bal_intr[0], &h->bal_intr[1], &h->bal_partL, &h->bal_HccBc, &h->bal_Hd, &h->bal_Minv, &h->bal_part9, &h->bal_x,
+                          &h->bal_r, &h->bal_z, &h->bal_p, &h->bal_q, &h->bal_misc, &h->bal_partB, &h->bal_partG};
+    for (auto b : bb) b->release(); }
+  h->bal_st.release();
   h->small_gS.release();
   h->small_np_pad = -1;
   h->run_beg.release(); h->run_pt.release(); h->run_agg.release(); h->run_pairs.release();
@@ -1488,6 +1497,260 @@ static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   const double per = sum->iterations ? sum->seconds_total / sum->iterations : 0.0;
   for (auto& r : h->trace) r.seconds = per;
   return BA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BAL 9-parameter camera: linearisation hook and the solve step (csrc/ba_bal.hpp).  Cameras (rvec, t) and points are the
+// handle's (ba_set_params / ba_get_params); the per-camera (f, k1, k2) travel with the call.  K4 of ba_set_problem is
+// not used.  Single rank.
+static int bal_alloc(ba_handle* h) {
+  const size_t Nc = (size_t)h->Nc, nbP = ((size_t)h->Np + BAL_PT_THREADS - 1) / BAL_PT_THREADS;
+  for (int k = 0; k < 2; ++k) HIPCHECK(h->bal_intr[k].alloc(3 * Nc));
+  HIPCHECK(h->bal_partL.alloc((size_t)NPART * Nc * BLIN));
+  HIPCHECK(h->bal_HccBc.alloc(Nc * (BH + BC)));
+  HIPCHECK(h->bal_Hd.alloc(Nc * BH));
+  HIPCHECK(h->bal_Minv.alloc(Nc * BH));
+  HIPCHECK(h->bal_part9.alloc((size_t)NPART * Nc * BC));
+  DBuf<double>* v[] = {&h->bal_x, &h->bal_r, &h->bal_z, &h->bal_p, &h->bal_q};
+  for (auto b : v) HIPCHECK(b->alloc(Nc * BC));
+  HIPCHECK(h->bal_misc.alloc(16));
+  HIPCHECK(h->bal_partB.alloc(4 * (nbP ? nbP : 1)));
+  HIPCHECK(h->bal_partG.alloc(nbP ? nbP : 1));
+  HIPCHECK(h->bal_st.alloc(sizeof(BalPcg)));
+  return BA_OK;
+}
+static int bal_nblk_pt(const ba_handle* h) { return (h->Np + BAL_PT_THREADS - 1) / BAL_PT_THREADS; }
+// camera half + point half at parameter set `w`
+static void bal_launch_lin(ba_handle* h, int w, bool robust, double fs) {
+  {
+    Scope sc(h, BA_K_LINEARIZE_CAM);
+    auto kc = robust ? k_bal_lin_cam<true> : k_bal_lin_cam<false>;
+    BA_LAUNCH(kc, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[w].p, h->bal_intr[w].p, h->ptab[w].p, h->offk.p, h->c_pt.p,
+              h->c_uv.p, fs, h->Nc, h->cam_band, h->fixed, h->bal_partL.p);
+  }
+  if (h->Np > 0) {
+    Scope sc(h, BA_K_LINEARIZE_PT);
+    auto kp = robust ? k_bal_lin_pt<true> : k_bal_lin_pt<false>;
+    BA_LAUNCH(kp, dim3(bal_nblk_pt(h)), dim3(BAL_PT_THREADS), 0, h->stream, h->cs[w].p, h->bal_intr[w].p, h->ptab[w].p, h->pt_off.p,
+              h->p_cam.p, h->p_uv.p, fs, h->Np, h->Hpp[0].p, h->bp[0].p, h->bal_partG.p);
+  }
+}
+
+extern "C" int ba_linearize_bal(ba_handle* h, const double* intr, int32_t loss, double f_scale, double* Hcc, double* bc,
+                                double* Hpp, double* bp) {
+  if (!h || !intr) return fail(BA_ERR_INVALID, "null argument");
+  if (!h->have_params) return fail(BA_ERR_STATE, "ba_set_problem / ba_set_params first");
+  if (h->multi) return fail(BA_ERR_STATE, "the BAL path runs on a single rank");
+  if (loss != BA_LOSS_LINEAR && loss != BA_LOSS_HUBER) return fail(BA_ERR_INVALID, "unknown loss %d", loss);
+  if (!(f_scale > 0)) return fail(BA_ERR_INVALID, "f_scale must be positive");
+  if (set_device(h)) return BA_ERR_HIP;
+  if (int rc = bal_alloc(h)) return rc;
+  const int w = h->cur;
+  HIPCHECK(hipMemcpyAsync(h->bal_intr[w].p, intr, 3 * (size_t)h->Nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  bal_launch_lin(h, w, loss == BA_LOSS_HUBER, f_scale);
+  BA_LAUNCH(k_bal_prep, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->bal_partL.p, 1, 0.0, h->Nc, h->fixed, h->bal_HccBc.p, h->bal_Hd.p,
+            h->bal_Minv.p, h->bal_misc.p);
+  h->linearized = false;                      // the 6-parameter linearisation buffers were overwritten (Hpp, bp)
+  if (Hcc || bc) {
+    std::vector<double> tmp((size_t)h->Nc * (BH + BC));
+    HIPCHECK(hipMemcpyAsync(tmp.data(), h->bal_HccBc.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    BA_SYNC(h);
+    for (int c = 0; c < h->Nc; ++c) {
+      if (Hcc) memcpy(Hcc + (size_t)c * BH, tmp.data() + (size_t)c * (BH + BC), BH * sizeof(double));
+      if (bc) memcpy(bc + (size_t)c * BC, tmp.data() + (size_t)c * (BH + BC) + BH, BC * sizeof(double));
+    }
+  }
+  if ((Hpp || bp) && h->Np) {
+    HIPCHECK(h->rbuf.alloc(6 * (size_t)h->Np));
+    if (Hpp) {
+      BA_LAUNCH(k_unpermute_rows, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp[0].p, h->slot.p, h->Np, 6, h->rbuf.p);
+      HIPCHECK(hipMemcpyAsync(Hpp, h->rbuf.p, 6 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (bp) {
+      BA_LAUNCH(k_unpermute_rows, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->bp[0].p, h->slot.p, h->Np, 3, h->stage.p);
+      HIPCHECK(hipMemcpyAsync(bp, h->stage.p, 3 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+  }
+  BA_SYNC(h);
+  return BA_OK;
+}
+
+static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba_summary* sum) {
+  if (!h->have_params) return fail(BA_ERR_STATE, "ba_set_problem / ba_set_params first");
+  if (h->multi) return fail(BA_ERR_STATE, "the BAL path runs on a single rank");
+  if (opts->loss != BA_LOSS_LINEAR && opts->loss != BA_LOSS_HUBER) return fail(BA_ERR_INVALID, "unknown loss");
+  if (!(opts->f_scale > 0) || opts->max_iters < 0 || opts->pcg_max_iters < 1 || !(opts->initial_lambda > 0))
+    return fail(BA_ERR_INVALID, "bad options");
+  if (set_device(h)) return BA_ERR_HIP;
+  if (int rc = bal_alloc(h)) return rc;
+  memset(sum, 0, sizeof *sum);
+  h->trace.clear();
+  h->linearized = false;
+  const bool robust = opts->loss == BA_LOSS_HUBER;
+  const double fs = opts->f_scale, tol2 = opts->pcg_tol * opts->pcg_tol;
+  const int Nc = h->Nc, nbP = bal_nblk_pt(h);
+  double* const hs = h->h_scal + 32;                     // host-mapped results of this path: 16 doubles
+  double* const ds = h->d_scal_host + 32;
+  long long* const dflag = h->d_flags + 6;
+  const double t_begin = now_s();
+  HIPCHECK(hipMemcpyAsync(h->bal_intr[h->cur].p, intr, 3 * (size_t)Nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
+
+  double lambda = opts->initial_lambda, nu = 2.0, cost = 0.0, sse = 0.0;
+  int it = 0, acc_n = 0, status = 0;
+  bool need_lin = true;
+  if (h->Np == 0 || h->Nobs == 0) { sum->status = 1; return BA_OK; }
+  while (it < opts->max_iters || it == 0) {
+    const int cur = h->cur, tr = 1 - cur;
+    const double t0 = now_s();
+    if (need_lin) bal_launch_lin(h, cur, robust, fs);
+    {
+      Scope sc(h, BA_K_PRECOND);
+      BA_LAUNCH(k_bal_prep, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->bal_partL.p, need_lin ? 1 : 0, lambda, Nc, h->fixed,
+                h->bal_HccBc.p, h->bal_Hd.p, h->bal_Minv.p, h->bal_misc.p);
+      BA_LAUNCH(k_point_invert, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp[0].p, h->bp[0].p, lambda, h->Np, h->Hppinv[0].p,
+                h->y0[0].p, h->ptab[cur].p);
+    }
+    {                                                   // W y0 -> right-hand side, PCG start
+      Scope sc(h, BA_K_SCHUR_CAM);
+      auto kc = robust ? k_bal_cam_schur<true> : k_bal_cam_schur<false>;
+      BA_LAUNCH(kc, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->offk.p,
+                h->c_pt.p, h->c_uv.p, fs, Nc, h->cam_band, h->fixed, h->bal_part9.p);
+    }
+    long long seq = ++h->bal_seq;
+    if (it == 0 && need_lin) {                          // initial cost rides along: the camera half summed r^2 and the rho terms
+      HIPCHECK(hipMemcpyAsync(hs + 12, h->bal_misc.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    }
+    {
+      Scope sc(h, BA_K_PCG_UPDATE);
+      BA_LAUNCH(k_bal_pcg_init, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->bal_HccBc.p, h->bal_part9.p, h->bal_Minv.p, h->bal_partG.p,
+                nbP, Nc, h->fixed, h->bal_x.p, h->bal_r.p, h->bal_z.p, h->bal_p.p, (BalPcg*)h->bal_st.p, ds, dflag, seq);
+    }
+    if (int rc = wait_flag(h, 6, seq)) return rc;
+    if (it == 0) {
+      BA_SYNC(h);                                       // the two words of the initial cost (a copy, not a mapped store)
+      sse = hs[12]; cost = 0.5 * hs[13];
+      sum->initial_sse = sse; sum->initial_cost = cost;
+      if (!std::isfinite(cost)) return fail(BA_ERR_NUMERIC, "non-finite cost at the initial parameters");
+      if (opts->max_iters == 0) break;
+    }
+    const double rz0 = hs[0], gmax = hs[1];
+    if (!std::isfinite(gmax)) return fail(BA_ERR_NUMERIC, "non-finite gradient at LM iteration %d", it + 1);
+    if (need_lin && gmax <= opts->gtol) { status = 3; break; }
+    const double t1 = now_s();
+    sum->seconds_linearize += t1 - t0;
+    // ---- PCG on the reduced camera system
+    int k = 0;
+    if (rz0 > 0.0) {
+      auto kp = robust ? k_bal_pt_schur<true, 0> : k_bal_pt_schur<false, 0>;
+      auto kc = robust ? k_bal_cam_schur<true> : k_bal_cam_schur<false>;
+      while (k < opts->pcg_max_iters) {
+        {
+          Scope sc(h, BA_K_SCHUR_PT);
+          BA_LAUNCH(kp, dim3(nbP), dim3(BAL_PT_THREADS), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->pt_off.p,
+                    h->p_cam.p, h->p_uv.p, fs, h->Np, h->fixed, h->bal_p.p, h->Hppinv[0].p, h->y0[0].p, h->Hpp[0].p, h->bp[0].p,
+                    (double*)nullptr, (double*)nullptr);
+        }
+        {
+          Scope sc(h, BA_K_SCHUR_CAM);
+          BA_LAUNCH(kc, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->offk.p,
+                    h->c_pt.p, h->c_uv.p, fs, Nc, h->cam_band, h->fixed, h->bal_part9.p);
+        }
+        seq = ++h->bal_seq;
+        {
+          Scope sc(h, BA_K_PCG_UPDATE);
+          BA_LAUNCH(k_bal_pcg_step, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->bal_Hd.p, h->bal_Minv.p, h->bal_part9.p, Nc, h->fixed,
+                    tol2, opts->pcg_min_iters, h->bal_x.p, h->bal_r.p, h->bal_z.p, h->bal_p.p, h->bal_q.p, (BalPcg*)h->bal_st.p, dflag, seq);
+        }
+        if (int rc = wait_flag(h, 6, seq)) return rc;
+        const long long verdict = h->h_flags[7];         // 1 = go on, 2 = converged or broke down
+        if (verdict == 2) {
+          BalPcg stv;
+          HIPCHECK(hipMemcpy(&stv, h->bal_st.p, sizeof stv, hipMemcpyDeviceToHost));
+          k = stv.iters;
+          break;
+        }
+        ++k;
+      }
+    }
+    sum->pcg_iterations += k;
+    const double t2 = now_s();
+    sum->seconds_pcg += t2 - t1;
+    // ---- step: trial cameras, back substitution, trial cost, sums to the host
+    {
+      Scope sc(h, BA_K_MISC);
+      BA_LAUNCH(k_bal_update, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->cams[cur].p, h->bal_intr[cur].p, h->bal_x.p, h->bal_r.p,
+                h->bal_HccBc.p, Nc, h->fixed, h->cams[tr].p, h->bal_intr[tr].p, h->cs[tr].p, h->bal_misc.p + 4);
+    }
+    {
+      Scope sc(h, BA_K_BACKSUB);
+      auto kb = robust ? k_bal_pt_schur<true, 1> : k_bal_pt_schur<false, 1>;
+      BA_LAUNCH(kb, dim3(nbP), dim3(BAL_PT_THREADS), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->pt_off.p, h->p_cam.p,
+                h->p_uv.p, fs, h->Np, h->fixed, h->bal_x.p, h->Hppinv[0].p, h->y0[0].p, h->Hpp[0].p, h->bp[0].p, h->ptab[tr].p,
+                h->bal_partB.p);
+    }
+    {
+      Scope sc(h, BA_K_RESIDUAL);
+      auto kr = robust ? k_cam_residual_bal<true> : k_cam_residual_bal<false>;
+      BA_LAUNCH(kr, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[tr].p, (const double*)h->bal_intr[tr].p, h->ptab[tr].p,
+                h->offk.p, h->c_pt.p, h->c_uv.p, h->c_orig.p, fs, Nc, h->cam_band, (double*)nullptr, h->partR.p);
+    }
+    seq = ++h->bal_seq;
+    BA_LAUNCH(k_bal_step_sums, dim3(1), dim3(64), 0, h->stream, h->bal_misc.p + 4, h->bal_partB.p, nbP, h->partR.p, Nc, ds, dflag, seq);
+    if (int rc = wait_flag(h, 6, seq)) return rc;
+    // ---- verdict, the rules of ba_solve / oracle.lm_solve
+    const double gTd = hs[0] + hs[5], dDd = hs[1] + hs[6], step2 = hs[2] + hs[7], x2 = hs[3] + hs[8], dcr = hs[4];
+    const double sse_new = hs[9], cost_new = 0.5 * hs[10];
+    const double model = 0.5 * (lambda * dDd - gTd + dcr);
+    const double rho = (model > 0.0 && std::isfinite(cost_new)) ? (cost - cost_new) / model : -1.0;
+    ++it;
+    ba_iter_record rec;
+    memset(&rec, 0, sizeof rec);
+    rec.iteration = it; rec.accepted = (rho > 0.0 && std::isfinite(cost_new)) ? 1 : 0; rec.pcg_iterations = k;
+    rec.cost = cost; rec.cost_trial = cost_new; rec.sse_trial = sse_new; rec.lambda = lambda; rec.gain_ratio = rho;
+    rec.step_norm = std::sqrt(step2); rec.seconds = now_s() - t0;
+    h->trace.push_back(rec);
+    bool stop = false;
+    if (rec.accepted) {
+      const double dcost = cost - cost_new;
+      h->cur = tr;
+      cost = cost_new; sse = sse_new;
+      ++acc_n;
+      const double t = 2.0 * rho - 1.0;
+      lambda = std::max(lambda * std::max(1.0 / 3.0, 1.0 - t * t * t), 1e-12);
+      nu = 2.0;
+      need_lin = true;
+      if (dcost <= opts->ftol * cost_new) { status = 1; stop = true; }
+    } else {
+      if (!std::isfinite(cost_new) && lambda >= 1e12)
+        return fail(BA_ERR_NUMERIC, "non-finite trial cost up to the largest damping (LM iteration %d)", it);
+      lambda = std::min(lambda * nu, 1e12);
+      nu *= 2.0;
+      need_lin = false;
+    }
+    sum->seconds_update += now_s() - t2;
+    if (!stop && std::sqrt(step2) <= opts->xtol * (opts->xtol + std::sqrt(x2))) { status = 2; stop = true; }
+    if (stop) break;
+    if (it >= opts->max_iters) { status = 0; break; }
+  }
+  // the multi-kernel entry points read the packed camera table of the current set: rebuild it from the result
+  BA_LAUNCH(k_cam_prepare, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->cams[h->cur].p, h->cs[h->cur].p, h->camA[h->cur].p, h->Nc);
+  HIPCHECK(hipMemcpyAsync(intr, h->bal_intr[h->cur].p, 3 * (size_t)Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  BA_SYNC(h);
+  sum->iterations = it; sum->accepted = acc_n; sum->status = status;
+  sum->final_sse = sse; sum->final_cost = cost; sum->final_lambda = lambda;
+  sum->seconds_total = now_s() - t_begin;
+  return BA_OK;
+}
+
+extern "C" int ba_solve_bal(ba_handle* h, double* intr, const ba_options* opts, ba_summary* sum) {
+  if (!h || !intr || !opts || !sum) return fail(BA_ERR_INVALID, "null argument");
+  const int rc = solve_bal_impl(h, intr, opts, sum);
+  if (rc != BA_OK) {                                   // leave the handle usable: drain the stream, forget what was half done
+    (void)hipStreamSynchronize(h->stream);
+    h->launch_err = hipSuccess;
+    h->linearized = false;
+  }
+  return rc;
 }
 
 static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {

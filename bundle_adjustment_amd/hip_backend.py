@@ -80,6 +80,8 @@ SYMBOLS = {
     "ba_allgather_points": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _DP]),
     "ba_residuals": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _DP, _DP, _DP]),
     "ba_residuals_bal": (C.c_int, [C.c_void_p, _DP, C.c_int32, C.c_double, _DP, _DP, _DP]),
+    "ba_linearize_bal": (C.c_int, [C.c_void_p, _DP, C.c_int32, C.c_double, _DP, _DP, _DP, _DP]),
+    "ba_solve_bal": (C.c_int, [C.c_void_p, _DP, C.POINTER(BAOptions), C.POINTER(BASummary)]),
     "ba_linearize": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _DP, _DP, _DP, _DP]),
     "ba_schur_rhs": (C.c_int, [C.c_void_p, C.c_double, _DP]),
     "ba_schur_apply": (C.c_int, [C.c_void_p, C.c_double, _DP, _DP]),
@@ -255,6 +257,37 @@ class Solver:
         _check(self._lib.ba_residuals_bal(self._h, _dp(intr), LOSS[loss] if isinstance(loss, str) else loss, float(f_scale),
                                           _dp(r), C.byref(sse), C.byref(cost)))
         return r, sse.value, cost.value
+
+    def _set_bal(self, bal, fixed_cam=-1):
+        from .problem import BAProblem
+        self.set_problem(BAProblem(np.ascontiguousarray(bal.cams[:, :6]), bal.pts, bal.cam_idx, bal.pt_idx, bal.uv,
+                                   np.array([1.0, 1.0, 0.0, 0.0]), fixed_cam))
+        return np.ascontiguousarray(bal.cams[:, 6:9], dtype=np.float64).copy()
+
+    def linearize_bal(self, bal, loss="linear", f_scale=1.0, fixed_cam=-1):
+        """ba_linearize_bal on a bal.BALProblem: dict(Hcc (Nc,45), bc (Nc,9), Hpp (Np,6), bp (Np,3)), packed upper triangles."""
+        intr = self._set_bal(bal, fixed_cam)
+        out = dict(Hcc=np.empty((self.n_cams, 45)), bc=np.empty((self.n_cams, 9)), Hpp=np.empty((self.n_pts, 6)),
+                   bp=np.empty((self.n_pts, 3)))
+        _check(self._lib.ba_linearize_bal(self._h, _dp(intr), LOSS[loss] if isinstance(loss, str) else loss, float(f_scale),
+                                          _dp(out["Hcc"]), _dp(out["bc"]), _dp(out["Hpp"]), _dp(out["bp"])))
+        return out
+
+    def solve_bal(self, bal, fixed_cam=-1, **kw):
+        """ba_solve_bal on a bal.BALProblem (9-parameter cameras, f / k1 / k2 adjusted with the pose): returns
+        (summary dict, cams (Nc,9), pts (Np,3)).  kw as for solve()."""
+        intr = self._set_bal(bal, fixed_cam)
+        o = self.default_options()
+        for k, v in kw.items():
+            if k == "loss":
+                v = LOSS[v] if isinstance(v, str) else v
+            if not hasattr(o, k):
+                raise TypeError(f"unknown option {k}")
+            setattr(o, k, v)
+        s = BASummary()
+        _check(self._lib.ba_solve_bal(self._h, _dp(intr), C.byref(o), C.byref(s)))
+        cams6, pts = self.get_params()
+        return s.as_dict(), np.concatenate([cams6, intr], axis=1), pts
 
     def triangulate(self, camera_matrix, R_rel, t_rel, pts1, pts2):
         """ba_triangulate: (n,3) points in the first camera's frame and the (n,) cheirality mask."""

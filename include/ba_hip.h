@@ -177,6 +177,20 @@ int ba_residuals(ba_handle* h, int32_t loss, double f_scale, double* r, double* 
  * centre, the camera looking down -z.  Same row order and outputs as ba_residuals. */
 int ba_residuals_bal(ba_handle* h, const double* intr, int32_t loss, double f_scale, double* r, double* sse, double* cost);
 
+/* K2 for the BAL camera (parity hook, like ba_linearize): block normal equations at the current parameters with the 2x9
+ * camera block [d/d rvec (additive) | d/d t | d/d f | d/d k1 | d/d k2].  Outputs (any may be NULL):
+ *   Hcc double[Nc][45]  upper triangle of Jc^T w Jc, row-major (00 01 .. 08 11 .. 88);  bc double[Nc][9]  Jc^T w r
+ *   Hpp double[Np][6], bp double[Np][3] as ba_linearize.  The fixed camera's blocks are zero.  Single rank. */
+int ba_linearize_bal(ba_handle* h, const double* intr, int32_t loss, double f_scale, double* Hcc, double* bc, double* Hpp,
+                     double* bp);
+
+/* The solve step for the BAL 9-parameter camera (csrc/ba_bal.hpp): LM + Schur complement + matrix-free PCG with 9x9 camera
+ * blocks and a block-Jacobi preconditioner; same damping / gain-ratio / stopping rules, options, summary and trace as
+ * ba_solve (preconditioner, jacobian_precision and small_solver are ignored).  Cameras (rvec, t) and points are the
+ * handle's (ba_set_params before, ba_get_params after); intr double[Nc][3] = (f, k1, k2) per camera is read AND updated.
+ * fixed_cam of ba_set_problem is honoured (-1: no camera held; the damping carries the gauge).  Single rank. */
+int ba_solve_bal(ba_handle* h, double* intr, const ba_options* opts, ba_summary* sum);
+
 /* K2/K3: linearise at the current parameters.  Outputs (any may be NULL):
  *   Hcc double[Nc][21]  upper triangle of Jc^T w Jc, row-major (00 01 .. 05 11 .. 55)
  *   bc  double[Nc][6]   Jc^T w r

@@ -324,27 +324,28 @@ def schur_dense(ne, cam_idx, pt_idx, lam, fixed_cam=-1):
         rhs = -(bc - W (Hpp + lam Dp)^-1 bp).
     The fixed camera's row/column is replaced by identity / zero rhs."""
     nc = ne['Hcc'].shape[0]
+    nb = ne['Hcc'].shape[1]
     npt = ne['Hpp'].shape[0]
     Hccd = damp_blocks(ne['Hcc'], lam)
     Hppinv = np.linalg.inv(damp_blocks(ne['Hpp'], lam))
-    S = np.zeros((6 * nc, 6 * nc))
+    S = np.zeros((nb * nc, nb * nc))
     for c in range(nc):
-        S[6 * c:6 * c + 6, 6 * c:6 * c + 6] = Hccd[c]
-    # W as a dense (6Nc, 3Np) matrix
-    Wd = np.zeros((6 * nc, 3 * npt))
+        S[nb * c:nb * c + nb, nb * c:nb * c + nb] = Hccd[c]
+    # W as a dense (nb Nc, 3Np) matrix
+    Wd = np.zeros((nb * nc, 3 * npt))
     for o in range(len(cam_idx)):
         c, p = cam_idx[o], pt_idx[o]
-        Wd[6 * c:6 * c + 6, 3 * p:3 * p + 3] += ne['W'][o]
+        Wd[nb * c:nb * c + nb, 3 * p:3 * p + 3] += ne['W'][o]
     Hinv = np.zeros((3 * npt, 3 * npt))
     for p in range(npt):
         Hinv[3 * p:3 * p + 3, 3 * p:3 * p + 3] = Hppinv[p]
     S -= Wd @ Hinv @ Wd.T
     rhs = -(ne['bc'].ravel() - Wd @ Hinv @ ne['bp'].ravel())
     if fixed_cam >= 0:
-        sl = slice(6 * fixed_cam, 6 * fixed_cam + 6)
+        sl = slice(nb * fixed_cam, nb * fixed_cam + nb)
         S[sl, :] = 0
         S[:, sl] = 0
-        S[sl, sl] = np.eye(6)
+        S[sl, sl] = np.eye(nb)
         rhs[sl] = 0
     return S, rhs, Wd, Hinv
 
@@ -355,6 +356,7 @@ class SchurOperator:
 
     def __init__(self, ne, cam_idx, pt_idx, lam, fixed_cam=-1):
         self.nc = ne['Hcc'].shape[0]
+        self.nb = ne['Hcc'].shape[1]              # camera block size: 6 (the reference's pinhole) or 9 (BAL)
         self.np_ = ne['Hpp'].shape[0]
         self.cam_idx, self.pt_idx = cam_idx, pt_idx
         self.W = ne['W']
@@ -369,12 +371,12 @@ class SchurOperator:
         return np.einsum('pij,pj->pi', self.Hppinv, u)
 
     def w_times(self, y):                      # (Np,3) -> (Nc,6):  W y
-        q = np.zeros((self.nc, 6))
+        q = np.zeros((self.nc, self.nb))
         np.add.at(q, self.cam_idx, np.einsum('nij,nj->ni', self.W, y[self.pt_idx]))
         return q
 
     def apply(self, v):
-        v = v.reshape(self.nc, 6)
+        v = v.reshape(self.nc, self.nb)
         q = np.einsum('cij,cj->ci', self.Hccd, v) - self.w_times(self.wt_times(v))
         if self.fixed >= 0:
             q[self.fixed] = v[self.fixed]
@@ -393,7 +395,7 @@ class SchurOperator:
         t = np.einsum('nij,njk,nlk->nil', self.W, self.Hppinv[self.pt_idx], self.W)
         np.subtract.at(D, self.cam_idx, t)
         if self.fixed >= 0:
-            D[self.fixed] = np.eye(6)
+            D[self.fixed] = np.eye(self.nb)
         return D
 
     def back_substitute(self, dc):
@@ -469,8 +471,7 @@ def pcg(op, rhs, Minv, tol, max_iters, min_iters=0):
     if not callable(Minv):
         blocks = Minv
         Minv = lambda r_: np.einsum('cij,cj->ci', blocks, r_)          # noqa: E731
-    nc = rhs.shape[0]
-    x = np.zeros((nc, 6))
+    x = np.zeros_like(rhs)
     r = rhs.copy()
     z = Minv(r)
     p = z.copy()
@@ -501,16 +502,27 @@ def pcg(op, rhs, Minv, tol, max_iters, min_iters=0):
 
 def lm_solve(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam=-1, loss='linear',
              max_iters=50, ftol=1e-10, xtol=1e-10, gtol=1e-10, lam0=1e-4,
-             pcg_tol=1e-1, pcg_max_iters=200, precond='schur_jacobi', verbose=False, linear_solver='pcg'):
+             pcg_tol=1e-1, pcg_max_iters=200, precond='schur_jacobi', verbose=False, linear_solver='pcg', model='pinhole'):
     """CPU mirror of the device LM / Schur / PCG loop (same formulas, same update
     rules, same stopping tests) -- see ba_solve in bundle_adjustment_amd/csrc/ba_hip.hip.
     linear_solver='dense' solves the explicit reduced system (schur_dense) exactly instead, as the
     single-launch solver for window-sized problems does (csrc/ba_small.hpp).
+    model='bal': the 9-parameter BAL camera [rvec | t | f k1 k2] (bal_residuals, bal_normal_equations; K4 is ignored) --
+    the mirror of ba_solve_bal (csrc/ba_bal.hpp); same loop, 9x9 camera blocks.
     Returns dict(cams, pts, iterations, accepted, sse0, sse, cost0, cost, pcg_iters,
     history)."""
-    cams = np.array(cams, dtype=np.float64).reshape(-1, 6)
+    nb = 9 if model == 'bal' else 6
+    cams = np.array(cams, dtype=np.float64).reshape(-1, nb)
     pts = np.array(pts, dtype=np.float64).reshape(-1, 3)
     lam, nu = lam0, 2.0
+    if model == 'bal':
+        def residuals(c_, p_, ci_, pi_, uv_, K4_):                       # noqa: F811  (shadows the pinhole residual)
+            return bal_residuals(c_, p_, ci_, pi_, uv_)
+
+        def normal_equations(c_, p_, ci_, pi_, uv_, K4_, fixed_, loss_):  # noqa: F811
+            return bal_normal_equations(c_, p_, ci_, pi_, uv_, fixed_, loss_)
+    else:
+        residuals, normal_equations = globals()['residuals'], globals()['normal_equations']
     res = residuals(cams, pts, cam_idx, pt_idx, uv, K4)
     cost = robust_cost(res, loss)
     sse0 = float((res * res).sum())
@@ -528,19 +540,19 @@ def lm_solve(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam=-1, loss='linear',
         rhs = op.rhs()
         D = op.Hccd.copy() if precond == 'jacobi' else op.schur_diag_blocks()
         if fixed_cam >= 0:
-            D[fixed_cam] = np.eye(6)
+            D[fixed_cam] = np.eye(nb)
         Minv = np.linalg.inv(D)
         if precond == 'two_level':
             Minv = two_level_apply(Minv, np.linalg.inv(coarse_matrix(op, fixed_cam)), fixed_cam)
         if linear_solver == 'dense':
             S_, g_, _, _ = schur_dense(ne, cam_idx, pt_idx, lam, fixed_cam)
-            dc, k, rfin = np.linalg.solve(S_, g_).reshape(-1, 6), 0, np.zeros_like(rhs)
+            dc, k, rfin = np.linalg.solve(S_, g_).reshape(-1, nb), 0, np.zeros_like(rhs)
         else:
             dc, k, rfin = pcg(op, rhs, Minv, pcg_tol, pcg_max_iters)
         pcg_total += k
         dp = op.back_substitute(dc)
         # model decrease of the damped, inexactly solved system (LM section)
-        dcd = np.maximum(ne['Hcc'][:, np.arange(6), np.arange(6)], 1e-12)
+        dcd = np.maximum(ne['Hcc'][:, np.arange(nb), np.arange(nb)], 1e-12)
         dpd = np.maximum(ne['Hpp'][:, np.arange(3), np.arange(3)], 1e-12)
         if fixed_cam >= 0:
             dcd[fixed_cam] = 0
@@ -737,3 +749,26 @@ def bal_jacobian_blocks(cams9, pts, cam_idx, pt_idx):
     Jc[:, :, 7] = -(f * n2)[:, None] * p
     Jc[:, :, 8] = -(f * n2 * n2)[:, None] * p
     return Jc, Jp
+
+
+def bal_normal_equations(cams9, pts, cam_idx, pt_idx, uv, fixed_cam=-1, loss='linear'):
+    """normal_equations for the BAL camera: Hcc (Nc,9,9), Hpp (Np,3,3), bc (Nc,9), bp (Np,3), W (Nobs,9,3)."""
+    nc = np.asarray(cams9).reshape(-1, 9).shape[0]
+    npt = np.asarray(pts).reshape(-1, 3).shape[0]
+    res = bal_residuals(cams9, pts, cam_idx, pt_idx, uv)
+    w = robust_weights(res, loss)
+    Jc, Jp = bal_jacobian_blocks(cams9, pts, cam_idx, pt_idx)
+    if fixed_cam >= 0:
+        Jc = Jc * (np.asarray(cam_idx) != fixed_cam)[:, None, None]
+    Jcw = Jc * w[:, :, None]
+    Jpw = Jp * w[:, :, None]
+    Hcc = np.zeros((nc, 9, 9))
+    Hpp = np.zeros((npt, 3, 3))
+    bc = np.zeros((nc, 9))
+    bp = np.zeros((npt, 3))
+    np.add.at(Hcc, cam_idx, np.einsum('nki,nkj->nij', Jcw, Jc))
+    np.add.at(Hpp, pt_idx, np.einsum('nki,nkj->nij', Jpw, Jp))
+    np.add.at(bc, cam_idx, np.einsum('nki,nk->ni', Jcw, res))
+    np.add.at(bp, pt_idx, np.einsum('nki,nk->ni', Jpw, res))
+    W = np.einsum('nki,nkj->nij', Jcw, Jp)
+    return dict(Hcc=Hcc, Hpp=Hpp, bc=bc, bp=bp, W=W, res=res, w=w, Jc=Jc, Jp=Jp)

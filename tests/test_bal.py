@@ -117,3 +117,116 @@ def test_undistorted_bal_problem_is_adjusted_through_the_reference_model():
         r = o.bal_residuals(done.cams, done.pts, done.cam_idx, done.pt_idx, done.uv)
         assert abs(float((r * r).sum()) - out["final_sse"]) <= 1e-8 * out["final_sse"]
         assert np.sqrt((r * r).sum() / start.n_obs) < 0.45
+
+
+def _perturbed(p, seed, pose=1e-3, pt=0.02, focal=0.01):
+    rng = np.random.default_rng(seed)
+    cams = p.cams.copy()
+    cams[:, :6] += rng.normal(0, pose, (p.n_cams, 6))
+    cams[:, 6] *= 1.0 + focal * rng.normal(size=p.n_cams)
+    return BALProblem(cams, p.pts + rng.normal(0, pt, p.pts.shape), p.cam_idx, p.pt_idx, p.uv)
+
+
+def _synthetic_bal(n_cams, n_pts, k, seed, return_truth=False):
+    """A BAL-convention problem with distinct (f, k1, k2) per camera, pixel noise 0.5, and a perturbed start."""
+    rng = np.random.default_rng(seed)
+    rvec = rng.normal(0, 0.05, (n_cams, 3))
+    centre = np.stack([np.linspace(0, 0.4 * n_cams, n_cams), 0.1 * rng.normal(size=n_cams), 0.1 * rng.normal(size=n_cams)], 1)
+    R = o.rodrigues_batch(rvec)
+    t = -np.einsum("nij,nj->ni", R, centre)
+    cams = np.concatenate([rvec, t, (800.0 + 40.0 * rng.normal(size=n_cams))[:, None], (-0.05 + 0.02 * rng.normal(size=n_cams))[:, None],
+                           (0.01 * rng.normal(size=n_cams))[:, None]], axis=1)
+    pts = np.stack([rng.uniform(-2, 0.4 * n_cams + 2, n_pts), rng.uniform(-1.5, 1.5, n_pts), rng.uniform(-14, -6, n_pts)], 1)
+    # every point is seen by k of the 2k cameras nearest to it along the track (a camera far down the track would see it at a
+    # grazing angle, where the radial polynomial is meaningless)
+    near = np.argsort(np.abs(pts[:, :1] - centre[None, :, 0]), axis=1)[:, :min(2 * k, n_cams)]
+    cam_idx = np.concatenate([np.sort(rng.choice(near[j], size=k, replace=False)) for j in range(n_pts)]).astype(np.int32)
+    pt_idx = np.repeat(np.arange(n_pts, dtype=np.int32), k)
+    proj = -o.bal_residuals(cams, pts, cam_idx, pt_idx, np.zeros((len(cam_idx), 2)))
+    start = _perturbed(BALProblem(cams, pts, cam_idx, pt_idx, proj + rng.normal(0, 0.5, proj.shape)), seed + 1)
+    return (start, cams) if return_truth else start
+
+
+def test_oracle_bal_lm_dense_and_pcg_agree():
+    """CPU: oracle.lm_solve(model='bal') -- the checker of ba_solve_bal -- with the explicit 9-block reduced system solved
+    exactly against the matrix-free operator with PCG driven to round-off."""
+    p = _perturbed(read_bal(TINY), 3)
+    kw = dict(fixed_cam=-1, loss="huber", max_iters=6, ftol=0.0, xtol=0.0, gtol=0.0, model="bal", precond="jacobi")
+    a = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, None, linear_solver="dense", **kw)
+    b = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, None, pcg_tol=1e-13, pcg_max_iters=5000, **kw)
+    assert a["cost"] < 0.1 * a["cost0"]
+    for ha, hb in zip(a["history"], b["history"]):
+        assert abs(ha["cost_new"] - hb["cost_new"]) <= 1e-8 * hb["cost_new"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loss,fixed", [("linear", -1), ("huber", 2)])
+def test_device_bal_linearisation_matches_the_oracle_blocks(loss, fixed):
+    """ba_linearize_bal (2x9 camera blocks, K2 of row f2) against oracle.bal_normal_equations, whose blocks are tested
+    against central differences above."""
+    from bundle_adjustment_amd import hip_backend
+    p = _synthetic_bal(12, 300, 4, seed=4)
+    ne = o.bal_normal_equations(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, fixed, loss)
+    iu9, iu3 = np.triu_indices(9), np.triu_indices(3)
+    with hip_backend.Solver(0) as s:
+        out = s.linearize_bal(p, loss, fixed_cam=fixed)
+    for dev, ref in ((out["Hcc"], ne["Hcc"][:, iu9[0], iu9[1]]), (out["bc"], ne["bc"]), (out["Hpp"], ne["Hpp"][:, iu3[0], iu3[1]]),
+                     (out["bp"], ne["bp"])):
+        assert np.abs(dev - ref).max() <= 1e-10 * np.abs(ref).max()
+    if fixed >= 0:
+        assert not out["Hcc"][fixed].any() and not out["bc"][fixed].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["tiny_huber", "synthetic_linear_fixed"])
+def test_device_bal_solve_follows_the_oracle_lm(case):
+    """ba_solve_bal against oracle.lm_solve(model='bal', precond='jacobi'): every LM iteration (PCG iteration count, trial
+    cost, damping, acceptance), then the adjusted cameras (f, k1, k2 included) and points."""
+    from bundle_adjustment_amd import hip_backend
+    if case == "tiny_huber":
+        p, loss, fixed = _perturbed(read_bal(TINY), 3), "huber", -1
+    else:
+        p, loss, fixed = _synthetic_bal(20, 600, 5, seed=8), "linear", 0
+    iters = 8
+    ref = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, None, fixed_cam=fixed, loss=loss, max_iters=iters, ftol=0.0, xtol=0.0,
+                     gtol=0.0, pcg_tol=1e-2, pcg_max_iters=300, precond="jacobi", model="bal")
+    with hip_backend.Solver(0) as s:
+        out, cams, pts = s.solve_bal(p, fixed_cam=fixed, loss=loss, max_iters=iters, ftol=0.0, xtol=0.0, gtol=0.0, pcg_tol=1e-2,
+                                     pcg_max_iters=300, pcg_min_iters=0)
+        tr = s.trace()
+    assert out["iterations"] == iters == len(ref["history"])
+    assert abs(out["initial_cost"] - ref["cost0"]) <= 1e-10 * ref["cost0"]
+    compared = 0
+    for t, h in zip(tr, ref["history"]):
+        if abs(h["cost"] - h["cost_new"]) <= 1e-8 * h["cost"]:
+            break                      # converged: accept / reject is decided by round-off from here on, the paths may part
+        assert abs(t["pcg_iterations"] - h["pcg"]) <= 1, (t, h)
+        assert abs(t["cost_trial"] - h["cost_new"]) <= 1e-6 * h["cost_new"], (t, h)
+        assert bool(t["accepted"]) == bool(h["rho"] > 0)
+        compared += 1
+    assert compared >= 3
+    assert abs(out["final_cost"] - ref["cost"]) <= 1e-6 * ref["cost"]
+    assert out["final_cost"] < 0.1 * out["initial_cost"]
+    assert np.abs(cams - ref["cams"]).max() <= 1e-4 * np.abs(ref["cams"]).max()
+    assert np.abs(pts - ref["pts"]).max() <= 1e-4 * np.abs(ref["pts"]).max()
+    if fixed >= 0:
+        assert np.array_equal(cams[fixed], p.cams[fixed])
+    # the summary's cost is the BAL residual of what the handle returned
+    r = o.bal_residuals(cams, pts, p.cam_idx, p.pt_idx, p.uv)
+    assert abs(o.robust_cost(r, loss) - out["final_cost"]) <= 1e-9 * out["final_cost"]
+
+
+@pytest.mark.gpu
+def test_device_bal_solve_converges_on_a_larger_problem():
+    """120 cameras / 6000 points / 36 k observations, poses, points and focal lengths perturbed, no camera held: the solve
+    stops on the reference's kind of tolerance with the reprojection RMSE at the pixel noise (0.5 px per coordinate), and the
+    summary's SSE is the oracle's BAL residual of the returned parameters."""
+    from bundle_adjustment_amd import hip_backend
+    p = _synthetic_bal(120, 6000, 6, seed=10)
+    with hip_backend.Solver(0) as s:
+        out, cams, pts = s.solve_bal(p, loss="huber", max_iters=60, ftol=1e-8, xtol=1e-10, gtol=1e-10, pcg_tol=1e-1, pcg_max_iters=300)
+    assert out["status_name"] in ("ftol", "xtol", "gtol")
+    assert np.sqrt(out["initial_sse"] / p.n_obs) > 2.0 and np.sqrt(out["final_sse"] / p.n_obs) < 0.7
+    assert np.abs(cams[:, 6:] - p.cams[:, 6:]).max() > 0                  # f, k1, k2 were adjusted with the poses
+    r = o.bal_residuals(cams, pts, p.cam_idx, p.pt_idx, p.uv)
+    assert abs(float((r * r).sum()) - out["final_sse"]) <= 1e-9 * out["final_sse"]
