@@ -17,8 +17,9 @@ then y, the reference's sign (``src/bundle_adjuster.py:68-69``).
 What runs where: ``read_bal`` / ``write_bal`` are host code; ``Solver.residuals_bal`` evaluates the BAL residual on the
 GPU (``ba_residuals_bal``: K1 with per-camera ``f, k1, k2``); ``to_pinhole`` converts a BAL problem whose cameras share
 one focal length and have no distortion into the reference's model (z flipped, shared K), which the LM / Schur / PCG
-solver then adjusts as it stands.  The 2x9 camera blocks (f, k1, k2 as unknowns in K2-K7) are not built yet; the
-oracle has the analytic 2x9 block (``oracle.ba_oracle.bal_jacobian_blocks``) they will be checked against.
+solver then adjusts as it stands; ``solve`` / ``Solver.solve_bal`` adjust the full 9-parameter cameras (``ba_solve_bal``,
+``csrc/ba_bal.hpp``: LM + Schur + PCG with 2x9 camera blocks, checked step by step against
+``oracle.lm_solve(model='bal')``), ``Solver.linearize_bal`` returns the block normal equations (``ba_linearize_bal``).
 """
 from __future__ import annotations
 
@@ -118,14 +119,27 @@ def to_pinhole(prob: BALProblem, tol=0.0) -> BAProblem:
 
 
 def from_pinhole(prob: BAProblem) -> BALProblem:
-    """Inverse of ``to_pinhole`` for problems with ``fy = -fx`` and a zero principal point, else the general pinhole
-    written as a BAL problem is not representable (BAL has one focal length and no principal point)."""
+    """A problem in the reference's camera model written as a BAL problem: needs |fy| = fx (BAL has one focal length);
+    the principal point is taken out of the pixels (BAL's origin is the image centre) and, for fy = +fx, the y axis is
+    turned over (BAL's camera looks down -z: v_bal = -(v - cy)).  Inverse of ``to_pinhole`` when K4 = (f, -f, 0, 0)."""
     from .rotations import matrices_to_rvecs, rvecs_to_matrices
     fx, fy, cx, cy = (float(v) for v in prob.K4)
-    if fy != -fx or cx != 0.0 or cy != 0.0:
-        raise ValueError("only K4 = (f, -f, 0, 0) maps onto the BAL camera")
+    if abs(fy) != fx:
+        raise ValueError("only |fy| = fx maps onto the BAL camera (one focal length)")
     S = np.diag([1.0, -1.0, -1.0])
     R = S @ rvecs_to_matrices(prob.cams[:, :3])
     t = prob.cams[:, 3:6] @ S.T
     cams = np.concatenate([matrices_to_rvecs(R), t, np.tile([fx, 0.0, 0.0], (prob.n_cams, 1))], axis=1)
-    return BALProblem(cams, prob.pts.copy(), prob.cam_idx.copy(), prob.pt_idx.copy(), prob.uv.copy()).validate()
+    uv = prob.uv - np.array([cx, cy])
+    if fy > 0:
+        uv = uv * np.array([1.0, -1.0])
+    return BALProblem(cams, prob.pts.copy(), prob.cam_idx.copy(), prob.pt_idx.copy(), uv).validate()
+
+
+def solve(prob: BALProblem, device=0, fixed_cam=-1, **options):
+    """Adjust a BAL problem on the GPU (``ba_solve_bal``: poses, points AND f / k1 / k2 per camera).  Returns
+    ``(BALProblem with the adjusted parameters, summary dict)``; options as ``hip_backend.Solver.solve``."""
+    from . import hip_backend
+    with hip_backend.Solver(device) as s:
+        summary, cams, pts = s.solve_bal(prob, fixed_cam=fixed_cam, **options)
+    return BALProblem(cams, pts, prob.cam_idx.copy(), prob.pt_idx.copy(), prob.uv.copy()), summary

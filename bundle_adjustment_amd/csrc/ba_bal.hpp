@@ -8,8 +8,9 @@
 //                  Jp = -B;  Jc = [ (B_row x X) M | -A | -rad p | -f n2 p | -f n2^2 p ]     (M: right Jacobian of SO(3))
 //
 // These are first-version kernels: correct, deterministic, resident on the device, but written for clarity, not tuned
-// like the 6-parameter family in ba_kernels.hpp (no LDS camera table, one thread per point, one workgroup for the
-// camera-vector algebra).  Camera-major passes reuse that family's (camera, partition) wave mapping and its wave sums;
+// like the 6-parameter family in ba_kernels.hpp (no LDS camera table: camera rows come through L1 / L2; 8 lanes per
+// point; ONE workgroup for the camera-vector algebra, a thread per vector entry; the host waits for a verdict word after
+// every PCG iteration).  Camera-major passes reuse that family's (camera, partition) wave mapping and its wave sums;
 // the host loop (ba_solve_bal in ba_hip.hip) mirrors oracle.lm_solve(model='bal', precond='jacobi') line by line.
 #pragma once
 #include "ba_kernels.hpp"
@@ -21,8 +22,18 @@ constexpr int BH = 45;                // packed upper triangle of a 9x9 block
 constexpr int BLIN = BH + BC + 2;     // running sums of the camera half: Hcc | bc | sum r^2 | sum rho-term
 constexpr int BAL_VEC_THREADS = 1024; // the camera-vector kernels are ONE workgroup
 constexpr int BAL_PT_THREADS = 256;
+constexpr int BAL_LANES = 8;          // lanes per point in the point passes (tracks are short on average, a few are long)
+constexpr int BAL_PTS_PER_BLOCK = BAL_PT_THREADS / BAL_LANES;
+constexpr int BF = BC * BC;           // a full 9x9 block, row-major (the vector kernels read rows)
 
 __host__ __device__ constexpr int U9(int a, int b) { return a * 9 - a * (a - 1) / 2 + (b - a); }   // a <= b
+
+struct BalPcg {            // device-resident PCG state; iteration k reads st[k & 1] and leaves st[(k + 1) & 1]
+  double rz, rz0;
+  int iters, done;
+};
+constexpr int BAL_CAMS_PER_WG = 28;                         // camera-vector kernels: whole cameras per workgroup,
+constexpr int BAL_VEC_WG = 256;                             // 252 of 256 threads hold one vector entry each
 
 struct BalObs {
   double r0, r1;          // residual
@@ -114,19 +125,19 @@ k_bal_lin_cam(const double* __restrict__ cs, const double* __restrict__ intr, co
   wave_store_sums<BLIN>(acc, s.lane, partL + ((size_t)s.k * n_cams + s.c) * BLIN);
 }
 
-// ---- K2, point half (thread = point): Hpp (6 packed), bp (3), block maximum of |bp|
+// ---- K2, point half (BAL_LANES lanes per point): Hpp (6 packed), bp (3), block maximum of |bp|
 template <bool ROBUST>
 __global__ void __launch_bounds__(BAL_PT_THREADS)
 k_bal_lin_pt(const double* __restrict__ cs, const double* __restrict__ intr, const double* __restrict__ ptab,
              const int* __restrict__ pt_off, const int* __restrict__ p_cam, const double2* __restrict__ p_uv, double hub_c,
              int n_pts, double* __restrict__ Hpp, double* __restrict__ bp, double* __restrict__ partG) {
   __shared__ double sm[BAL_PT_THREADS / 64];
-  const int p = blockIdx.x * BAL_PT_THREADS + threadIdx.x;
+  const int p = blockIdx.x * BAL_PTS_PER_BLOCK + threadIdx.x / BAL_LANES, sub = threadIdx.x % BAL_LANES;
   double gm = 0.0;
+  double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (p < n_pts) {
     const double4 X = *(const double4*)(ptab + PT * (size_t)p);
-    double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int j = pt_off[p]; j < pt_off[p + 1]; ++j) {
+    for (int j = pt_off[p] + sub; j < pt_off[p + 1]; j += BAL_LANES) {
       const int c = p_cam[j];
       const double2 uv = p_uv[j];
       BalObs g;
@@ -141,6 +152,10 @@ k_bal_lin_pt(const double* __restrict__ cs, const double* __restrict__ intr, con
         a[6 + q] -= wa0 * g.r0 + wa1 * g.r1;                              // Jp^T w r
       }
     }
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) a[q] = lanes_sum<BAL_LANES>(a[q]);
+  if (p < n_pts && sub == BAL_LANES - 1) {
 #pragma unroll
     for (int q = 0; q < 6; ++q) Hpp[6 * (size_t)p + q] = a[q];
 #pragma unroll
@@ -156,7 +171,7 @@ k_bal_lin_pt(const double* __restrict__ cs, const double* __restrict__ intr, con
   }
 }
 
-// ---- point pass of the Schur product (thread = point).  u = sum_o Jp^T w (Jc v_c);
+// ---- point pass of the Schur product (BAL_LANES lanes per point).  u = sum_o Jp^T w (Jc v_c);
 //   MODE 0 (PCG): y = Hppinv u into the point record's y slot.
 //   MODE 1 (back substitution, v = dc): dp = -(y0 + Hppinv u), trial point, partB[block][4] = bp.dp, sum Dp dp^2, |dp|^2, |X|^2
 template <bool ROBUST, int MODE>
@@ -165,14 +180,16 @@ k_bal_pt_schur(const double* __restrict__ cs, const double* __restrict__ intr, d
                const int* __restrict__ pt_off, const int* __restrict__ p_cam, const double2* __restrict__ p_uv, double hub_c,
                int n_pts, int fixed_cam, const double* __restrict__ vec, const double* __restrict__ Hppinv,
                const double* __restrict__ y0, const double* __restrict__ Hpp, const double* __restrict__ bp,
-               double* __restrict__ ptab_trial, double* __restrict__ partB) {
+               double* __restrict__ ptab_trial, double* __restrict__ partB, const BalPcg* __restrict__ st_k) {
   __shared__ double sm[4 * (BAL_PT_THREADS / 64)];
-  const int p = blockIdx.x * BAL_PT_THREADS + threadIdx.x;
+  if (st_k && st_k->done) return;                      // queued past the end of PCG
+  const int p = blockIdx.x * BAL_PTS_PER_BLOCK + threadIdx.x / BAL_LANES, sub = threadIdx.x % BAL_LANES;
   double acc[4] = {0, 0, 0, 0};
+  double u[3] = {0, 0, 0};
+  double4 X = make_double4(0, 0, 0, 0);
   if (p < n_pts) {
-    const double4 X = *(const double4*)(ptab + PT * (size_t)p);
-    double u[3] = {0, 0, 0};
-    for (int j = pt_off[p]; j < pt_off[p + 1]; ++j) {
+    X = *(const double4*)(ptab + PT * (size_t)p);
+    for (int j = pt_off[p] + sub; j < pt_off[p + 1]; j += BAL_LANES) {
       const int c = p_cam[j];
       if (c == fixed_cam) continue;
       const double2 uv = p_uv[j];
@@ -192,6 +209,10 @@ k_bal_pt_schur(const double* __restrict__ cs, const double* __restrict__ intr, d
       u[1] -= g.B[1] * s0 + g.B[4] * s1;
       u[2] -= g.B[2] * s0 + g.B[5] * s1;
     }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) u[q] = lanes_sum<BAL_LANES>(u[q]);
+  if (p < n_pts && sub == BAL_LANES - 1) {
     double hi[6], yy[3];
 #pragma unroll
     for (int q = 0; q < 6; ++q) hi[q] = Hppinv[6 * (size_t)p + q];
@@ -232,7 +253,8 @@ template <bool ROBUST>
 __global__ void __launch_bounds__(64 * WPB)
 k_bal_cam_schur(const double* __restrict__ cs, const double* __restrict__ intr, const double* __restrict__ ptab,
                 const int* __restrict__ offk, const int* __restrict__ c_pt, const double2* __restrict__ c_uv, double hub_c,
-                int n_cams, int band, int fixed_cam, double* __restrict__ part9) {
+                int n_cams, int band, int fixed_cam, double* __restrict__ part9, const BalPcg* __restrict__ st_k) {
+  if (st_k && st_k->done) return;                      // queued past the end of PCG
   Seg s;
   if (!cam_segment(offk, n_cams, band, s)) return;
   const double* cam = cs + CS * s.c;
@@ -281,18 +303,9 @@ __device__ inline void bal_block_sum(double (&v)[N], double* __restrict__ sm /* 
   }
 }
 
-__device__ inline void sym9_mul(const double* __restrict__ h /* packed 45 */, const double* __restrict__ v, double* __restrict__ o) {
-#pragma unroll
-  for (int a = 0; a < BC; ++a) {
-    double s = 0.0;
-#pragma unroll
-    for (int b = 0; b < BC; ++b) s += h[a <= b ? U9(a, b) : U9(b, a)] * v[b];
-    o[a] = s;
-  }
-}
-
-// Linearisation -> damped blocks and their inverses (block-Jacobi preconditioner).  relin: fold the camera half's
-// partition sums into HccBc first (a rejected step only re-damps).  Also the initial cost of this linearisation.
+// Linearisation -> damped blocks and their inverses (block-Jacobi preconditioner), both as full row-major 9x9 so that the
+// vector kernels read rows.  relin: fold the camera half's partition sums into HccBc first (a rejected step only
+// re-damps).  Also the cost of this linearisation (the camera half carried sum r^2 and the rho terms).
 __global__ void __launch_bounds__(BAL_VEC_THREADS)
 k_bal_prep(const double* __restrict__ partL, int relin, double lambda, int n_cams, int fixed_cam, double* __restrict__ HccBc,
            double* __restrict__ Hd, double* __restrict__ Minv, double* __restrict__ out /* [0] sse, [1] rho-sum (relin only) */) {
@@ -326,7 +339,7 @@ k_bal_prep(const double* __restrict__ partL, int relin, double lambda, int n_cam
       for (int a = 0; a < BC; ++a)
         for (int b = 0; b < BC; ++b) Lm[a][b] = (a == b) ? 1.0 : 0.0;
     for (int a = 0; a < BC; ++a)
-      for (int b = a; b < BC; ++b) Hd[(size_t)c * BH + U9(a, b)] = Lm[a][b];
+      for (int b = 0; b < BC; ++b) Hd[(size_t)c * BF + a * BC + b] = Lm[a][b];
     for (int j = 0; j < BC; ++j) {                       // Cholesky, lower triangle in place
       double d = Lm[j][j];
       for (int k = 0; k < j; ++k) d -= Lm[j][k] * Lm[j][k];
@@ -351,7 +364,8 @@ k_bal_prep(const double* __restrict__ partL, int relin, double lambda, int n_cam
       for (int b = a; b < BC; ++b) {
         double s = 0.0;
         for (int k = b; k < BC; ++k) s += Li[k][a] * Li[k][b];
-        Minv[(size_t)c * BH + U9(a, b)] = s;
+        Minv[(size_t)c * BF + a * BC + b] = s;
+        Minv[(size_t)c * BF + b * BC + a] = s;
       }
   }
   if (relin) {
@@ -360,12 +374,19 @@ k_bal_prep(const double* __restrict__ partL, int relin, double lambda, int n_cam
   }
 }
 
-struct BalPcg {            // device-resident PCG state
-  double rz, rz0, pq, rz_new;
-  int iters, done;
-};
 
-// g = -(bc - W y0) from the camera pass on y0; r = g, z = Minv r, p = z, x = 0; rz0; max |gradient|
+// row e = 9 c + a of a block-diagonal product: sum_b M[c][a][b] v[9 c + b]
+__device__ inline double bal_row_dot(const double* __restrict__ M, const double* __restrict__ v, int e) {
+  const int c = e / BC;
+  const double* row = M + (size_t)e * BC;
+  const double* vc = v + (size_t)c * BC;
+  double s = 0.0;
+#pragma unroll
+  for (int b = 0; b < BC; ++b) s += row[b] * vc[b];
+  return s;
+}
+
+// g = -(bc - W y0) from the camera pass on y0; r = g, z = Minv r, p = z, x = 0; rz0; max |gradient|.  Thread = vector entry.
 __global__ void __launch_bounds__(BAL_VEC_THREADS)
 k_bal_pcg_init(const double* __restrict__ HccBc, const double* __restrict__ part9, const double* __restrict__ Minv,
                const double* __restrict__ partG, int nG, int n_cams, int fixed_cam, double* __restrict__ x, double* __restrict__ r,
@@ -373,26 +394,25 @@ k_bal_pcg_init(const double* __restrict__ HccBc, const double* __restrict__ part
                long long* __restrict__ host_flag, long long seq) {
   __shared__ double sm[(BAL_VEC_THREADS / 64) * 1];
   __shared__ double smax[BAL_VEC_THREADS / 64];
-  double acc[1] = {0.0};
+  const int n = n_cams * BC;
   double gm = 0.0;
-  for (int c = threadIdx.x; c < n_cams; c += BAL_VEC_THREADS) {
-    double g[BC], zz[BC];
-    const double* bc = HccBc + (size_t)c * (BH + BC) + BH;
-#pragma unroll
-    for (int q = 0; q < BC; ++q) {
-      double wy = 0.0;
-      for (int k = 0; k < NPART; ++k) wy += part9[((size_t)k * n_cams + c) * BC + q];
-      g[q] = (c == fixed_cam) ? 0.0 : -(bc[q] - wy);
-      gm = nanmax(gm, fabs(bc[q]));
-    }
-    sym9_mul(Minv + (size_t)c * BH, g, zz);
-#pragma unroll
-    for (int q = 0; q < BC; ++q) {
-      x[(size_t)c * BC + q] = 0.0; r[(size_t)c * BC + q] = g[q]; z[(size_t)c * BC + q] = zz[q]; p[(size_t)c * BC + q] = zz[q];
-      acc[0] += g[q] * zz[q];
-    }
+  for (int e = threadIdx.x; e < n; e += BAL_VEC_THREADS) {
+    const int c = e / BC, a = e % BC;
+    const double bca = HccBc[(size_t)c * (BH + BC) + BH + a];
+    double wy = 0.0;
+    for (int k = 0; k < NPART; ++k) wy += part9[(size_t)k * n + e];
+    r[e] = (c == fixed_cam) ? 0.0 : -(bca - wy);
+    x[e] = 0.0;
+    gm = nanmax(gm, fabs(bca));
   }
   for (int b = threadIdx.x; b < nG; b += BAL_VEC_THREADS) gm = nanmax(gm, partG[b]);
+  __syncthreads();                                      // r complete (this workgroup wrote all of it)
+  double acc[1] = {0.0};
+  for (int e = threadIdx.x; e < n; e += BAL_VEC_THREADS) {
+    const double ze = bal_row_dot(Minv, r, e);
+    z[e] = ze; p[e] = ze;
+    acc[0] += r[e] * ze;
+  }
   bal_block_sum<1>(acc, sm);
   gm = wave_nanmax(gm);
   if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = gm;
@@ -400,75 +420,112 @@ k_bal_pcg_init(const double* __restrict__ HccBc, const double* __restrict__ part
   if (threadIdx.x == 0) {
     double m = 0.0;
     for (int w = 0; w < BAL_VEC_THREADS / 64; ++w) m = nanmax(m, smax[w]);
-    st->rz = acc[0]; st->rz0 = acc[0]; st->iters = 0; st->done = !(acc[0] > 0.0);
+    st[0].rz = acc[0]; st[0].rz0 = acc[0]; st[0].iters = 0; st[0].done = !(acc[0] > 0.0);
     host_out[0] = acc[0]; host_out[1] = m;
     publish_flag(host_flag, seq, 1);
   }
 }
 
-// one PCG iteration on the camera vectors (oracle.pcg): q = S p from the two passes, alpha, x, r, z, rz, beta, p
-__global__ void __launch_bounds__(BAL_VEC_THREADS)
-k_bal_pcg_step(const double* __restrict__ Hd, const double* __restrict__ Minv, const double* __restrict__ part9, int n_cams,
-               int fixed_cam, double tol2, int min_iters, double* __restrict__ x, double* __restrict__ r, double* __restrict__ z,
-               double* __restrict__ p, double* __restrict__ q, BalPcg* __restrict__ st, long long* __restrict__ host_flag, long long seq) {
-  __shared__ double sm[(BAL_VEC_THREADS / 64) * 1];
-  double acc[1] = {0.0};
-  for (int c = threadIdx.x; c < n_cams; c += BAL_VEC_THREADS) {
-    double pv[BC], qv[BC];
-#pragma unroll
-    for (int a = 0; a < BC; ++a) pv[a] = p[(size_t)c * BC + a];
-    if (c == fixed_cam) {
-#pragma unroll
-      for (int a = 0; a < BC; ++a) qv[a] = pv[a];
-    } else {
-      sym9_mul(Hd + (size_t)c * BH, pv, qv);
-#pragma unroll
-      for (int a = 0; a < BC; ++a) {
-        double w = 0.0;
-        for (int k = 0; k < NPART; ++k) w += part9[((size_t)k * n_cams + c) * BC + a];
-        qv[a] -= w;
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < BC; ++a) { q[(size_t)c * BC + a] = qv[a]; acc[0] += pv[a] * qv[a]; }
-  }
-  bal_block_sum<1>(acc, sm);
-  const double pq = acc[0], rz = st->rz, rz0 = st->rz0;
-  const int it0 = st->iters;
-  if (!(pq > 0.0)) {                                    // breakdown: leave x, r as they are (oracle: break)
-    __syncthreads();
-    if (threadIdx.x == 0) { st->done = 1; st->pq = pq; publish_flag(host_flag, seq, 2); }
-    return;
-  }
-  const double alpha = rz / pq;
-  acc[0] = 0.0;
-  for (int c = threadIdx.x; c < n_cams; c += BAL_VEC_THREADS) {
-    double rv[BC], zz[BC];
-#pragma unroll
-    for (int a = 0; a < BC; ++a) {
-      x[(size_t)c * BC + a] += alpha * p[(size_t)c * BC + a];
-      rv[a] = r[(size_t)c * BC + a] - alpha * q[(size_t)c * BC + a];
-      r[(size_t)c * BC + a] = rv[a];
-    }
-    sym9_mul(Minv + (size_t)c * BH, rv, zz);
-#pragma unroll
-    for (int a = 0; a < BC; ++a) { z[(size_t)c * BC + a] = zz[a]; acc[0] += rv[a] * zz[a]; }
-  }
-  bal_block_sum<1>(acc, sm);
-  const double rz_new = acc[0];
-  const int it = it0 + 1;
-  const bool done = it >= min_iters && rz_new <= tol2 * rz0;
-  if (!done) {
-    const double beta = rz_new / rz;
-    for (int c = threadIdx.x; c < n_cams; c += BAL_VEC_THREADS) {
-#pragma unroll
-      for (int a = 0; a < BC; ++a) p[(size_t)c * BC + a] = z[(size_t)c * BC + a] + beta * p[(size_t)c * BC + a];
-    }
-  }
+// deterministic sum of n per-workgroup partials, the same in every thread of every workgroup
+__device__ inline double bal_sum_partials(const double* __restrict__ part, int n) {
+  double a = 0.0;
+  for (int w = 0; w < n; ++w) a += part[w];
+  return a;
+}
+// workgroup sum (256 threads) of one value -> thread 0
+__device__ inline double bal_wg_sum(double v, double* __restrict__ sm /* [4] */) {
+  v = wave_total_dpp(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    st->rz = rz_new; st->rz_new = rz_new; st->pq = pq; st->iters = it; st->done = done ? 1 : 0;
-    publish_flag(host_flag, seq, done ? 2 : 1);
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+// One PCG iteration on the camera vectors (oracle.pcg) in three launches of ceil(Nc / 28) workgroups, each holding whole
+// cameras; every workgroup re-sums the previous launch's per-workgroup partials in the same order, so all agree on
+// alpha / beta / the verdict without a grid-wide barrier:
+//   a: q = S p from the two passes (Hd p - W Hpp^-1 W^T p), partA[wg] = p . q
+//   b: alpha = rz / sum partA;  x += alpha p;  r -= alpha q;  z = Minv r;  partZ[wg] = r . z
+//   c: rz' = sum partZ; verdict; p = z + (rz' / rz) p; workgroup 0 leaves the next state and tells the host
+// Iterations queued past the end of PCG (the host enqueues k + 1 before it has k's verdict) find done set and return.
+__global__ void __launch_bounds__(BAL_VEC_WG)
+k_bal_pcg_a(int k, const BalPcg* __restrict__ st, const double* __restrict__ Hd, const double* __restrict__ part9, int n_cams,
+            int fixed_cam, const double* __restrict__ p, double* __restrict__ q, double* __restrict__ partA) {
+  __shared__ double sm[4];
+  if (st[k & 1].done) return;
+  const int n = n_cams * BC;
+  const int e = blockIdx.x * (BAL_CAMS_PER_WG * BC) + threadIdx.x;
+  double v = 0.0;
+  if (threadIdx.x < BAL_CAMS_PER_WG * BC && e < n) {
+    const int c = e / BC;
+    double qe;
+    if (c == fixed_cam) qe = p[e];
+    else {
+      double w = 0.0;
+      for (int kk = 0; kk < NPART; ++kk) w += part9[(size_t)kk * n + e];
+      qe = bal_row_dot(Hd, p, e) - w;
+    }
+    q[e] = qe;
+    v = p[e] * qe;
+  }
+  const double tot = bal_wg_sum(v, sm);
+  if (threadIdx.x == 0) partA[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(BAL_VEC_WG)
+k_bal_pcg_b(int k, const BalPcg* __restrict__ st, const double* __restrict__ Minv, const double* __restrict__ partA, int n_wg,
+            int n_cams, const double* __restrict__ p, const double* __restrict__ q, double* __restrict__ x, double* __restrict__ r,
+            double* __restrict__ z, double* __restrict__ partZ) {
+  __shared__ double sm[4];
+  const BalPcg s = st[k & 1];
+  if (s.done) return;
+  const double pq = bal_sum_partials(partA, n_wg);
+  if (!(pq > 0.0)) return;                               // breakdown: x, r stay (kernel c reports it)
+  const double alpha = s.rz / pq;
+  const int n = n_cams * BC;
+  const int e = blockIdx.x * (BAL_CAMS_PER_WG * BC) + threadIdx.x;
+  const bool live = threadIdx.x < BAL_CAMS_PER_WG * BC && e < n;
+  if (live) {
+    x[e] += alpha * p[e];
+    r[e] -= alpha * q[e];
+  }
+  __syncthreads();                                       // the camera's nine r entries, all written by this workgroup
+  double v = 0.0;
+  if (live) {
+    const double ze = bal_row_dot(Minv, r, e);
+    z[e] = ze;
+    v = r[e] * ze;
+  }
+  const double tot = bal_wg_sum(v, sm);
+  if (threadIdx.x == 0) partZ[blockIdx.x] = tot;
+}
+
+// verdict word = flag_base + 4 (k + 1) + {1 go on, 2 converged after k + 1 iterations, 3 broke down in iteration k + 1 (p.Sp <= 0)}
+__global__ void __launch_bounds__(BAL_VEC_WG)
+k_bal_pcg_c(int k, BalPcg* __restrict__ st, const double* __restrict__ partA, const double* __restrict__ partZ, int n_wg, int n_cams,
+            double tol2, int min_iters, const double* __restrict__ z, double* __restrict__ p, long long* __restrict__ host_flag,
+            long long flag_base) {
+  const BalPcg s = st[k & 1];
+  if (s.done) return;
+  const double pq = bal_sum_partials(partA, n_wg);
+  BalPcg nx = s;
+  int verdict;
+  if (!(pq > 0.0)) { nx.done = 1; verdict = 3; }
+  else {
+    const double rz_new = bal_sum_partials(partZ, n_wg);
+    nx.iters = s.iters + 1;
+    nx.done = (nx.iters >= min_iters && rz_new <= tol2 * s.rz0) ? 1 : 0;
+    nx.rz = rz_new;
+    verdict = nx.done ? 2 : 1;
+    if (!nx.done) {
+      const double beta = rz_new / s.rz;
+      const int n = n_cams * BC;
+      const int e = blockIdx.x * (BAL_CAMS_PER_WG * BC) + threadIdx.x;
+      if (threadIdx.x < BAL_CAMS_PER_WG * BC && e < n) p[e] = z[e] + beta * p[e];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st[(k + 1) & 1] = nx;
+    __hip_atomic_store(host_flag, flag_base + 4 * (long long)(k + 1) + verdict, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -504,25 +561,24 @@ k_bal_update(const double* __restrict__ cams, const double* __restrict__ intr, c
   }
 }
 
-// step sums to the host: out_host[0..8] = camera side (5) | point side (4, partB blocks in order) ; [9], [10] = sse, rho-sum of the trial
-__global__ void __launch_bounds__(64)
+// step sums to the host: out_host[0..8] = camera side (5) | point side (4, partB blocks) ; [9], [10] = sse, rho-sum of the trial
+__global__ void __launch_bounds__(BAL_VEC_THREADS)
 k_bal_step_sums(const double* __restrict__ cam5, const double* __restrict__ partB, int nB, const double* __restrict__ partR,
                 int n_cams, double* __restrict__ host_out, long long* __restrict__ host_flag, long long seq) {
-  double pb[4] = {0, 0, 0, 0}, e[2] = {0, 0};
-  for (int b = threadIdx.x; b < nB; b += 64) {
+  __shared__ double sm[(BAL_VEC_THREADS / 64) * 6];
+  double v[6] = {0, 0, 0, 0, 0, 0};
+  for (int b = threadIdx.x; b < nB; b += BAL_VEC_THREADS) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pb[q] += partB[4 * (size_t)b + q];
+    for (int q = 0; q < 4; ++q) v[q] += partB[4 * (size_t)b + q];
   }
-  for (int i = threadIdx.x; i < NPART * n_cams; i += 64) { e[0] += partR[2 * (size_t)i]; e[1] += partR[2 * (size_t)i + 1]; }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) pb[q] = wave_total_dpp(pb[q]);
-  e[0] = wave_total_dpp(e[0]); e[1] = wave_total_dpp(e[1]);
+  for (int i = threadIdx.x; i < NPART * n_cams; i += BAL_VEC_THREADS) { v[4] += partR[2 * (size_t)i]; v[5] += partR[2 * (size_t)i + 1]; }
+  bal_block_sum<6>(v, sm);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int q = 0; q < 5; ++q) host_out[q] = cam5[q];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) host_out[5 + q] = pb[q];
-    host_out[9] = e[0]; host_out[10] = e[1];
+    for (int q = 0; q < 4; ++q) host_out[5 + q] = v[q];
+    host_out[9] = v[4]; host_out[10] = v[5];
     publish_flag(host_flag, seq, 1);
   }
 }

@@ -176,7 +176,7 @@ struct ba_handle {
   size_t h_small_bytes = 0;
   long long small_seq = 0;     // sequence number of h_flags[4], which k_small_lm publishes when its results are written
   // BAL 9-parameter path (ba_solve_bal, csrc/ba_bal.hpp)
-  DBuf<double> bal_intr[2], bal_partL, bal_HccBc, bal_Hd, bal_Minv, bal_part9, bal_x, bal_r, bal_z, bal_p, bal_q, bal_misc, bal_partB, bal_partG;
+  DBuf<double> bal_intr[2], bal_partL, bal_HccBc, bal_Hd, bal_Minv, bal_part9, bal_x, bal_r, bal_z, bal_p, bal_q, bal_misc, bal_partB, bal_partG, bal_partA;
   DBuf<char> bal_st;
   long long bal_seq = 0;       // sequence number of h_flags[6]
   DBuf<double> small_V, small_gS;   // k_small_lm: V = W L (49 x 3 Np_pad, zero where unwritten), per-wave partial V V^T
@@ -344,7 +344,7 @@ extern "C" int ba_destroy(ba_handle* h) {
   h->tri.release();
   h->small_V.release();
   { DBuf<double>* bb[] = {&h->bal_intr[0], &h->bal_intr[1], &h->bal_partL, &h->bal_HccBc, &h->bal_Hd, &h->bal_Minv, &h->bal_part9, &h->bal_x,
-                          &h->bal_r, &h->bal_z, &h->bal_p, &h->bal_q, &h->bal_misc, &h->bal_partB, &h->bal_partG};
+                          &h->bal_r, &h->bal_z, &h->bal_p, &h->bal_q, &h->bal_misc, &h->bal_partB, &h->bal_partG, &h->bal_partA};
     for (auto b : bb) b->release(); }
   h->bal_st.release();
   h->small_gS.release();
@@ -1504,22 +1504,23 @@ static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
 // handle's (ba_set_params / ba_get_params); the per-camera (f, k1, k2) travel with the call.  K4 of ba_set_problem is
 // not used.  Single rank.
 static int bal_alloc(ba_handle* h) {
-  const size_t Nc = (size_t)h->Nc, nbP = ((size_t)h->Np + BAL_PT_THREADS - 1) / BAL_PT_THREADS;
+  const size_t Nc = (size_t)h->Nc, nbP = ((size_t)h->Np + BAL_PTS_PER_BLOCK - 1) / BAL_PTS_PER_BLOCK;
   for (int k = 0; k < 2; ++k) HIPCHECK(h->bal_intr[k].alloc(3 * Nc));
   HIPCHECK(h->bal_partL.alloc((size_t)NPART * Nc * BLIN));
   HIPCHECK(h->bal_HccBc.alloc(Nc * (BH + BC)));
-  HIPCHECK(h->bal_Hd.alloc(Nc * BH));
-  HIPCHECK(h->bal_Minv.alloc(Nc * BH));
+  HIPCHECK(h->bal_Hd.alloc(Nc * BF));
+  HIPCHECK(h->bal_Minv.alloc(Nc * BF));
   HIPCHECK(h->bal_part9.alloc((size_t)NPART * Nc * BC));
   DBuf<double>* v[] = {&h->bal_x, &h->bal_r, &h->bal_z, &h->bal_p, &h->bal_q};
   for (auto b : v) HIPCHECK(b->alloc(Nc * BC));
   HIPCHECK(h->bal_misc.alloc(16));
   HIPCHECK(h->bal_partB.alloc(4 * (nbP ? nbP : 1)));
   HIPCHECK(h->bal_partG.alloc(nbP ? nbP : 1));
-  HIPCHECK(h->bal_st.alloc(sizeof(BalPcg)));
+  HIPCHECK(h->bal_st.alloc(2 * sizeof(BalPcg)));
+  HIPCHECK(h->bal_partA.alloc(2 * (Nc / BAL_CAMS_PER_WG + 1)));
   return BA_OK;
 }
-static int bal_nblk_pt(const ba_handle* h) { return (h->Np + BAL_PT_THREADS - 1) / BAL_PT_THREADS; }
+static int bal_nblk_pt(const ba_handle* h) { return (h->Np + BAL_PTS_PER_BLOCK - 1) / BAL_PTS_PER_BLOCK; }
 // camera half + point half at parameter set `w`
 static void bal_launch_lin(ba_handle* h, int w, bool robust, double fs) {
   {
@@ -1614,7 +1615,7 @@ static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba
       Scope sc(h, BA_K_SCHUR_CAM);
       auto kc = robust ? k_bal_cam_schur<true> : k_bal_cam_schur<false>;
       BA_LAUNCH(kc, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->offk.p,
-                h->c_pt.p, h->c_uv.p, fs, Nc, h->cam_band, h->fixed, h->bal_part9.p);
+                h->c_pt.p, h->c_uv.p, fs, Nc, h->cam_band, h->fixed, h->bal_part9.p, (const BalPcg*)nullptr);
     }
     long long seq = ++h->bal_seq;
     if (it == 0 && need_lin) {                          // initial cost rides along: the camera half summed r^2 and the rho terms
@@ -1638,39 +1639,50 @@ static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba
     if (need_lin && gmax <= opts->gtol) { status = 3; break; }
     const double t1 = now_s();
     sum->seconds_linearize += t1 - t0;
-    // ---- PCG on the reduced camera system
+    // ---- PCG on the reduced camera system: iteration k + 1 is queued before k's verdict is read (kernels queued past
+    //      the end find the state's done flag and return), so the device never waits for the host
     int k = 0;
     if (rz0 > 0.0) {
       auto kp = robust ? k_bal_pt_schur<true, 0> : k_bal_pt_schur<false, 0>;
       auto kc = robust ? k_bal_cam_schur<true> : k_bal_cam_schur<false>;
-      while (k < opts->pcg_max_iters) {
+      const int nwg = (Nc + BAL_CAMS_PER_WG - 1) / BAL_CAMS_PER_WG;
+      double* partA = h->bal_partA.p, *partZ = h->bal_partA.p + nwg;
+      BalPcg* st = (BalPcg*)h->bal_st.p;
+      const long long base4 = (h->bal_seq / 4 + 1) * 4;   // verdict words: base4 + 4 (k + 1) + verdict, above every word published so far
+      int enq = -1;
+      auto enqueue = [&](int kk) {
+        enq = kk;
         {
           Scope sc(h, BA_K_SCHUR_PT);
           BA_LAUNCH(kp, dim3(nbP), dim3(BAL_PT_THREADS), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->pt_off.p,
                     h->p_cam.p, h->p_uv.p, fs, h->Np, h->fixed, h->bal_p.p, h->Hppinv[0].p, h->y0[0].p, h->Hpp[0].p, h->bp[0].p,
-                    (double*)nullptr, (double*)nullptr);
+                    (double*)nullptr, (double*)nullptr, (const BalPcg*)(st + (kk & 1)));
         }
         {
           Scope sc(h, BA_K_SCHUR_CAM);
           BA_LAUNCH(kc, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->offk.p,
-                    h->c_pt.p, h->c_uv.p, fs, Nc, h->cam_band, h->fixed, h->bal_part9.p);
+                    h->c_pt.p, h->c_uv.p, fs, Nc, h->cam_band, h->fixed, h->bal_part9.p, (const BalPcg*)(st + (kk & 1)));
         }
-        seq = ++h->bal_seq;
-        {
-          Scope sc(h, BA_K_PCG_UPDATE);
-          BA_LAUNCH(k_bal_pcg_step, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->bal_Hd.p, h->bal_Minv.p, h->bal_part9.p, Nc, h->fixed,
-                    tol2, opts->pcg_min_iters, h->bal_x.p, h->bal_r.p, h->bal_z.p, h->bal_p.p, h->bal_q.p, (BalPcg*)h->bal_st.p, dflag, seq);
-        }
-        if (int rc = wait_flag(h, 6, seq)) return rc;
-        const long long verdict = h->h_flags[7];         // 1 = go on, 2 = converged or broke down
-        if (verdict == 2) {
-          BalPcg stv;
-          HIPCHECK(hipMemcpy(&stv, h->bal_st.p, sizeof stv, hipMemcpyDeviceToHost));
-          k = stv.iters;
-          break;
-        }
+        Scope sc(h, BA_K_PCG_UPDATE);
+        BA_LAUNCH(k_bal_pcg_a, dim3(nwg), dim3(BAL_VEC_WG), 0, h->stream, kk, (const BalPcg*)st, h->bal_Hd.p, h->bal_part9.p, Nc, h->fixed,
+                  h->bal_p.p, h->bal_q.p, partA);
+        BA_LAUNCH(k_bal_pcg_b, dim3(nwg), dim3(BAL_VEC_WG), 0, h->stream, kk, (const BalPcg*)st, h->bal_Minv.p, partA, nwg, Nc, h->bal_p.p,
+                  h->bal_q.p, h->bal_x.p, h->bal_r.p, h->bal_z.p, partZ);
+        BA_LAUNCH(k_bal_pcg_c, dim3(nwg), dim3(BAL_VEC_WG), 0, h->stream, kk, st, partA, partZ, nwg, Nc, tol2, opts->pcg_min_iters,
+                  h->bal_z.p, h->bal_p.p, dflag, base4);
+      };
+      enqueue(0);
+      while (true) {
+        if (k + 1 < opts->pcg_max_iters) enqueue(k + 1);
+        if (int rc = wait_flag(h, 6, base4 + 4 * (long long)(k + 1))) return rc;
+        const long long word = h->h_flags[6] - base4;     // a later iteration may have published already: then this one said "go on"
+        const int verdict = (word / 4 == k + 1) ? (int)(word % 4) : 1;
+        if (verdict == 2) { ++k; break; }
+        if (verdict == 3) break;
         ++k;
+        if (k >= opts->pcg_max_iters) break;
       }
+      h->bal_seq = base4 + 4 * (long long)(enq + 2);      // past every word a queued iteration can still publish
     }
     sum->pcg_iterations += k;
     const double t2 = now_s();
@@ -1686,7 +1698,7 @@ static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba
       auto kb = robust ? k_bal_pt_schur<true, 1> : k_bal_pt_schur<false, 1>;
       BA_LAUNCH(kb, dim3(nbP), dim3(BAL_PT_THREADS), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->pt_off.p, h->p_cam.p,
                 h->p_uv.p, fs, h->Np, h->fixed, h->bal_x.p, h->Hppinv[0].p, h->y0[0].p, h->Hpp[0].p, h->bp[0].p, h->ptab[tr].p,
-                h->bal_partB.p);
+                h->bal_partB.p, (const BalPcg*)nullptr);
     }
     {
       Scope sc(h, BA_K_RESIDUAL);
@@ -1695,7 +1707,7 @@ static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba
                 h->offk.p, h->c_pt.p, h->c_uv.p, h->c_orig.p, fs, Nc, h->cam_band, (double*)nullptr, h->partR.p);
     }
     seq = ++h->bal_seq;
-    BA_LAUNCH(k_bal_step_sums, dim3(1), dim3(64), 0, h->stream, h->bal_misc.p + 4, h->bal_partB.p, nbP, h->partR.p, Nc, ds, dflag, seq);
+    BA_LAUNCH(k_bal_step_sums, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->bal_misc.p + 4, h->bal_partB.p, nbP, h->partR.p, Nc, ds, dflag, seq);
     if (int rc = wait_flag(h, 6, seq)) return rc;
     // ---- verdict, the rules of ba_solve / oracle.lm_solve
     const double gTd = hs[0] + hs[5], dDd = hs[1] + hs[6], step2 = hs[2] + hs[7], x2 = hs[3] + hs[8], dcr = hs[4];
