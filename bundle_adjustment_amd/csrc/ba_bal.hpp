@@ -303,12 +303,12 @@ __device__ inline void bal_block_sum(double (&v)[N], double* __restrict__ sm /* 
   }
 }
 
-// Linearisation -> damped blocks and their inverses (block-Jacobi preconditioner), both as full row-major 9x9 so that the
-// vector kernels read rows.  relin: fold the camera half's partition sums into HccBc first (a rejected step only
-// re-damps).  Also the cost of this linearisation (the camera half carried sum r^2 and the rho terms).
+// Linearisation -> damped camera blocks, full row-major 9x9 so that the vector kernels read rows.  relin: fold the camera
+// half's partition sums into HccBc first (a rejected step only re-damps).  Also the cost of this linearisation (the
+// camera half carried sum r^2 and the rho terms).
 __global__ void __launch_bounds__(BAL_VEC_THREADS)
 k_bal_prep(const double* __restrict__ partL, int relin, double lambda, int n_cams, int fixed_cam, double* __restrict__ HccBc,
-           double* __restrict__ Hd, double* __restrict__ Minv, double* __restrict__ out /* [0] sse, [1] rho-sum (relin only) */) {
+           double* __restrict__ Hd, double* __restrict__ out /* [0] sse, [1] rho-sum (relin only) */) {
   __shared__ double sm[(BAL_VEC_THREADS / 64) * 2];
   double cs2[2] = {0.0, 0.0};
   for (int c = threadIdx.x; c < n_cams; c += BAL_VEC_THREADS) {
@@ -330,42 +330,13 @@ k_bal_prep(const double* __restrict__ partL, int relin, double lambda, int n_cam
 #pragma unroll
       for (int q = 0; q < BH; ++q) h[q] = HccBc[(size_t)c * (BH + BC) + q];
     }
-    // damped block, its Cholesky factor and inverse (dense 9x9 in private memory; once per damping change)
-    double Lm[BC][BC], Li[BC][BC];
+    // damped block (what the operator multiplies by); the fixed camera's block is the identity
     for (int a = 0; a < BC; ++a)
-      for (int b = 0; b < BC; ++b) Lm[a][b] = h[a <= b ? U9(a, b) : U9(b, a)];
-    for (int a = 0; a < BC; ++a) Lm[a][a] += lambda * fmax(Lm[a][a], DIAG_FLOOR);
-    if (c == fixed_cam)
-      for (int a = 0; a < BC; ++a)
-        for (int b = 0; b < BC; ++b) Lm[a][b] = (a == b) ? 1.0 : 0.0;
-    for (int a = 0; a < BC; ++a)
-      for (int b = 0; b < BC; ++b) Hd[(size_t)c * BF + a * BC + b] = Lm[a][b];
-    for (int j = 0; j < BC; ++j) {                       // Cholesky, lower triangle in place
-      double d = Lm[j][j];
-      for (int k = 0; k < j; ++k) d -= Lm[j][k] * Lm[j][k];
-      d = sqrt(fmax(d, DIAG_FLOOR));
-      Lm[j][j] = d;
-      for (int i = j + 1; i < BC; ++i) {
-        double s = Lm[i][j];
-        for (int k = 0; k < j; ++k) s -= Lm[i][k] * Lm[j][k];
-        Lm[i][j] = s / d;
-      }
-    }
-    for (int j = 0; j < BC; ++j) {                       // Li = L^-1 (lower), column by column
-      for (int i = 0; i < BC; ++i) Li[i][j] = 0.0;
-      Li[j][j] = 1.0 / Lm[j][j];
-      for (int i = j + 1; i < BC; ++i) {
-        double s = 0.0;
-        for (int k = j; k < i; ++k) s -= Lm[i][k] * Li[k][j];
-        Li[i][j] = s / Lm[i][i];
-      }
-    }
-    for (int a = 0; a < BC; ++a)                         // (L L^T)^-1 = Li^T Li
-      for (int b = a; b < BC; ++b) {
-        double s = 0.0;
-        for (int k = b; k < BC; ++k) s += Li[k][a] * Li[k][b];
-        Minv[(size_t)c * BF + a * BC + b] = s;
-        Minv[(size_t)c * BF + b * BC + a] = s;
+      for (int b = 0; b < BC; ++b) {
+        double v = h[a <= b ? U9(a, b) : U9(b, a)];
+        if (a == b) v += lambda * fmax(v, DIAG_FLOOR);
+        if (c == fixed_cam) v = (a == b) ? 1.0 : 0.0;
+        Hd[(size_t)c * BF + a * BC + b] = v;
       }
   }
   if (relin) {
@@ -374,6 +345,99 @@ k_bal_prep(const double* __restrict__ partL, int relin, double lambda, int n_cam
   }
 }
 
+
+// Schur-Jacobi: partS[(k Nc + c) BH + q] = sum over partition k of W Hpp^-1 W^T (9x9, packed), W = Jc^T w Jp per observation
+template <bool ROBUST>
+__global__ void __launch_bounds__(64 * WPB)
+k_bal_cam_sdiag(const double* __restrict__ cs, const double* __restrict__ intr, const double* __restrict__ ptab,
+                const int* __restrict__ offk, const int* __restrict__ c_pt, const double2* __restrict__ c_uv, double hub_c,
+                int n_cams, int band, int fixed_cam, const double* __restrict__ Hppinv, double* __restrict__ partS) {
+  Seg s;
+  if (!cam_segment(offk, n_cams, band, s)) return;
+  const double* cam = cs + CS * s.c;
+  const double f = intr[3 * s.c], k1 = intr[3 * s.c + 1], k2 = intr[3 * s.c + 2];
+  double acc[BH];
+#pragma unroll
+  for (int q = 0; q < BH; ++q) acc[q] = 0.0;
+  if (s.c != fixed_cam) {
+    for (int i = s.beg + s.lane; i < s.end; i += 64) {
+      const int p = c_pt[i];
+      const double4 X = *(const double4*)(ptab + PT * (size_t)p);
+      const double2 uv = c_uv[i];
+      double hi[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) hi[q] = Hppinv[6 * (size_t)p + q];
+      BalObs g;
+      bal_obs(cam, f, k1, k2, X.x, X.y, X.z, uv.x, uv.y, g);
+      double w0, w1, rho;
+      bal_weights(ROBUST, g, hub_c, w0, w1, rho);
+      double J0[BC], J1[BC];
+      bal_cam_rows(cam, g, X.x, X.y, X.z, J0, J1);
+      // W = -(w0 J0 B0^T + w1 J1 B1^T); with G = B Hinv B^T-like 2x2 weights: W Hinv W^T = [J0 J1] C [J0 J1]^T,
+      // C = diag(w) (B Hinv B^T) diag(w)  (2x2, symmetric)
+      double t0[3], t1[3];
+      sym3_mul(hi, g.B, t0);
+      sym3_mul(hi, g.B + 3, t1);
+      const double c00 = w0 * w0 * (g.B[0] * t0[0] + g.B[1] * t0[1] + g.B[2] * t0[2]);
+      const double c01 = w0 * w1 * (g.B[0] * t1[0] + g.B[1] * t1[1] + g.B[2] * t1[2]);
+      const double c11 = w1 * w1 * (g.B[3] * t1[0] + g.B[4] * t1[1] + g.B[5] * t1[2]);
+#pragma unroll
+      for (int a = 0; a < BC; ++a) {
+        const double ua = c00 * J0[a] + c01 * J1[a], va = c01 * J0[a] + c11 * J1[a];
+#pragma unroll
+        for (int b = a; b < BC; ++b) acc[U9(a, b)] += ua * J0[b] + va * J1[b];
+      }
+    }
+  }
+  wave_store_sums<BH>(acc, s.lane, partS + ((size_t)s.k * n_cams + s.c) * BH);
+}
+
+// Preconditioner blocks: Minv = (Hd - sum_k partS)^-1 (Schur-Jacobi; partS == nullptr: block-Jacobi), full row-major 9x9.
+// Dense 9x9 Cholesky + inverse in private memory, once per damping change.
+__global__ void __launch_bounds__(256)
+k_bal_minv(const double* __restrict__ Hd, const double* __restrict__ partS, int n_cams, int fixed_cam, double* __restrict__ Minv) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= n_cams) return;
+  double Lm[BC][BC], Li[BC][BC];
+  for (int a = 0; a < BC; ++a)
+    for (int b = 0; b < BC; ++b) Lm[a][b] = Hd[(size_t)c * BF + a * BC + b];
+  if (partS && c != fixed_cam) {
+    for (int a = 0; a < BC; ++a)
+      for (int b = a; b < BC; ++b) {
+        double t = 0.0;
+        for (int k = 0; k < NPART; ++k) t += partS[((size_t)k * n_cams + c) * BH + U9(a, b)];
+        Lm[a][b] -= t;
+        if (b != a) Lm[b][a] -= t;
+      }
+  }
+  for (int j = 0; j < BC; ++j) {                       // Cholesky, lower triangle in place
+    double d = Lm[j][j];
+    for (int k = 0; k < j; ++k) d -= Lm[j][k] * Lm[j][k];
+    d = sqrt(fmax(d, DIAG_FLOOR));
+    Lm[j][j] = d;
+    for (int i = j + 1; i < BC; ++i) {
+      double sacc = Lm[i][j];
+      for (int k = 0; k < j; ++k) sacc -= Lm[i][k] * Lm[j][k];
+      Lm[i][j] = sacc / d;
+    }
+  }
+  for (int j = 0; j < BC; ++j) {                       // Li = L^-1 (lower), column by column
+    for (int i = 0; i < BC; ++i) Li[i][j] = 0.0;
+    Li[j][j] = 1.0 / Lm[j][j];
+    for (int i = j + 1; i < BC; ++i) {
+      double sacc = 0.0;
+      for (int k = j; k < i; ++k) sacc -= Lm[i][k] * Li[k][j];
+      Li[i][j] = sacc / Lm[i][i];
+    }
+  }
+  for (int a = 0; a < BC; ++a)                         // (L L^T)^-1 = Li^T Li
+    for (int b = a; b < BC; ++b) {
+      double sacc = 0.0;
+      for (int k = b; k < BC; ++k) sacc += Li[k][a] * Li[k][b];
+      Minv[(size_t)c * BF + a * BC + b] = sacc;
+      Minv[(size_t)c * BF + b * BC + a] = sacc;
+    }
+}
 
 // row e = 9 c + a of a block-diagonal product: sum_b M[c][a][b] v[9 c + b]
 __device__ inline double bal_row_dot(const double* __restrict__ M, const double* __restrict__ v, int e) {

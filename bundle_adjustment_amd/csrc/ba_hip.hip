@@ -1550,7 +1550,7 @@ extern "C" int ba_linearize_bal(ba_handle* h, const double* intr, int32_t loss, 
   HIPCHECK(hipMemcpyAsync(h->bal_intr[w].p, intr, 3 * (size_t)h->Nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
   bal_launch_lin(h, w, loss == BA_LOSS_HUBER, f_scale);
   BA_LAUNCH(k_bal_prep, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->bal_partL.p, 1, 0.0, h->Nc, h->fixed, h->bal_HccBc.p, h->bal_Hd.p,
-            h->bal_Minv.p, h->bal_misc.p);
+            h->bal_misc.p);
   h->linearized = false;                      // the 6-parameter linearisation buffers were overwritten (Hpp, bp)
   if (Hcc || bc) {
     std::vector<double> tmp((size_t)h->Nc * (BH + BC));
@@ -1588,6 +1588,7 @@ static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba
   h->trace.clear();
   h->linearized = false;
   const bool robust = opts->loss == BA_LOSS_HUBER;
+  const bool schur_diag = opts->preconditioner != BA_PRECOND_JACOBI;      // (two-level is a 6-parameter feature: Schur-Jacobi here)
   const double fs = opts->f_scale, tol2 = opts->pcg_tol * opts->pcg_tol;
   const int Nc = h->Nc, nbP = bal_nblk_pt(h);
   double* const hs = h->h_scal + 32;                     // host-mapped results of this path: 16 doubles
@@ -1607,9 +1608,16 @@ static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba
     {
       Scope sc(h, BA_K_PRECOND);
       BA_LAUNCH(k_bal_prep, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->bal_partL.p, need_lin ? 1 : 0, lambda, Nc, h->fixed,
-                h->bal_HccBc.p, h->bal_Hd.p, h->bal_Minv.p, h->bal_misc.p);
+                h->bal_HccBc.p, h->bal_Hd.p, h->bal_misc.p);
       BA_LAUNCH(k_point_invert, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp[0].p, h->bp[0].p, lambda, h->Np, h->Hppinv[0].p,
                 h->y0[0].p, h->ptab[cur].p);
+      if (schur_diag) {                                   // partL is free again: k_bal_prep has folded it into HccBc
+        auto ks = robust ? k_bal_cam_sdiag<true> : k_bal_cam_sdiag<false>;
+        BA_LAUNCH(ks, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->offk.p,
+                  h->c_pt.p, h->c_uv.p, fs, Nc, h->cam_band, h->fixed, h->Hppinv[0].p, h->bal_partL.p);
+      }
+      BA_LAUNCH(k_bal_minv, dim3((Nc + 255) / 256), dim3(256), 0, h->stream, h->bal_Hd.p,
+                schur_diag ? (const double*)h->bal_partL.p : (const double*)nullptr, Nc, h->fixed, h->bal_Minv.p);
     }
     {                                                   // W y0 -> right-hand side, PCG start
       Scope sc(h, BA_K_SCHUR_CAM);

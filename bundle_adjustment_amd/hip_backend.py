@@ -281,6 +281,8 @@ class Solver:
         for k, v in kw.items():
             if k == "loss":
                 v = LOSS[v] if isinstance(v, str) else v
+            if k == "preconditioner":
+                v = PRECOND[v] if isinstance(v, str) else v
             if not hasattr(o, k):
                 raise TypeError(f"unknown option {k}")
             setattr(o, k, v)

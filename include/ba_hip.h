@@ -185,8 +185,9 @@ int ba_linearize_bal(ba_handle* h, const double* intr, int32_t loss, double f_sc
                      double* bp);
 
 /* The solve step for the BAL 9-parameter camera (csrc/ba_bal.hpp): LM + Schur complement + matrix-free PCG with 9x9 camera
- * blocks and a block-Jacobi preconditioner; same damping / gain-ratio / stopping rules, options, summary and trace as
- * ba_solve (preconditioner, jacobian_precision and small_solver are ignored).  Cameras (rvec, t) and points are the
+ * blocks; preconditioner BA_PRECOND_JACOBI (damped 9x9 camera blocks) or Schur-Jacobi (their Schur complements: the
+ * default; BA_PRECOND_TWO_LEVEL means Schur-Jacobi here); same damping / gain-ratio / stopping rules, options, summary
+ * and trace as ba_solve (jacobian_precision and small_solver are ignored).  Cameras (rvec, t) and points are the
  * handle's (ba_set_params before, ba_get_params after); intr double[Nc][3] = (f, k1, k2) per camera is read AND updated.
  * fixed_cam of ba_set_problem is honoured (-1: no camera held; the damping carries the gauge).  Single rank. */
 int ba_solve_bal(ba_handle* h, double* intr, const ba_options* opts, ba_summary* sum);

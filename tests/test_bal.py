@@ -178,21 +178,22 @@ def test_device_bal_linearisation_matches_the_oracle_blocks(loss, fixed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["tiny_huber", "synthetic_linear_fixed"])
-def test_device_bal_solve_follows_the_oracle_lm(case):
-    """ba_solve_bal against oracle.lm_solve(model='bal', precond='jacobi'): every LM iteration (PCG iteration count, trial
-    cost, damping, acceptance), then the adjusted cameras (f, k1, k2 included) and points."""
+@pytest.mark.parametrize("case,precond", [("tiny_huber", "jacobi"), ("synthetic_linear_fixed", "jacobi"),
+                                          ("tiny_huber", "schur_jacobi"), ("synthetic_huber_fixed", "schur_jacobi")])
+def test_device_bal_solve_follows_the_oracle_lm(case, precond):
+    """ba_solve_bal against oracle.lm_solve(model='bal') with the same preconditioner: every LM iteration (PCG iteration
+    count, trial cost, damping, acceptance), then the adjusted cameras (f, k1, k2 included) and points."""
     from bundle_adjustment_amd import hip_backend
     if case == "tiny_huber":
         p, loss, fixed = _perturbed(read_bal(TINY), 3), "huber", -1
     else:
-        p, loss, fixed = _synthetic_bal(20, 600, 5, seed=8), "linear", 0
+        p, loss, fixed = _synthetic_bal(20, 600, 5, seed=8), case.split("_")[1], 0
     iters = 8
     ref = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, None, fixed_cam=fixed, loss=loss, max_iters=iters, ftol=0.0, xtol=0.0,
-                     gtol=0.0, pcg_tol=1e-2, pcg_max_iters=300, precond="jacobi", model="bal")
+                     gtol=0.0, pcg_tol=1e-2, pcg_max_iters=300, precond=precond, model="bal")
     with hip_backend.Solver(0) as s:
         out, cams, pts = s.solve_bal(p, fixed_cam=fixed, loss=loss, max_iters=iters, ftol=0.0, xtol=0.0, gtol=0.0, pcg_tol=1e-2,
-                                     pcg_max_iters=300, pcg_min_iters=0)
+                                     pcg_max_iters=300, pcg_min_iters=0, preconditioner=precond)
         tr = s.trace()
     assert out["iterations"] == iters == len(ref["history"])
     assert abs(out["initial_cost"] - ref["cost0"]) <= 1e-10 * ref["cost0"]
@@ -200,7 +201,9 @@ def test_device_bal_solve_follows_the_oracle_lm(case):
     for t, h in zip(tr, ref["history"]):
         if abs(h["cost"] - h["cost_new"]) <= 1e-8 * h["cost"]:
             break                      # converged: accept / reject is decided by round-off from here on, the paths may part
-        assert abs(t["pcg_iterations"] - h["pcg"]) <= 1, (t, h)
+        # (the PCG stopping test is a threshold on a residual norm: round-off moves the crossing by an iteration or so,
+        #  a few at the long solves near the end)
+        assert abs(t["pcg_iterations"] - h["pcg"]) <= max(1, 0.1 * h["pcg"]), (t, h)
         assert abs(t["cost_trial"] - h["cost_new"]) <= 1e-6 * h["cost_new"], (t, h)
         assert bool(t["accepted"]) == bool(h["rho"] > 0)
         compared += 1
