@@ -1,6 +1,8 @@
 """GPU: the library's failure codes ("failure detection"): a kernel launch the runtime refuses
 comes back as BA_ERR_HIP with the kernel's name instead of a 20 s spin; non-finite costs come back as
 BA_ERR_NUMERIC, at the initial parameters and mid-solve; a failed call leaves the handle usable."""
+import os
+
 import numpy as np
 import pytest
 
@@ -82,3 +84,30 @@ def test_rejected_set_problem_keeps_the_previous_problem():
         assert rc == -1 and b"out of range" in s._lib.ba_last_error()          # BA_ERR_INVALID
         out = s.solve(**KW)
         assert out["final_cost"] < out["initial_cost"]
+
+
+def test_bal_path_reports_its_failures_like_ba_solve():
+    """ba_solve_bal / ba_linearize_bal: call order, a NaN pixel (numeric error at the initial cost, handle still usable),
+    bad options -- the same status codes as the 6-parameter entry points."""
+    import ctypes as C
+    BA_ERR_STATE = -3                                  # include/ba_hip.h ba_status
+    from bundle_adjustment_amd.bal import read_bal, BALProblem
+    from tests.helpers import GOLDEN
+    p = read_bal(os.path.join(GOLDEN, "tiny_bal.txt"))
+    with hip_backend.Solver(0) as s:
+        intr = np.ascontiguousarray(p.cams[:, 6:9])
+        o_, sm = s.default_options(), hip_backend.BASummary()
+        dp = intr.ctypes.data_as(C.POINTER(C.c_double))
+        assert s._lib.ba_solve_bal(s._h, dp, C.byref(o_), C.byref(sm)) == BA_ERR_STATE      # nothing uploaded yet
+        assert s._lib.ba_linearize_bal(s._h, dp, 0, 1.0, None, None, None, None) == BA_ERR_STATE
+        out, _, _ = s.solve_bal(p, max_iters=3)
+        assert out["iterations"] == 3
+        with pytest.raises(hip_backend.BAHipError, match="bad options"):
+            s.solve_bal(p, pcg_max_iters=0)
+        with pytest.raises(hip_backend.BAHipError, match="unknown loss"):
+            s.solve_bal(p, loss=7)
+        uv = p.uv.copy(); uv[5, 0] = np.nan
+        with pytest.raises(hip_backend.BAHipError, match="non-finite cost at the initial parameters"):
+            s.solve_bal(BALProblem(p.cams, p.pts, p.cam_idx, p.pt_idx, uv))
+        again, _, _ = s.solve_bal(p, max_iters=3)                  # the handle survived
+        assert again["final_cost"] == out["final_cost"]
