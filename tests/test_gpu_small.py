@@ -108,6 +108,27 @@ def test_small_solver_follows_the_oracles_dense_lm_step_by_step(n_cams, n_pts, k
     assert np.abs(pts - ref["pts"]).max() <= 1e-7 * max(1.0, np.abs(ref["pts"]).max())
 
 
+def test_small_solver_rejected_steps_follow_the_oracle():
+    """A start far from the minimiser (0.2 rad, 1 m, 3 m of noise): the first four steps are rejected -- same linearisation,
+    larger damping, no re-linearisation in the kernel -- then the descent starts; acceptance, damping and trial costs
+    against the oracle's dense LM, iteration by iteration."""
+    p = make_problem(5, 200, 4, seed=5, point_sigma=3.0, rot_sigma=0.2, trans_sigma=1.0)
+    iters = 10
+    ref = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, fixed_cam=0, loss="huber", max_iters=iters, ftol=0.0, xtol=0.0,
+                     gtol=0.0, lam0=1e-6, linear_solver="dense")
+    assert [h["rho"] > 0 for h in ref["history"]][:5] == [False, False, False, False, True]
+    with hip_backend.Solver(0) as s:
+        s.set_problem(p)
+        out = s.solve(loss="huber", max_iters=iters, ftol=0.0, xtol=0.0, gtol=0.0, initial_lambda=1e-6)
+        tr = s.trace()
+    assert out["pcg_iterations"] == 0 and out["iterations"] == iters
+    for t, h in zip(tr, ref["history"]):
+        assert bool(t["accepted"]) == bool(h["rho"] > 0)
+        assert abs(t["damping"] - h["lam"]) <= 1e-6 * h["lam"]
+        assert abs(t["cost_trial"] - h["cost_new"]) <= 1e-6 * h["cost_new"], (t, h)
+    assert abs(out["final_cost"] - ref["cost"]) <= 1e-6 * ref["cost"]
+
+
 def test_small_solver_with_only_the_fixed_camera():
     """One keyframe, fixed: nothing but points move, each onto the ray of its single observation (cost -> 0)."""
     p = make_problem(1, 40, 1, seed=18)
