@@ -151,13 +151,15 @@ def main():
         print(f"chunk done: status {res.status} nfev {total} scipy cost {res.cost:.12f} "
               f"reference-evaluated cost {cost:.12f} sse {sse:.9f} rmse {rmse:.9f} optimality {res.optimality:.3e} "
               f"({time.time() - t_start:.0f} s)", flush=True)
-        np.savez_compressed(os.path.join(HERE, name), config=np.array(args.config), seed=args.seed, loss=np.array(args.loss),
+        tmp = os.path.join(HERE, name + ".part.npz")     # written beside the fixture, then moved over it: readers never see half a file
+        np.savez_compressed(tmp, config=np.array(args.config), seed=args.seed, loss=np.array(args.loss),
                             fun=np.array(args.fun), n_cams=p.n_cams, n_pts=p.n_pts, n_obs=p.n_obs,
                             problem_sha256=np.array(problem_checksum(p)), sse0=float(f0_ref @ f0_ref),
                             res_cost=cost, res_cost_scipy=float(res.cost), res_sse=sse, res_rmse=rmse,
                             res_optimality=float(res.optimality), res_nfev=total, res_status=int(res.status),
                             jac_fd_max_abs_diff=fd_err, lsmr_tol=args.lsmr_tol, warm_start=bool(args.warm_start),
                             rmse_history=np.array(history, dtype=np.float64))
+        os.replace(tmp, os.path.join(HERE, name if name.endswith(".npz") else name + ".npz"))
         if res.status in (1, 2, 3, 4):               # gtol / ftol / xtol: scipy itself says converged
             break
         if len(history) >= 3 and abs(history[-1][1] - history[-2][1]) < args.stall and abs(history[-2][1] - history[-3][1]) < args.stall:
