@@ -1465,6 +1465,7 @@ static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   A.cur_out = (int*)(h->d_small_host + off_cur);
   A.trace = (ba_iter_record*)(h->d_small_host + off_trace);
   A.host_flag = h->d_flags + 4;
+  h->profile = opts->profile != 0;
   A.stamps = getenv("BA_SMALL_STAMPS") ? (long long*)(h->small_gS.p + (size_t)SMALL_WAVES * SMALL_TILES * 256) : nullptr;   // device memory: a host store would stall the wave
   A.seq = ++h->small_seq;
   {
@@ -1475,6 +1476,8 @@ static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   // memory by then, and whatever the caller queues next on the stream is ordered behind the kernel as usual
   if (int rc = wait_flag(h, 4, A.seq)) return rc;
   memcpy(sum, h->h_small, sizeof(ba_summary));
+  if (h->profile) flush_profile(h);
+  h->profile = false;
   if (sum->status == BA_ERR_NUMERIC)
     return fail(BA_ERR_NUMERIC, sum->iterations == 0 ? "non-finite cost at the initial parameters"
                                                      : "non-finite cost / gradient during the solve (LM iteration %d)", sum->iterations);
