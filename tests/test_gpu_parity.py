@@ -57,8 +57,10 @@ def test_residuals_match_oracle_synthetic(solver, cfg, seed):
     assert abs(cost - o.robust_cost(ref, "huber")) <= 1e-11 * cost
 
 
-def test_empty_and_ragged_inputs(solver):
-    """A camera without observations, a point seen once, zero observations overall."""
+@pytest.mark.parametrize("small_solver", [0, 1], ids=["single_launch", "multi_kernel"])
+def test_empty_and_ragged_inputs(solver, small_solver):
+    """A camera without observations, a point seen once, zero observations overall -- through both implementations behind
+    ba_solve (a window this small is dispatched to the single-launch solver unless small_solver = 1)."""
     p = make_problem(5, 40, 3, seed=3)
     keep = p.cam_idx != 2                       # camera 2 loses every observation
     keep[np.nonzero(p.pt_idx == 7)[0][1:]] = False   # point 7 keeps a single view
@@ -69,7 +71,8 @@ def test_empty_and_ragged_inputs(solver):
     assert np.abs(r - ref).max() <= 1e-9
     Hcc, bc, Hpp, bp = solver.linearize()
     assert np.all(Hcc[2] == 0) and np.all(bc[2] == 0)
-    out = solver.solve(loss="linear", max_iters=10)
+    out = solver.solve(loss="linear", max_iters=10, small_solver=small_solver)
+    assert (out["pcg_iterations"] > 0) == bool(small_solver)
     assert np.isfinite(out["final_cost"]) and out["final_cost"] <= out["initial_cost"]
     e = type(p)(p.cams, p.pts, p.cam_idx[:0], p.pt_idx[:0], p.uv[:0], p.K4, 0)
     solver.set_problem(e)
@@ -154,14 +157,17 @@ def test_schur_rhs_and_apply_match_dense(solver, loss):
 
 
 # ---------------------------------------------------------------- K2-K7 solve
+@pytest.mark.parametrize("small_solver", [0, 1], ids=["single_launch", "multi_kernel"])
 @pytest.mark.parametrize("name,loss", [("conv_linear", "linear"), ("conv_huber", "huber")])
-def test_converged_rmse_matches_scipy_path(solver, name, loss):
+def test_converged_rmse_matches_scipy_path(solver, name, loss, small_solver):
     """North-star bar: final reprojection RMSE within 1e-6 px of the reference's
     scipy.optimize.least_squares path driven to convergence on the same inputs."""
     g = load_golden(name)
     p = golden_flat_problem(g)
     solver.set_problem(p)
-    out = solver.solve(loss=loss, max_iters=300, ftol=1e-15, xtol=1e-15, gtol=0.0, pcg_tol=1e-3, pcg_max_iters=300)
+    out = solver.solve(loss=loss, max_iters=300, ftol=1e-15, xtol=1e-15, gtol=0.0, pcg_tol=1e-3, pcg_max_iters=300,
+                       small_solver=small_solver)
+    assert (out["pcg_iterations"] > 0) == bool(small_solver)
     rmse = np.sqrt(out["final_sse"] / p.n_obs)
     rmse_ref = np.sqrt(float((g["res_fun"] ** 2).sum()) / p.n_obs)
     assert abs(rmse - rmse_ref) <= 1e-6
@@ -197,10 +203,11 @@ def test_reference_default_settings_never_worse_than_reference(solver):
         local = sorted(gmap.keyframes)[-(w + 1):-1]
         mp_ids, obs, kp = gather_window(gmap, local)
         p = flatten_window(gmap, local, mp_ids, obs, kp, g["K"])
-        solver.set_problem(p)
-        out = solver.solve()
         ref_sse = float((g["res_fun"] ** 2).sum())
-        assert out["final_sse"] <= ref_sse * (1 + 1e-9)
+        for small_solver in (0, 1):                      # both implementations behind ba_solve
+            solver.set_problem(p)
+            out = solver.solve(small_solver=small_solver)
+            assert out["final_sse"] <= ref_sse * (1 + 1e-9)
 
 
 def test_c2_solve_and_properties(solver):

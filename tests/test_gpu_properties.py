@@ -87,12 +87,14 @@ def test_solve_handles_single_view_points_and_is_gauge_consistent(solver, seed):
         idx = np.nonzero(p.pt_idx == j)[0]
         keep[idx[1:]] = False
     q = BAProblem(p.cams, p.pts, p.cam_idx[keep], p.pt_idx[keep], p.uv[keep], p.K4, 0)
-    solver.set_problem(q)
-    out = solver.solve(loss="huber", max_iters=30, ftol=1e-12, xtol=1e-12, gtol=0.0, pcg_tol=1e-3)
-    assert np.isfinite(out["final_cost"]) and out["final_cost"] <= out["initial_cost"]
-    cams, pts = solver.get_params()
-    assert np.all(np.isfinite(cams)) and np.all(np.isfinite(pts))
-    np.testing.assert_array_equal(cams[0], q.cams[0])          # the fixed camera never moves
     ref = o.lm_solve(q.cams, q.pts, q.cam_idx, q.pt_idx, q.uv, q.K4, 0, "huber", max_iters=30, ftol=1e-12,
                      xtol=1e-12, gtol=0.0, pcg_tol=1e-3)
-    assert abs(out["final_cost"] - ref["cost"]) <= 1e-7 * max(1.0, ref["cost"])
+    for small_solver in (1, 0):                                # the multi-kernel loop, then the single-launch window solver
+        solver.set_problem(q)
+        out = solver.solve(loss="huber", max_iters=30, ftol=1e-12, xtol=1e-12, gtol=0.0, pcg_tol=1e-3, small_solver=small_solver)
+        assert (out["pcg_iterations"] > 0) == bool(small_solver)
+        assert np.isfinite(out["final_cost"]) and out["final_cost"] <= out["initial_cost"]
+        cams, pts = solver.get_params()
+        assert np.all(np.isfinite(cams)) and np.all(np.isfinite(pts))
+        np.testing.assert_array_equal(cams[0], q.cams[0])          # the fixed camera never moves
+        assert abs(out["final_cost"] - ref["cost"]) <= 1e-7 * max(1.0, ref["cost"])
