@@ -155,8 +155,13 @@ def test_small_solver_is_bit_reproducible_and_honours_the_options():
         s.set_problem(p)
         loose = s.solve(loss="huber")                      # the reference's tolerances: stops on ftol
         assert loose["status_name"] in ("ftol", "xtol") and loose["final_cost"] < 0.2 * loose["initial_cost"]      # (2 % gross outliers stay in the Huber cost)
-        # nine cameras: not the direct solver's case any more
+        # nine cameras, or more than 6144 observations (the measured crossover, tools/small_crossover.py): not the
+        # single-launch solver's case any more
         q = make_problem(9, 600, 4, seed=1)
+        s.set_problem(q)
+        assert s.solve(max_iters=5)["pcg_iterations"] > 0
+        q = make_problem(8, 1300, 5, seed=1)
+        assert q.n_obs > 6144
         s.set_problem(q)
         assert s.solve(max_iters=5)["pcg_iterations"] > 0
         # NaN pixel: the same failure code as the multi-kernel path
