@@ -307,32 +307,33 @@ __device__ inline void bal_block_sum(double (&v)[N], double* __restrict__ sm /* 
 // Linearisation -> damped camera blocks, full row-major 9x9 so that the vector kernels read rows.  relin: fold the camera
 // half's partition sums into HccBc first (a rejected step only re-damps).  Also the cost of this linearisation (the
 // camera half carried sum r^2 and the rho terms).
-__global__ void __launch_bounds__(BAL_VEC_THREADS)
+constexpr int BAL_PREP_WG = 64;     // cameras per workgroup of k_bal_prep (one wave: the 54-word fold lives in registers)
+__global__ void __launch_bounds__(BAL_PREP_WG)
 k_bal_prep(const double* __restrict__ partL, int relin, double lambda, int n_cams, int fixed_cam, double* __restrict__ HccBc,
-           double* __restrict__ Hd, double* __restrict__ out /* [0] sse, [1] rho-sum (relin only) */) {
-  __shared__ double sm[(BAL_VEC_THREADS / 64) * 2];
+           double* __restrict__ Hd, double* __restrict__ out /* [2 wg], [2 wg + 1]: this workgroup's sse, rho-sum (relin only) */) {
+  const int c = blockIdx.x * BAL_PREP_WG + threadIdx.x;
   double cs2[2] = {0.0, 0.0};
-  for (int c = threadIdx.x; c < n_cams; c += BAL_VEC_THREADS) {
+  if (c < n_cams) {
     double h[BH + BC];
     if (relin) {
-      double e[2] = {0.0, 0.0};
 #pragma unroll
       for (int q = 0; q < BH + BC; ++q) h[q] = 0.0;
       for (int k = 0; k < NPART; ++k) {
         const double* src = partL + ((size_t)k * n_cams + c) * BLIN;
 #pragma unroll
         for (int q = 0; q < BH + BC; ++q) h[q] += src[q];
-        e[0] += src[BH + BC]; e[1] += src[BH + BC + 1];
+        cs2[0] += src[BH + BC]; cs2[1] += src[BH + BC + 1];
       }
 #pragma unroll
       for (int q = 0; q < BH + BC; ++q) HccBc[(size_t)c * (BH + BC) + q] = h[q];
-      cs2[0] += e[0]; cs2[1] += e[1];
     } else {
 #pragma unroll
       for (int q = 0; q < BH; ++q) h[q] = HccBc[(size_t)c * (BH + BC) + q];
     }
     // damped block (what the operator multiplies by); the fixed camera's block is the identity
+#pragma unroll
     for (int a = 0; a < BC; ++a)
+#pragma unroll
       for (int b = 0; b < BC; ++b) {
         double v = h[a <= b ? U9(a, b) : U9(b, a)];
         if (a == b) v += lambda * fmax(v, DIAG_FLOOR);
@@ -340,12 +341,11 @@ k_bal_prep(const double* __restrict__ partL, int relin, double lambda, int n_cam
         Hd[(size_t)c * BF + a * BC + b] = v;
       }
   }
-  if (relin) {
-    bal_block_sum<2>(cs2, sm);
-    if (threadIdx.x == 0) { out[0] = cs2[0]; out[1] = cs2[1]; }
+  if (relin) {                                      // per-workgroup partial of the cost; the host adds the few of them in order
+    cs2[0] = wave_total_dpp(cs2[0]); cs2[1] = wave_total_dpp(cs2[1]);
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = cs2[0]; out[2 * blockIdx.x + 1] = cs2[1]; }
   }
 }
-
 
 // Schur-Jacobi: partS[(k Nc + c) BH + q] = sum over partition k of W Hpp^-1 W^T (9x9, packed), W = Jc^T w Jp per observation
 template <bool ROBUST>

@@ -1516,7 +1516,7 @@ static int bal_alloc(ba_handle* h) {
   HIPCHECK(h->bal_part9.alloc((size_t)NPART * Nc * BC));
   DBuf<double>* v[] = {&h->bal_x, &h->bal_r, &h->bal_z, &h->bal_p, &h->bal_q};
   for (auto b : v) HIPCHECK(b->alloc(Nc * BC));
-  HIPCHECK(h->bal_misc.alloc(16));
+  HIPCHECK(h->bal_misc.alloc(16 + 2 * (Nc / BAL_PREP_WG + 1)));      // [0..3] spare | [4..8] camera-side step sums | [16..] cost partials of k_bal_prep
   HIPCHECK(h->bal_partB.alloc(4 * (nbP ? nbP : 1)));
   HIPCHECK(h->bal_partG.alloc(nbP ? nbP : 1));
   HIPCHECK(h->bal_st.alloc(2 * sizeof(BalPcg)));
@@ -1552,8 +1552,8 @@ extern "C" int ba_linearize_bal(ba_handle* h, const double* intr, int32_t loss, 
   const int w = h->cur;
   HIPCHECK(hipMemcpyAsync(h->bal_intr[w].p, intr, 3 * (size_t)h->Nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
   bal_launch_lin(h, w, loss == BA_LOSS_HUBER, f_scale);
-  BA_LAUNCH(k_bal_prep, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->bal_partL.p, 1, 0.0, h->Nc, h->fixed, h->bal_HccBc.p, h->bal_Hd.p,
-            h->bal_misc.p);
+  BA_LAUNCH(k_bal_prep, dim3((h->Nc + BAL_PREP_WG - 1) / BAL_PREP_WG), dim3(BAL_PREP_WG), 0, h->stream, h->bal_partL.p, 1, 0.0, h->Nc,
+            h->fixed, h->bal_HccBc.p, h->bal_Hd.p, h->bal_misc.p + 16);
   h->linearized = false;                      // the 6-parameter linearisation buffers were overwritten (Hpp, bp)
   if (Hcc || bc) {
     std::vector<double> tmp((size_t)h->Nc * (BH + BC));
@@ -1593,7 +1593,8 @@ static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba
   const bool robust = opts->loss == BA_LOSS_HUBER;
   const bool schur_diag = opts->preconditioner != BA_PRECOND_JACOBI;      // (two-level is a 6-parameter feature: Schur-Jacobi here)
   const double fs = opts->f_scale, tol2 = opts->pcg_tol * opts->pcg_tol;
-  const int Nc = h->Nc, nbP = bal_nblk_pt(h);
+  const int Nc = h->Nc, nbP = bal_nblk_pt(h), n_prep = (Nc + BAL_PREP_WG - 1) / BAL_PREP_WG;
+  std::vector<double> cost_part(2 * (size_t)n_prep);
   double* const hs = h->h_scal + 32;                     // host-mapped results of this path: 16 doubles
   double* const ds = h->d_scal_host + 32;
   long long* const dflag = h->d_flags + 6;
@@ -1610,8 +1611,8 @@ static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba
     if (need_lin) bal_launch_lin(h, cur, robust, fs);
     {
       Scope sc(h, BA_K_PRECOND);
-      BA_LAUNCH(k_bal_prep, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->bal_partL.p, need_lin ? 1 : 0, lambda, Nc, h->fixed,
-                h->bal_HccBc.p, h->bal_Hd.p, h->bal_misc.p);
+      BA_LAUNCH(k_bal_prep, dim3(n_prep), dim3(BAL_PREP_WG), 0, h->stream, h->bal_partL.p, need_lin ? 1 : 0, lambda, Nc, h->fixed,
+                h->bal_HccBc.p, h->bal_Hd.p, h->bal_misc.p + 16);
       BA_LAUNCH(k_point_invert, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp[0].p, h->bp[0].p, lambda, h->Np, h->Hppinv[0].p,
                 h->y0[0].p, h->ptab[cur].p);
       if (schur_diag) {                                   // partL is free again: k_bal_prep has folded it into HccBc
@@ -1629,9 +1630,8 @@ static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba
                 h->c_pt.p, h->c_uv.p, fs, Nc, h->cam_band, h->fixed, h->bal_part9.p, (const BalPcg*)nullptr);
     }
     long long seq = ++h->bal_seq;
-    if (it == 0 && need_lin) {                          // initial cost rides along: the camera half summed r^2 and the rho terms
-      HIPCHECK(hipMemcpyAsync(hs + 12, h->bal_misc.p, 2 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    }
+    if (it == 0 && need_lin)                            // initial cost rides along: the camera half summed r^2 and the rho terms
+      HIPCHECK(hipMemcpyAsync(cost_part.data(), h->bal_misc.p + 16, cost_part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     {
       Scope sc(h, BA_K_PCG_UPDATE);
       BA_LAUNCH(k_bal_pcg_init, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->bal_HccBc.p, h->bal_part9.p, h->bal_Minv.p, h->bal_partG.p,
@@ -1639,8 +1639,10 @@ static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba
     }
     if (int rc = wait_flag(h, 6, seq)) return rc;
     if (it == 0) {
-      BA_SYNC(h);                                       // the two words of the initial cost (a copy, not a mapped store)
-      sse = hs[12]; cost = 0.5 * hs[13];
+      BA_SYNC(h);                                       // the cost partials (a copy, not a mapped store)
+      double s0 = 0.0, s1 = 0.0;
+      for (int w = 0; w < n_prep; ++w) { s0 += cost_part[2 * w]; s1 += cost_part[2 * w + 1]; }
+      sse = s0; cost = 0.5 * s1;
       sum->initial_sse = sse; sum->initial_cost = cost;
       if (!std::isfinite(cost)) return fail(BA_ERR_NUMERIC, "non-finite cost at the initial parameters");
       if (opts->max_iters == 0) break;
