@@ -199,12 +199,13 @@ k_bal_pt_schur(const double* __restrict__ cs, const double* __restrict__ intr, d
       bal_obs(cam, intr[3 * c], intr[3 * c + 1], intr[3 * c + 2], X.x, X.y, X.z, uv.x, uv.y, g);
       double w0, w1, rho;
       bal_weights(ROBUST, g, hub_c, w0, w1, rho);
-      double J0[BC], J1[BC];
-      bal_cam_rows(cam, g, X.x, X.y, X.z, J0, J1);
+      // Jc v without forming Jc: (B_row x X) . (M v_r) - A_row . v_t - (rad v_f + f n2 v_k1 + f n2^2 v_k2) p_row; vec = vt
       const double* v = vec + BC * (size_t)c;
-      double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-      for (int q = 0; q < BC; ++q) { s0 += J0[q] * v[q]; s1 += J1[q] * v[q]; }
+      const double a0 = g.B[1] * X.z - g.B[2] * X.y, a1 = g.B[2] * X.x - g.B[0] * X.z, a2 = g.B[0] * X.y - g.B[1] * X.x;
+      const double b0 = g.B[4] * X.z - g.B[5] * X.y, b1 = g.B[5] * X.x - g.B[3] * X.z, b2 = g.B[3] * X.y - g.B[4] * X.x;
+      const double ki = g.rad * v[6] + g.f * g.n2 * (v[7] + g.n2 * v[8]);
+      double s0 = a0 * v[0] + a1 * v[1] + a2 * v[2] - (g.A[0] * v[3] + g.A[1] * v[4] + g.A[2] * v[5]) - ki * g.p0;
+      double s1 = b0 * v[0] + b1 * v[1] + b2 * v[2] - (g.A[3] * v[3] + g.A[4] * v[4] + g.A[5] * v[5]) - ki * g.p1;
       s0 *= w0; s1 *= w1;
       u[0] -= g.B[0] * s0 + g.B[3] * s1;                      // Jp^T (.), Jp = -B
       u[1] -= g.B[1] * s0 + g.B[4] * s1;
@@ -451,12 +452,25 @@ __device__ inline double bal_row_dot(const double* __restrict__ M, const double*
   return s;
 }
 
+// The point passes multiply Jc by a camera vector v through its rotation part as (B_row x X) . (M v_r): M v_r is computed
+// HERE, once per camera and vector, instead of once per observation -- entry e = 9 c + a of vt = (M v_r | v_t | v_f v_k1 v_k2).
+// cs: camera states (M at [12..20], row-major); v complete for camera c (same workgroup, barrier before the call).
+// (Packing pose, intrinsics and vt into one record per camera for the point passes was measured: no gain at a 208-byte
+// stride, 13 % slower at 256 bytes -- the dense small arrays cache better.)
+__device__ inline double bal_vt_entry(const double* __restrict__ cs, const double* __restrict__ v, int e) {
+  const int c = e / BC, a = e % BC;
+  if (a >= 3) return v[e];
+  const double* M = cs + CS * (size_t)c + 12 + 3 * a;
+  const double* vc = v + (size_t)c * BC;
+  return M[0] * vc[0] + M[1] * vc[1] + M[2] * vc[2];
+}
+
 // g = -(bc - W y0) from the camera pass on y0; r = g, z = Minv r, p = z, x = 0; rz0; max |gradient|.  Thread = vector entry.
 __global__ void __launch_bounds__(BAL_VEC_THREADS)
 k_bal_pcg_init(const double* __restrict__ HccBc, const double* __restrict__ part9, const double* __restrict__ Minv,
                const double* __restrict__ partG, int nG, int n_cams, int fixed_cam, double* __restrict__ x, double* __restrict__ r,
                double* __restrict__ z, double* __restrict__ p, BalPcg* __restrict__ st, double* __restrict__ host_out /* [0] rz0, [1] gmax */,
-               long long* __restrict__ host_flag, long long seq) {
+               long long* __restrict__ host_flag, long long seq, const double* __restrict__ cs, double* __restrict__ vt) {
   __shared__ double sm[(BAL_VEC_THREADS / 64) * 1];
   __shared__ double smax[BAL_VEC_THREADS / 64];
   const int n = n_cams * BC;
@@ -478,7 +492,8 @@ k_bal_pcg_init(const double* __restrict__ HccBc, const double* __restrict__ part
     z[e] = ze; p[e] = ze;
     acc[0] += r[e] * ze;
   }
-  bal_block_sum<1>(acc, sm);
+  bal_block_sum<1>(acc, sm);                             // (its barriers also complete p for the loop below)
+  for (int e = threadIdx.x; e < n; e += BAL_VEC_THREADS) vt[e] = bal_vt_entry(cs, p, e);
   gm = wave_nanmax(gm);
   if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = gm;
   __syncthreads();
@@ -568,7 +583,7 @@ k_bal_pcg_b(int k, const BalPcg* __restrict__ st, const double* __restrict__ Min
 __global__ void __launch_bounds__(BAL_VEC_WG)
 k_bal_pcg_c(int k, BalPcg* __restrict__ st, const double* __restrict__ partA, const double* __restrict__ partZ, int n_wg, int n_cams,
             double tol2, int min_iters, const double* __restrict__ z, double* __restrict__ p, long long* __restrict__ host_flag,
-            long long flag_base) {
+            long long flag_base, const double* __restrict__ cs, double* __restrict__ vt) {
   const BalPcg s = st[k & 1];
   if (s.done) return;
   const double pq = bal_sum_partials(partA, n_wg);
@@ -585,7 +600,10 @@ k_bal_pcg_c(int k, BalPcg* __restrict__ st, const double* __restrict__ partA, co
       const double beta = rz_new / s.rz;
       const int n = n_cams * BC;
       const int e = blockIdx.x * (BAL_CAMS_PER_WG * BC) + threadIdx.x;
-      if (threadIdx.x < BAL_CAMS_PER_WG * BC && e < n) p[e] = z[e] + beta * p[e];
+      const bool live = threadIdx.x < BAL_CAMS_PER_WG * BC && e < n;
+      if (live) p[e] = z[e] + beta * p[e];
+      __syncthreads();                                   // the camera's nine p entries, all written by this workgroup
+      if (live) vt[e] = bal_vt_entry(cs, p, e);
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -599,8 +617,11 @@ k_bal_pcg_c(int k, BalPcg* __restrict__ st, const double* __restrict__ partA, co
 __global__ void __launch_bounds__(BAL_VEC_THREADS)
 k_bal_update(const double* __restrict__ cams, const double* __restrict__ intr, const double* __restrict__ x,
              const double* __restrict__ r, const double* __restrict__ HccBc, int n_cams, int fixed_cam,
-             double* __restrict__ cams_t, double* __restrict__ intr_t, double* __restrict__ cs_t, double* __restrict__ out) {
+             double* __restrict__ cams_t, double* __restrict__ intr_t, double* __restrict__ cs_t, double* __restrict__ out,
+             const double* __restrict__ cs_cur, double* __restrict__ vt) {
   __shared__ double sm[(BAL_VEC_THREADS / 64) * 5];
+  for (int e = threadIdx.x; e < n_cams * BC; e += BAL_VEC_THREADS)      // the step in the point passes' form (back substitution)
+    vt[e] = (e / BC == fixed_cam) ? 0.0 : bal_vt_entry(cs_cur, x, e);
   double acc[5] = {0, 0, 0, 0, 0};
   for (int c = threadIdx.x; c < n_cams; c += BAL_VEC_THREADS) {
     const double* h = HccBc + (size_t)c * (BH + BC);

@@ -176,7 +176,7 @@ struct ba_handle {
   size_t h_small_bytes = 0;
   long long small_seq = 0;     // sequence number of h_flags[4], which k_small_lm publishes when its results are written
   // BAL 9-parameter path (ba_solve_bal, csrc/ba_bal.hpp)
-  DBuf<double> bal_intr[2], bal_partL, bal_HccBc, bal_Hd, bal_Minv, bal_part9, bal_x, bal_r, bal_z, bal_p, bal_q, bal_misc, bal_partB, bal_partG, bal_partA;
+  DBuf<double> bal_intr[2], bal_partL, bal_HccBc, bal_Hd, bal_Minv, bal_part9, bal_x, bal_r, bal_z, bal_p, bal_q, bal_misc, bal_partB, bal_partG, bal_partA, bal_vt;
   DBuf<char> bal_st;
   long long bal_seq = 0;       // sequence number of h_flags[6]
   DBuf<double> small_V, small_gS;   // k_small_lm: V = W L (49 x 3 Np_pad, zero where unwritten), per-wave partial V V^T
@@ -344,7 +344,7 @@ extern "C" int ba_destroy(ba_handle* h) {
   h->tri.release();
   h->small_V.release();
   { DBuf<double>* bb[] = {&h->bal_intr[0], &h->bal_intr[1], &h->bal_partL, &h->bal_HccBc, &h->bal_Hd, &h->bal_Minv, &h->bal_part9, &h->bal_x,
-                          &h->bal_r, &h->bal_z, &h->bal_p, &h->bal_q, &h->bal_misc, &h->bal_partB, &h->bal_partG, &h->bal_partA};
+                          &h->bal_r, &h->bal_z, &h->bal_p, &h->bal_q, &h->bal_misc, &h->bal_partB, &h->bal_partG, &h->bal_partA, &h->bal_vt};
     for (auto b : bb) b->release(); }
   h->bal_st.release();
   h->small_gS.release();
@@ -1514,7 +1514,7 @@ static int bal_alloc(ba_handle* h) {
   HIPCHECK(h->bal_Hd.alloc(Nc * BF));
   HIPCHECK(h->bal_Minv.alloc(Nc * BF));
   HIPCHECK(h->bal_part9.alloc((size_t)NPART * Nc * BC));
-  DBuf<double>* v[] = {&h->bal_x, &h->bal_r, &h->bal_z, &h->bal_p, &h->bal_q};
+  DBuf<double>* v[] = {&h->bal_x, &h->bal_r, &h->bal_z, &h->bal_p, &h->bal_q, &h->bal_vt};
   for (auto b : v) HIPCHECK(b->alloc(Nc * BC));
   HIPCHECK(h->bal_misc.alloc(16 + 2 * (Nc / BAL_PREP_WG + 1)));      // [0..3] spare | [4..8] camera-side step sums | [16..] cost partials of k_bal_prep
   HIPCHECK(h->bal_partB.alloc(4 * (nbP ? nbP : 1)));
@@ -1635,7 +1635,8 @@ static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba
     {
       Scope sc(h, BA_K_PCG_UPDATE);
       BA_LAUNCH(k_bal_pcg_init, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->bal_HccBc.p, h->bal_part9.p, h->bal_Minv.p, h->bal_partG.p,
-                nbP, Nc, h->fixed, h->bal_x.p, h->bal_r.p, h->bal_z.p, h->bal_p.p, (BalPcg*)h->bal_st.p, ds, dflag, seq);
+                nbP, Nc, h->fixed, h->bal_x.p, h->bal_r.p, h->bal_z.p, h->bal_p.p, (BalPcg*)h->bal_st.p, ds, dflag, seq,
+                (const double*)h->cs[cur].p, h->bal_vt.p);
     }
     if (int rc = wait_flag(h, 6, seq)) return rc;
     if (it == 0) {
@@ -1668,7 +1669,7 @@ static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba
         {
           Scope sc(h, BA_K_SCHUR_PT);
           BA_LAUNCH(kp, dim3(nbP), dim3(BAL_PT_THREADS), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->pt_off.p,
-                    h->p_cam.p, h->p_uv.p, fs, h->Np, h->fixed, h->bal_p.p, h->Hppinv[0].p, h->y0[0].p, h->Hpp[0].p, h->bp[0].p,
+                    h->p_cam.p, h->p_uv.p, fs, h->Np, h->fixed, h->bal_vt.p, h->Hppinv[0].p, h->y0[0].p, h->Hpp[0].p, h->bp[0].p,
                     (double*)nullptr, (double*)nullptr, (const BalPcg*)(st + (kk & 1)));
         }
         {
@@ -1682,7 +1683,7 @@ static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba
         BA_LAUNCH(k_bal_pcg_b, dim3(nwg), dim3(BAL_VEC_WG), 0, h->stream, kk, (const BalPcg*)st, h->bal_Minv.p, partA, nwg, Nc, h->bal_p.p,
                   h->bal_q.p, h->bal_x.p, h->bal_r.p, h->bal_z.p, partZ);
         BA_LAUNCH(k_bal_pcg_c, dim3(nwg), dim3(BAL_VEC_WG), 0, h->stream, kk, st, partA, partZ, nwg, Nc, tol2, opts->pcg_min_iters,
-                  h->bal_z.p, h->bal_p.p, dflag, base4);
+                  h->bal_z.p, h->bal_p.p, dflag, base4, (const double*)h->cs[cur].p, h->bal_vt.p);
       };
       enqueue(0);
       while (true) {
@@ -1704,13 +1705,14 @@ static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba
     {
       Scope sc(h, BA_K_MISC);
       BA_LAUNCH(k_bal_update, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->cams[cur].p, h->bal_intr[cur].p, h->bal_x.p, h->bal_r.p,
-                h->bal_HccBc.p, Nc, h->fixed, h->cams[tr].p, h->bal_intr[tr].p, h->cs[tr].p, h->bal_misc.p + 4);
+                h->bal_HccBc.p, Nc, h->fixed, h->cams[tr].p, h->bal_intr[tr].p, h->cs[tr].p, h->bal_misc.p + 4,
+                (const double*)h->cs[cur].p, h->bal_vt.p);
     }
     {
       Scope sc(h, BA_K_BACKSUB);
       auto kb = robust ? k_bal_pt_schur<true, 1> : k_bal_pt_schur<false, 1>;
       BA_LAUNCH(kb, dim3(nbP), dim3(BAL_PT_THREADS), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->pt_off.p, h->p_cam.p,
-                h->p_uv.p, fs, h->Np, h->fixed, h->bal_x.p, h->Hppinv[0].p, h->y0[0].p, h->Hpp[0].p, h->bp[0].p, h->ptab[tr].p,
+                h->p_uv.p, fs, h->Np, h->fixed, h->bal_vt.p, h->Hppinv[0].p, h->y0[0].p, h->Hpp[0].p, h->bp[0].p, h->ptab[tr].p,
                 h->bal_partB.p, (const BalPcg*)nullptr);
     }
     {
