@@ -30,7 +30,7 @@ constexpr int BF = BC * BC;           // a full 9x9 block, row-major (the vector
 __host__ __device__ constexpr int U9(int a, int b) { return a * 9 - a * (a - 1) / 2 + (b - a); }   // a <= b
 
 struct BalPcg {            // device-resident PCG state; iteration k reads st[k & 1] and leaves st[(k + 1) & 1]
-  double rz, rz0;
+  double gamma_prev, alpha_prev, gamma0;
   int iters, done;
 };
 constexpr int BAL_CAMS_PER_WG = 28;                         // camera-vector kernels: whole cameras per workgroup,
@@ -173,7 +173,7 @@ k_bal_lin_pt(const double* __restrict__ cs, const double* __restrict__ intr, con
 }
 
 // ---- point pass of the Schur product (BAL_LANES lanes per point).  u = sum_o Jp^T w (Jc v_c);
-//   MODE 0 (PCG): y = Hppinv u into the point record's y slot.
+//   MODE 0 (PCG): y = Hppinv u into the point record's y slot; partB[4 block] = sum u . y.
 //   MODE 1 (back substitution, v = dc): dp = -(y0 + Hppinv u), trial point, partB[block][4] = bp.dp, sum Dp dp^2, |dp|^2, |X|^2
 template <bool ROBUST, int MODE>
 __global__ void __launch_bounds__(BAL_PT_THREADS)
@@ -222,6 +222,7 @@ k_bal_pt_schur(const double* __restrict__ cs, const double* __restrict__ intr, d
     if (MODE == 0) {
       double* o = ptab + PT * (size_t)p + 4;
       o[0] = yy[0]; o[1] = yy[1]; o[2] = yy[2];
+      acc[0] = u[0] * yy[0] + u[1] * yy[1] + u[2] * yy[2];      // u . y: the point half of z . S z (summed per block below)
     } else {
       const double d0 = -(y0[3 * (size_t)p] + yy[0]), d1 = -(y0[3 * (size_t)p + 1] + yy[1]), d2 = -(y0[3 * (size_t)p + 2] + yy[2]);
       double* o = ptab_trial + PT * (size_t)p;
@@ -234,7 +235,7 @@ k_bal_pt_schur(const double* __restrict__ cs, const double* __restrict__ intr, d
       acc[3] = X.x * X.x + X.y * X.y + X.z * X.z;
     }
   }
-  if (MODE == 1) {
+  if (partB) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = wave_total_dpp(acc[q]);
     if ((threadIdx.x & 63) == 0) {
@@ -255,8 +256,19 @@ template <bool ROBUST>
 __global__ void __launch_bounds__(64 * WPB)
 k_bal_cam_schur(const double* __restrict__ cs, const double* __restrict__ intr, const double* __restrict__ ptab,
                 const int* __restrict__ offk, const int* __restrict__ c_pt, const double2* __restrict__ c_uv, double hub_c,
-                int n_cams, int band, int fixed_cam, double* __restrict__ part9, const BalPcg* __restrict__ st_k) {
+                int n_cams, int band, int fixed_cam, double* __restrict__ part9, const BalPcg* __restrict__ st_k,
+                const double* __restrict__ partB, int nB, double* __restrict__ uy_out) {
   if (st_k && st_k->done) return;                      // queued past the end of PCG
+  if (uy_out && blockIdx.x == gridDim.x - 1) {         // one extra workgroup: u . y of the point pass, blocks in a fixed order
+    __shared__ double smu[WPB];
+    double a = 0.0;
+    for (int b = threadIdx.x; b < nB; b += 64 * WPB) a += partB[4 * (size_t)b];
+    a = wave_total_dpp(a);
+    if ((threadIdx.x & 63) == 0) smu[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int w = 0; w < WPB; ++w) t += smu[w]; uy_out[0] = t; }
+    return;
+  }
   Seg s;
   if (!cam_segment(offk, n_cams, band, s)) return;
   const double* cam = cs + CS * s.c;
@@ -465,13 +477,16 @@ __device__ inline double bal_vt_entry(const double* __restrict__ cs, const doubl
   return M[0] * vc[0] + M[1] * vc[1] + M[2] * vc[2];
 }
 
-// g = -(bc - W y0) from the camera pass on y0; r = g, z = Minv r, p = z, x = 0; rz0; max |gradient|.  Thread = vector entry.
+// PCG start.  g = -(bc - W y0) from the camera pass on y0; x = 0, r = g, z = Minv r, p = s = 0; the two dot products the
+// first step needs (gamma = r . z, zeta = z . Hd z) into partV[0], partV[1] (the other workgroups' slots zero); vt = the
+// point passes' form of z; max |gradient|.  One workgroup, a thread per vector entry.
 __global__ void __launch_bounds__(BAL_VEC_THREADS)
-k_bal_pcg_init(const double* __restrict__ HccBc, const double* __restrict__ part9, const double* __restrict__ Minv,
-               const double* __restrict__ partG, int nG, int n_cams, int fixed_cam, double* __restrict__ x, double* __restrict__ r,
-               double* __restrict__ z, double* __restrict__ p, BalPcg* __restrict__ st, double* __restrict__ host_out /* [0] rz0, [1] gmax */,
+k_bal_pcg_init(const double* __restrict__ HccBc, const double* __restrict__ part9, const double* __restrict__ Hd,
+               const double* __restrict__ Minv, const double* __restrict__ partG, int nG, int n_cams, int fixed_cam,
+               double* __restrict__ x, double* __restrict__ r, double* __restrict__ z, double* __restrict__ p, double* __restrict__ sv,
+               BalPcg* __restrict__ st, double* __restrict__ partV, int n_wg, double* __restrict__ host_out /* [0] rz0, [1] gmax */,
                long long* __restrict__ host_flag, long long seq, const double* __restrict__ cs, double* __restrict__ vt) {
-  __shared__ double sm[(BAL_VEC_THREADS / 64) * 1];
+  __shared__ double sm[(BAL_VEC_THREADS / 64) * 2];
   __shared__ double smax[BAL_VEC_THREADS / 64];
   const int n = n_cams * BC;
   double gm = 0.0;
@@ -481,134 +496,110 @@ k_bal_pcg_init(const double* __restrict__ HccBc, const double* __restrict__ part
     double wy = 0.0;
     for (int k = 0; k < NPART; ++k) wy += part9[(size_t)k * n + e];
     r[e] = (c == fixed_cam) ? 0.0 : -(bca - wy);
-    x[e] = 0.0;
+    x[e] = 0.0; p[e] = 0.0; sv[e] = 0.0;
     gm = nanmax(gm, fabs(bca));
   }
   for (int b = threadIdx.x; b < nG; b += BAL_VEC_THREADS) gm = nanmax(gm, partG[b]);
   __syncthreads();                                      // r complete (this workgroup wrote all of it)
-  double acc[1] = {0.0};
+  for (int e = threadIdx.x; e < n; e += BAL_VEC_THREADS) z[e] = bal_row_dot(Minv, r, e);
+  __syncthreads();                                      // z complete
+  double acc[2] = {0.0, 0.0};
   for (int e = threadIdx.x; e < n; e += BAL_VEC_THREADS) {
-    const double ze = bal_row_dot(Minv, r, e);
-    z[e] = ze; p[e] = ze;
+    const double ze = z[e];
     acc[0] += r[e] * ze;
+    acc[1] += ze * ((e / BC == fixed_cam) ? ze : bal_row_dot(Hd, z, e));
+    vt[e] = bal_vt_entry(cs, z, e);
   }
-  bal_block_sum<1>(acc, sm);                             // (its barriers also complete p for the loop below)
-  for (int e = threadIdx.x; e < n; e += BAL_VEC_THREADS) vt[e] = bal_vt_entry(cs, p, e);
+  bal_block_sum<2>(acc, sm);
+  for (int w = threadIdx.x; w < 2 * n_wg; w += BAL_VEC_THREADS) partV[w] = w < 2 ? acc[w] : 0.0;
   gm = wave_nanmax(gm);
   if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = gm;
   __syncthreads();
   if (threadIdx.x == 0) {
     double m = 0.0;
     for (int w = 0; w < BAL_VEC_THREADS / 64; ++w) m = nanmax(m, smax[w]);
-    st[0].rz = acc[0]; st[0].rz0 = acc[0]; st[0].iters = 0; st[0].done = !(acc[0] > 0.0);
+    st[0].gamma_prev = 1.0; st[0].alpha_prev = 1.0; st[0].gamma0 = acc[0]; st[0].iters = 0; st[0].done = !(acc[0] > 0.0);
     host_out[0] = acc[0]; host_out[1] = m;
     publish_flag(host_flag, seq, 1);
   }
 }
 
-// deterministic sum of n per-workgroup partials, the same in every thread of every workgroup
-__device__ inline double bal_sum_partials(const double* __restrict__ part, int n) {
-  double a = 0.0;
-  for (int w = 0; w < n; ++w) a += part[w];
-  return a;
-}
-// workgroup sum (256 threads) of one value -> thread 0
-__device__ inline double bal_wg_sum(double v, double* __restrict__ sm /* [4] */) {
-  v = wave_total_dpp(v);
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return sm[0] + sm[1] + sm[2] + sm[3];
-}
-
-// One PCG iteration on the camera vectors (oracle.pcg) in three launches of ceil(Nc / 28) workgroups, each holding whole
-// cameras; every workgroup re-sums the previous launch's per-workgroup partials in the same order, so all agree on
-// alpha / beta / the verdict without a grid-wide barrier:
-//   a: q = S p from the two passes (Hd p - W Hpp^-1 W^T p), partA[wg] = p . q
-//   b: alpha = rz / sum partA;  x += alpha p;  r -= alpha q;  z = Minv r;  partZ[wg] = r . z
-//   c: rz' = sum partZ; verdict; p = z + (rz' / rz) p; workgroup 0 leaves the next state and tells the host
-// Iterations queued past the end of PCG (the host enqueues k + 1 before it has k's verdict) find done set and return.
+// One PCG iteration on the camera vectors in ONE launch of ceil(Nc / 28) workgroups (whole cameras per workgroup),
+// Chronopoulos-Gear form as in k_pcg_step (ba_kernels.hpp): the two passes have applied S to z (not to the direction),
+//     w = Hd z - W Hpp^-1 W^T z,   delta = z . w = zeta - u . y,   beta = gamma / gamma_prev,
+//     alpha = gamma / (delta - beta gamma / alpha_prev),   p = z + beta p,   s = w + beta s,   x += alpha p,   r -= alpha s,
+// and every scalar on the right is a sum that already exists when the kernel starts -- gamma = r . z and zeta = z . Hd z
+// as per-workgroup partials of the PREVIOUS step (partV), u . y folded by the camera pass's extra workgroup -- so every
+// workgroup re-sums them in the same order and all agree without a grid-wide barrier.  Same iterates as oracle.pcg in
+// exact arithmetic.  The head of step k is also the convergence test after k iterations (gamma <= tol^2 gamma0): the
+// update is then NOT applied and workgroup 0 tells the host.  Verdict word = flag_base + 4 (k + 1) + {1 applied, go on;
+// 2 converged after k iterations; 3 broke down (denominator <= 0), k iterations stand}.
 __global__ void __launch_bounds__(BAL_VEC_WG)
-k_bal_pcg_a(int k, const BalPcg* __restrict__ st, const double* __restrict__ Hd, const double* __restrict__ part9, int n_cams,
-            int fixed_cam, const double* __restrict__ p, double* __restrict__ q, double* __restrict__ partA) {
-  __shared__ double sm[4];
-  if (st[k & 1].done) return;
-  const int n = n_cams * BC;
-  const int e = blockIdx.x * (BAL_CAMS_PER_WG * BC) + threadIdx.x;
-  double v = 0.0;
-  if (threadIdx.x < BAL_CAMS_PER_WG * BC && e < n) {
-    const int c = e / BC;
-    double qe;
-    if (c == fixed_cam) qe = p[e];
-    else {
-      double w = 0.0;
-      for (int kk = 0; kk < NPART; ++kk) w += part9[(size_t)kk * n + e];
-      qe = bal_row_dot(Hd, p, e) - w;
+k_bal_cg_step(int k, BalPcg* __restrict__ st, const double* __restrict__ Hd, const double* __restrict__ Minv,
+              const double* __restrict__ part9, const double* __restrict__ uy_src, const double* __restrict__ partV_in, int n_wg,
+              int n_cams, int fixed_cam, double tol2, int min_iters, double* __restrict__ x, double* __restrict__ r,
+              double* __restrict__ p, double* __restrict__ sv, double* __restrict__ z, double* __restrict__ partV_out,
+              long long* __restrict__ host_flag, long long flag_base, const double* __restrict__ cs, double* __restrict__ vt) {
+  __shared__ double sm[2][4];
+  const BalPcg sin = st[k & 1];
+  if (sin.done) return;
+  double gamma = 0.0, zeta = 0.0;
+  for (int w = 0; w < n_wg; ++w) { gamma += partV_in[2 * w]; zeta += partV_in[2 * w + 1]; }
+  const double delta = zeta - uy_src[0];
+  const double beta = (k == 0) ? 0.0 : gamma / sin.gamma_prev;
+  const double denom = (k == 0) ? delta : delta - beta * gamma / sin.alpha_prev;
+  int verdict = 1;
+  if (k >= 1 && k >= min_iters && gamma <= tol2 * sin.gamma0) verdict = 2;
+  else if (!(denom > 0.0) || !isfinite(denom)) verdict = 3;
+  if (verdict != 1) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      BalPcg o = sin; o.done = 1; o.iters = k;
+      st[(k + 1) & 1] = o;
+      __hip_atomic_store(host_flag, flag_base + 4 * (long long)(k + 1) + verdict, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    q[e] = qe;
-    v = p[e] * qe;
+    return;
   }
-  const double tot = bal_wg_sum(v, sm);
-  if (threadIdx.x == 0) partA[blockIdx.x] = tot;
-}
-
-__global__ void __launch_bounds__(BAL_VEC_WG)
-k_bal_pcg_b(int k, const BalPcg* __restrict__ st, const double* __restrict__ Minv, const double* __restrict__ partA, int n_wg,
-            int n_cams, const double* __restrict__ p, const double* __restrict__ q, double* __restrict__ x, double* __restrict__ r,
-            double* __restrict__ z, double* __restrict__ partZ) {
-  __shared__ double sm[4];
-  const BalPcg s = st[k & 1];
-  if (s.done) return;
-  const double pq = bal_sum_partials(partA, n_wg);
-  if (!(pq > 0.0)) return;                               // breakdown: x, r stay (kernel c reports it)
-  const double alpha = s.rz / pq;
+  const double alpha = gamma / denom;
   const int n = n_cams * BC;
   const int e = blockIdx.x * (BAL_CAMS_PER_WG * BC) + threadIdx.x;
   const bool live = threadIdx.x < BAL_CAMS_PER_WG * BC && e < n;
   if (live) {
-    x[e] += alpha * p[e];
-    r[e] -= alpha * q[e];
+    const int c = e / BC;
+    double w;
+    if (c == fixed_cam) w = z[e];
+    else {
+      double t = 0.0;
+      for (int kk = 0; kk < NPART; ++kk) t += part9[(size_t)kk * n + e];
+      w = bal_row_dot(Hd, z, e) - t;
+    }
+    const double pe = z[e] + beta * p[e], se = w + beta * sv[e];
+    p[e] = pe; sv[e] = se;
+    x[e] += alpha * pe;
+    r[e] -= alpha * se;
   }
   __syncthreads();                                       // the camera's nine r entries, all written by this workgroup
-  double v = 0.0;
+  double zn = 0.0;
+  if (live) { zn = bal_row_dot(Minv, r, e); }
+  __syncthreads();                                       // every read of the old z above is done
+  if (live) z[e] = zn;
+  __syncthreads();                                       // the camera's nine new z entries
+  double g2 = 0.0, z2 = 0.0;
   if (live) {
-    const double ze = bal_row_dot(Minv, r, e);
-    z[e] = ze;
-    v = r[e] * ze;
+    g2 = r[e] * zn;
+    z2 = zn * ((e / BC == fixed_cam) ? zn : bal_row_dot(Hd, z, e));
+    vt[e] = bal_vt_entry(cs, z, e);
   }
-  const double tot = bal_wg_sum(v, sm);
-  if (threadIdx.x == 0) partZ[blockIdx.x] = tot;
-}
-
-// verdict word = flag_base + 4 (k + 1) + {1 go on, 2 converged after k + 1 iterations, 3 broke down in iteration k + 1 (p.Sp <= 0)}
-__global__ void __launch_bounds__(BAL_VEC_WG)
-k_bal_pcg_c(int k, BalPcg* __restrict__ st, const double* __restrict__ partA, const double* __restrict__ partZ, int n_wg, int n_cams,
-            double tol2, int min_iters, const double* __restrict__ z, double* __restrict__ p, long long* __restrict__ host_flag,
-            long long flag_base, const double* __restrict__ cs, double* __restrict__ vt) {
-  const BalPcg s = st[k & 1];
-  if (s.done) return;
-  const double pq = bal_sum_partials(partA, n_wg);
-  BalPcg nx = s;
-  int verdict;
-  if (!(pq > 0.0)) { nx.done = 1; verdict = 3; }
-  else {
-    const double rz_new = bal_sum_partials(partZ, n_wg);
-    nx.iters = s.iters + 1;
-    nx.done = (nx.iters >= min_iters && rz_new <= tol2 * s.rz0) ? 1 : 0;
-    nx.rz = rz_new;
-    verdict = nx.done ? 2 : 1;
-    if (!nx.done) {
-      const double beta = rz_new / s.rz;
-      const int n = n_cams * BC;
-      const int e = blockIdx.x * (BAL_CAMS_PER_WG * BC) + threadIdx.x;
-      const bool live = threadIdx.x < BAL_CAMS_PER_WG * BC && e < n;
-      if (live) p[e] = z[e] + beta * p[e];
-      __syncthreads();                                   // the camera's nine p entries, all written by this workgroup
-      if (live) vt[e] = bal_vt_entry(cs, p, e);
+  g2 = wave_total_dpp(g2); z2 = wave_total_dpp(z2);
+  if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = g2; sm[1][threadIdx.x >> 6] = z2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partV_out[2 * blockIdx.x] = sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3];
+    partV_out[2 * blockIdx.x + 1] = sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3];
+    if (blockIdx.x == 0) {
+      BalPcg o = sin; o.gamma_prev = gamma; o.alpha_prev = alpha; o.iters = k + 1;
+      st[(k + 1) & 1] = o;
+      __hip_atomic_store(host_flag, flag_base + 4 * (long long)(k + 1) + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    st[(k + 1) & 1] = nx;
-    __hip_atomic_store(host_flag, flag_base + 4 * (long long)(k + 1) + verdict, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

@@ -176,7 +176,7 @@ struct ba_handle {
   size_t h_small_bytes = 0;
   long long small_seq = 0;     // sequence number of h_flags[4], which k_small_lm publishes when its results are written
   // BAL 9-parameter path (ba_solve_bal, csrc/ba_bal.hpp)
-  DBuf<double> bal_intr[2], bal_partL, bal_HccBc, bal_Hd, bal_Minv, bal_part9, bal_x, bal_r, bal_z, bal_p, bal_q, bal_misc, bal_partB, bal_partG, bal_partA, bal_vt;
+  DBuf<double> bal_intr[2], bal_partL, bal_HccBc, bal_Hd, bal_Minv, bal_part9, bal_x, bal_r, bal_z, bal_p, bal_q, bal_misc, bal_partB, bal_partG, bal_partA, bal_vt, bal_s;
   DBuf<char> bal_st;
   long long bal_seq = 0;       // sequence number of h_flags[6]
   DBuf<double> small_V, small_gS;   // k_small_lm: V = W L (49 x 3 Np_pad, zero where unwritten), per-wave partial V V^T
@@ -344,7 +344,7 @@ extern "C" int ba_destroy(ba_handle* h) {
   h->tri.release();
   h->small_V.release();
   { DBuf<double>* bb[] = {&h->bal_intr[0], &h->bal_intr[1], &h->bal_partL, &h->bal_HccBc, &h->bal_Hd, &h->bal_Minv, &h->bal_part9, &h->bal_x,
-                          &h->bal_r, &h->bal_z, &h->bal_p, &h->bal_q, &h->bal_misc, &h->bal_partB, &h->bal_partG, &h->bal_partA, &h->bal_vt};
+                          &h->bal_r, &h->bal_z, &h->bal_p, &h->bal_q, &h->bal_misc, &h->bal_partB, &h->bal_partG, &h->bal_partA, &h->bal_vt, &h->bal_s};
     for (auto b : bb) b->release(); }
   h->bal_st.release();
   h->small_gS.release();
@@ -1514,13 +1514,13 @@ static int bal_alloc(ba_handle* h) {
   HIPCHECK(h->bal_Hd.alloc(Nc * BF));
   HIPCHECK(h->bal_Minv.alloc(Nc * BF));
   HIPCHECK(h->bal_part9.alloc((size_t)NPART * Nc * BC));
-  DBuf<double>* v[] = {&h->bal_x, &h->bal_r, &h->bal_z, &h->bal_p, &h->bal_q, &h->bal_vt};
+  DBuf<double>* v[] = {&h->bal_x, &h->bal_r, &h->bal_z, &h->bal_p, &h->bal_q, &h->bal_vt, &h->bal_s};
   for (auto b : v) HIPCHECK(b->alloc(Nc * BC));
   HIPCHECK(h->bal_misc.alloc(16 + 2 * (Nc / BAL_PREP_WG + 1)));      // [0..3] spare | [4..8] camera-side step sums | [16..] cost partials of k_bal_prep
   HIPCHECK(h->bal_partB.alloc(4 * (nbP ? nbP : 1)));
   HIPCHECK(h->bal_partG.alloc(nbP ? nbP : 1));
   HIPCHECK(h->bal_st.alloc(2 * sizeof(BalPcg)));
-  HIPCHECK(h->bal_partA.alloc(2 * (Nc / BAL_CAMS_PER_WG + 1)));
+  HIPCHECK(h->bal_partA.alloc(4 * (Nc / BAL_CAMS_PER_WG + 1)));      // gamma | zeta partials of the PCG step, two parities
   return BA_OK;
 }
 static int bal_nblk_pt(const ba_handle* h) { return (h->Np + BAL_PTS_PER_BLOCK - 1) / BAL_PTS_PER_BLOCK; }
@@ -1594,6 +1594,7 @@ static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba
   const bool schur_diag = opts->preconditioner != BA_PRECOND_JACOBI;      // (two-level is a 6-parameter feature: Schur-Jacobi here)
   const double fs = opts->f_scale, tol2 = opts->pcg_tol * opts->pcg_tol;
   const int Nc = h->Nc, nbP = bal_nblk_pt(h), n_prep = (Nc + BAL_PREP_WG - 1) / BAL_PREP_WG;
+  const int nwg = (Nc + BAL_CAMS_PER_WG - 1) / BAL_CAMS_PER_WG;              // workgroups of the PCG step kernel
   std::vector<double> cost_part(2 * (size_t)n_prep);
   double* const hs = h->h_scal + 32;                     // host-mapped results of this path: 16 doubles
   double* const ds = h->d_scal_host + 32;
@@ -1627,16 +1628,17 @@ static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba
       Scope sc(h, BA_K_SCHUR_CAM);
       auto kc = robust ? k_bal_cam_schur<true> : k_bal_cam_schur<false>;
       BA_LAUNCH(kc, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->offk.p,
-                h->c_pt.p, h->c_uv.p, fs, Nc, h->cam_band, h->fixed, h->bal_part9.p, (const BalPcg*)nullptr);
+                h->c_pt.p, h->c_uv.p, fs, Nc, h->cam_band, h->fixed, h->bal_part9.p, (const BalPcg*)nullptr, (const double*)nullptr, 0,
+                (double*)nullptr);
     }
     long long seq = ++h->bal_seq;
     if (it == 0 && need_lin)                            // initial cost rides along: the camera half summed r^2 and the rho terms
       HIPCHECK(hipMemcpyAsync(cost_part.data(), h->bal_misc.p + 16, cost_part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     {
       Scope sc(h, BA_K_PCG_UPDATE);
-      BA_LAUNCH(k_bal_pcg_init, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->bal_HccBc.p, h->bal_part9.p, h->bal_Minv.p, h->bal_partG.p,
-                nbP, Nc, h->fixed, h->bal_x.p, h->bal_r.p, h->bal_z.p, h->bal_p.p, (BalPcg*)h->bal_st.p, ds, dflag, seq,
-                (const double*)h->cs[cur].p, h->bal_vt.p);
+      BA_LAUNCH(k_bal_pcg_init, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->bal_HccBc.p, h->bal_part9.p, h->bal_Hd.p, h->bal_Minv.p,
+                h->bal_partG.p, nbP, Nc, h->fixed, h->bal_x.p, h->bal_r.p, h->bal_z.p, h->bal_p.p, h->bal_s.p, (BalPcg*)h->bal_st.p,
+                h->bal_partA.p, nwg, ds, dflag, seq, (const double*)h->cs[cur].p, h->bal_vt.p);
     }
     if (int rc = wait_flag(h, 6, seq)) return rc;
     if (it == 0) {
@@ -1659,40 +1661,37 @@ static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba
     if (rz0 > 0.0) {
       auto kp = robust ? k_bal_pt_schur<true, 0> : k_bal_pt_schur<false, 0>;
       auto kc = robust ? k_bal_cam_schur<true> : k_bal_cam_schur<false>;
-      const int nwg = (Nc + BAL_CAMS_PER_WG - 1) / BAL_CAMS_PER_WG;
-      double* partA = h->bal_partA.p, *partZ = h->bal_partA.p + nwg;
       BalPcg* st = (BalPcg*)h->bal_st.p;
+      double* uy = h->bal_misc.p + 9;
       const long long base4 = (h->bal_seq / 4 + 1) * 4;   // verdict words: base4 + 4 (k + 1) + verdict, above every word published so far
       int enq = -1;
-      auto enqueue = [&](int kk) {
+      auto enqueue = [&](int kk) {                        // S z_kk by the two passes, then the step that uses it
         enq = kk;
         {
           Scope sc(h, BA_K_SCHUR_PT);
           BA_LAUNCH(kp, dim3(nbP), dim3(BAL_PT_THREADS), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->pt_off.p,
                     h->p_cam.p, h->p_uv.p, fs, h->Np, h->fixed, h->bal_vt.p, h->Hppinv[0].p, h->y0[0].p, h->Hpp[0].p, h->bp[0].p,
-                    (double*)nullptr, (double*)nullptr, (const BalPcg*)(st + (kk & 1)));
+                    (double*)nullptr, h->bal_partB.p, (const BalPcg*)(st + (kk & 1)));
         }
         {
           Scope sc(h, BA_K_SCHUR_CAM);
-          BA_LAUNCH(kc, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->offk.p,
-                    h->c_pt.p, h->c_uv.p, fs, Nc, h->cam_band, h->fixed, h->bal_part9.p, (const BalPcg*)(st + (kk & 1)));
+          BA_LAUNCH(kc, dim3(cam_grid(h) + 1), dim3(64 * WPB), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->offk.p,
+                    h->c_pt.p, h->c_uv.p, fs, Nc, h->cam_band, h->fixed, h->bal_part9.p, (const BalPcg*)(st + (kk & 1)),
+                    (const double*)h->bal_partB.p, nbP, uy);
         }
         Scope sc(h, BA_K_PCG_UPDATE);
-        BA_LAUNCH(k_bal_pcg_a, dim3(nwg), dim3(BAL_VEC_WG), 0, h->stream, kk, (const BalPcg*)st, h->bal_Hd.p, h->bal_part9.p, Nc, h->fixed,
-                  h->bal_p.p, h->bal_q.p, partA);
-        BA_LAUNCH(k_bal_pcg_b, dim3(nwg), dim3(BAL_VEC_WG), 0, h->stream, kk, (const BalPcg*)st, h->bal_Minv.p, partA, nwg, Nc, h->bal_p.p,
-                  h->bal_q.p, h->bal_x.p, h->bal_r.p, h->bal_z.p, partZ);
-        BA_LAUNCH(k_bal_pcg_c, dim3(nwg), dim3(BAL_VEC_WG), 0, h->stream, kk, st, partA, partZ, nwg, Nc, tol2, opts->pcg_min_iters,
-                  h->bal_z.p, h->bal_p.p, dflag, base4, (const double*)h->cs[cur].p, h->bal_vt.p);
+        BA_LAUNCH(k_bal_cg_step, dim3(nwg), dim3(BAL_VEC_WG), 0, h->stream, kk, st, h->bal_Hd.p, h->bal_Minv.p, h->bal_part9.p,
+                  (const double*)uy, (const double*)(h->bal_partA.p + 2 * nwg * (kk & 1)), nwg, Nc, h->fixed, tol2, opts->pcg_min_iters,
+                  h->bal_x.p, h->bal_r.p, h->bal_p.p, h->bal_s.p, h->bal_z.p, h->bal_partA.p + 2 * nwg * ((kk + 1) & 1), dflag, base4,
+                  (const double*)h->cs[cur].p, h->bal_vt.p);
       };
       enqueue(0);
       while (true) {
         if (k + 1 < opts->pcg_max_iters) enqueue(k + 1);
         if (int rc = wait_flag(h, 6, base4 + 4 * (long long)(k + 1))) return rc;
-        const long long word = h->h_flags[6] - base4;     // a later iteration may have published already: then this one said "go on"
+        const long long word = h->h_flags[6] - base4;     // a later step may have published already: then this one said "go on"
         const int verdict = (word / 4 == k + 1) ? (int)(word % 4) : 1;
-        if (verdict == 2) { ++k; break; }
-        if (verdict == 3) break;
+        if (verdict != 1) break;                          // converged after k iterations / broke down: k iterations stand
         ++k;
         if (k >= opts->pcg_max_iters) break;
       }
