@@ -468,7 +468,9 @@ __device__ inline double bal_row_dot(const double* __restrict__ M, const double*
 // HERE, once per camera and vector, instead of once per observation -- entry e = 9 c + a of vt = (M v_r | v_t | v_f v_k1 v_k2).
 // cs: camera states (M at [12..20], row-major); v complete for camera c (same workgroup, barrier before the call).
 // (Packing pose, intrinsics and vt into one record per camera for the point passes was measured: no gain at a 208-byte
-// stride, 13 % slower at 256 bytes -- the dense small arrays cache better.)
+// stride, 13 % slower at 256 bytes -- the dense small arrays cache better.  So was an LDS window per 32-point workgroup
+// (min .. max camera of its observations, 208-byte rows): 79 instead of 60 us per PCG iteration on the 1723-camera chain --
+// with tracks up to 120 cameras long a 32-point window holds about as many rows as the workgroup has observations.)
 __device__ inline double bal_vt_entry(const double* __restrict__ cs, const double* __restrict__ v, int e) {
   const int c = e / BC, a = e % BC;
   if (a >= 3) return v[e];
