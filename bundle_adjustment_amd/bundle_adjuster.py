@@ -16,6 +16,9 @@ Differences, by design:
   when the ``DEBUG_DIRS['lba_steps']`` directory exists (no open3d dependency);
 * extra keyword arguments select solver options; their defaults are the reference's
   literals (``loss='huber'``, ``xtol = ftol = 1e-5``, at most 50 evaluations);
+* ``inplace_writeback=True`` (opt-in) stores optimised landmark positions into their existing arrays instead of
+  rebinding ``MapPoint.position`` as the reference does (``:239-240``): faster on 100 k landmarks, but aliases of
+  the old array then see the new values;
 * ``comm=(rank, world, unique_id)`` makes ``run`` SPMD over ``world`` processes, one GPU each
   (SURVEY.md section 8e): every rank calls ``run`` with an identical map, solves its landmark shard
   (the library all-reduces the reduced camera system), gathers all points and writes the whole map
@@ -38,7 +41,8 @@ from .rotations import matrices_to_rvecs
 class BundleAdjuster:
     def __init__(self, camera_matrix, window_size=5, *, device_id=0, loss='huber', f_scale=1.0, ftol=1e-5,
                  xtol=1e-5, gtol=1e-8, max_iters=50, pcg_tol=0.1, pcg_max_iters=200, preconditioner='schur_jacobi',
-                 jacobian='f64', comm=None, sparsity_plot_hook=None, verbose=0, reuse_window=True, metrics_path=None):
+                 jacobian='f64', comm=None, sparsity_plot_hook=None, verbose=0, reuse_window=True, metrics_path=None,
+                 inplace_writeback=False):
         self.camera_matrix = camera_matrix
         self.window_size = window_size
         self.device_id = device_id
@@ -49,6 +53,10 @@ class BundleAdjuster:
         self.sparsity_plot_hook = sparsity_plot_hook
         self.last_summary = None
         self.metrics_path = metrics_path       # JSON lines, one per run(): sizes, summary, per-iteration trace
+        # False (default): landmark positions are REBOUND to fresh (3,1) arrays, as the reference does
+        # (src/bundle_adjuster.py:239-240) -- whoever holds the previous array keeps the previous values.
+        # True: the numbers are stored into the existing arrays (no object per landmark; aliases see the update).
+        self.inplace_writeback = inplace_writeback
         self._solver = None
         # what survives between consecutive run() calls (src/pipeline.py:99 calls run after every keyframe): the
         # flattened window (problem.WindowCache) and, while its observation structure is unchanged, the problem the
@@ -148,17 +156,21 @@ class BundleAdjuster:
         for i, kf_id in enumerate(adjustable_kf_ids):
             keyframes[kf_id].R = np.array(rotations[i], dtype=np.float64).reshape(3, 3)
             keyframes[kf_id].t = tvecs[i].reshape(3, 1).copy()
-        # Points: one native call stores each row into the landmark's existing (3,1) float64 position array, in place
-        # (csrc/mapwalk.c scatter_positions; no Python object per landmark).  Landmarks whose position is anything else
-        # get, like every landmark in the reference (:239-240), a fresh (3,1) view into the result array.
+        # Points.  Default: rebind every landmark's position to a fresh (3,1) view into the result array, exactly the
+        # reference's `position = p.reshape(3, 1)` (:239-240), in one native loop (csrc/mapwalk.c rebind_positions).
+        # inplace_writeback=True: store the three numbers into the landmark's EXISTING (3,1) float64 array instead
+        # (scatter_positions; no Python object per landmark) -- anything that aliases that array then sees the update,
+        # which the reference's rebinding does not do; landmarks whose position is anything else are rebound.
         from . import _mapwalk
         ids = np.ascontiguousarray(local_map_point_ids, dtype=np.int64)
         pts = np.ascontiguousarray(pts)
+        views = pts.reshape(-1, 3, 1)
+        if not self.inplace_writeback:
+            _mapwalk.rebind_positions(map_points, ids, views)
+            return
         todo = _mapwalk.scatter_positions(map_points, ids, pts)
-        if todo:
-            views = pts.reshape(-1, 3, 1)
-            for i in todo:
-                map_points[int(ids[i])].position = views[i]
+        for i in todo:
+            map_points[int(ids[i])].position = views[i]
 
     # -- the solve step -------------------------------------------------------------------
     def run(self, gmap: Map):

@@ -586,6 +586,10 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   h->have_problem = false;
   h->have_params = false;
   h->linearized = false;
+  // the window solver keeps V = W L resident and only ever writes the columns of points that exist: a new problem on
+  // the same handle (fewer landmarks inside the same 16-column padding, or other cameras per point) must not inherit
+  // columns of the previous one -> V is cleared again before its next use
+  h->small_np_pad = -1;
   const int Nc = n_cams, Np = n_pts, No = (int)n_obs;
   // internal point numbering.  When the whole camera table fits in LDS nothing is gained by
   // moving points, so the caller's order is kept.  Otherwise points are sorted by the mean index of
@@ -1786,18 +1790,22 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     return fail(BA_ERR_INVALID, "bad options");
   if (opts->jacobian_precision != 0 && opts->jacobian_precision != 1)
     return fail(BA_ERR_INVALID, "jacobian_precision must be 0 (f64) or 1 (f32 blocks, f64 accumulation)");
-  h->jac_f32 = opts->jacobian_precision == 1;
+  if (opts->preconditioner < BA_PRECOND_JACOBI || opts->preconditioner > BA_PRECOND_TWO_LEVEL) return fail(BA_ERR_INVALID, "unknown preconditioner");
   if (set_device(h)) return BA_ERR_HIP;
   memset(sum, 0, sizeof *sum);
   h->trace.clear();
+  // window-sized problems: one launch, exact reduced solve -- no PCG, so preconditioner / jacobian_precision (validated
+  // above) have nothing to act on, and no per-solve mode of the multi-kernel path is left switched on behind it
+  h->jac_f32 = false;
+  h->two_level = false;
   if (small_applies(h, opts)) return small_solve(h, opts, sum);
-  roctx_load();
-  Range r_solve("ba_solve");
-  const bool robust = opts->loss == BA_LOSS_HUBER;
-  if (opts->preconditioner < BA_PRECOND_JACOBI || opts->preconditioner > BA_PRECOND_TWO_LEVEL) return fail(BA_ERR_INVALID, "unknown preconditioner");
   if (opts->preconditioner == BA_PRECOND_TWO_LEVEL && !h->two_level_ok)
     return fail(BA_ERR_STATE, "the two-level preconditioner needs a band-structured problem on a single rank "
                               "(ba_set_problem found none for this one)");
+  h->jac_f32 = opts->jacobian_precision == 1;
+  roctx_load();
+  Range r_solve("ba_solve");
+  const bool robust = opts->loss == BA_LOSS_HUBER;
   const bool schur_diag = opts->preconditioner != BA_PRECOND_JACOBI;
   h->two_level = opts->preconditioner == BA_PRECOND_TWO_LEVEL;
   const double fs = opts->f_scale;

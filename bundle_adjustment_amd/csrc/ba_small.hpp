@@ -10,17 +10,17 @@
 // 6x3 camera / point coupling of one observation), every term the elimination needs is a product with the one matrix
 //     V  (6 Nc rows) x (3 Np columns),  V[6c + i][k * Np_pad + p] = (W_{c,p} L_p)[i][k]   (zero where c does not see p),
 //     stored in slabs of 16 columns x 64 rows (8 KB each, row-major inside): one MFMA operand load is 2 KB contiguous:
-//     S   = blockdiag(Hcc + lam D) - V V^T                    v_mfma_f64_16x16x4_f64 tiles, K split over the 16 waves
+//     S   = blockdiag(Hcc + lam D) - V V^T                    v_mfma_f64_16x16x4_f64 tiles, K split over the 8 waves
 //     g   = -(bc - V z),  z_p = L_p^T bp_p                     (W Hpp^-1 bp; z is row 6 Nc of V, so V z is a column of V V^T)
 //     dp  = -(y0 + L_p (V^T dc)_p)                             (back substitution)
 // This is the one place in the repository where the matrix cores fit: a genuinely dense symmetric rank-k update.  The
 // fp64 MFMA rate equals the fp64 VALU rate on gfx950; what it removes is everything around the multiply (no atomics, no
 // per-pair geometry, no cross-lane reductions), and its sums have a fixed order.
 //
-//   per LM iteration (all 1024 threads, __syncthreads between phases):
-//     C1  camera-major, 16 / Nc waves per camera: Hcc (21) | bc (6) by DPP wave sums              (linearise, camera half)
+//   per LM iteration (all 512 threads, __syncthreads between phases):
+//     C1  camera-major, 8 / Nc waves per camera: Hcc (21) | bc (6) by DPP wave sums              (linearise, camera half)
 //     P1  point-major, thread = point: Hpp, bp, damped inverse -> L, y0, z; the point's columns of V
-//     G   V V^T: wave w takes the 16-column slabs w, w + 16, ...; partial tiles to global; summed in wave order
+//     G   V V^T: wave w takes the 16-column slabs w, w + 8, ...; partial tiles to global; summed in wave order
 //     S and g from the tiles; Cholesky of S and the two triangular solves in ONE wave (lane = row, no workgroup barriers)
 //     camera update (thread = camera), P2 back substitution + model terms, C3 cost at the trial point
 //     thread 0: gain ratio, accept / reject, Nielsen's damping update, ftol / xtol / gtol / max_iters (as ba_solve)

@@ -9,7 +9,8 @@
  *                         listed twice takes the LAST keypoint for every one of its rows (the
  *                         reference keys its pixel dict by the pair, :214-216).
  *   gather_positions  <-> the point packing of :161-162.
- *   scatter_positions <-> the point half of _update_map (:238-240), in place where the map allows it.
+ *   rebind_positions  <-> the point half of _update_map (:238-240) as the reference does it: a fresh array per landmark.
+ *   scatter_positions <-> the same, in place where the map allows it (opt-in: BundleAdjuster(inplace_writeback=True)).
  *   count_present     <-> the membership filter of :208, for a cached window.
  * Arrays cross as writable buffers (numpy arrays on the Python side), so no numpy headers are
  * needed.  problem.flatten_map_window is the caller and keeps a numpy implementation of the
@@ -355,10 +356,45 @@ done:
   return result;
 }
 
+/* rebind_positions(map_points, ids[int64 buffer], views) -> None
+ *   <-> the point half of BundleAdjuster._update_map exactly as the reference does it (src/bundle_adjuster.py:238-240):
+ *   map_points[ids[i]].position = views[i], a FRESH (3, 1) array object per landmark (views is the (n, 3, 1) result
+ *   array; views[i] is a view into it, like the reference's p.reshape(3, 1) into res.x).  Whoever still holds the
+ *   previous position array keeps the previous values.  The loop is native; the per-landmark view object is the price.
+ */
+static PyObject *rebind_positions(PyObject *self, PyObject *args) {
+  PyObject *map_points, *o_ids, *views;
+  if (!PyArg_ParseTuple(args, "O!OO", &PyDict_Type, &map_points, &o_ids, &views)) return NULL;
+  Py_buffer b_ids;
+  if (PyObject_GetBuffer(o_ids, &b_ids, PyBUF_C_CONTIGUOUS) < 0) return NULL;
+  PyObject *result = NULL;
+  if (b_ids.itemsize != 8) { PyErr_SetString(PyExc_ValueError, "ids must be int64"); goto done; }
+  const Py_ssize_t n = b_ids.len / 8;
+  if (PySequence_Size(views) < n) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "fewer views than ids"); goto done; }
+  const int64_t *ids = (const int64_t *)b_ids.buf;
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    PyObject *key = PyLong_FromLongLong(ids[i]);
+    if (!key) goto done;
+    PyObject *obj = PyDict_GetItemWithError(map_points, key);   /* borrowed */
+    if (!obj) { if (!PyErr_Occurred()) PyErr_SetObject(PyExc_KeyError, key); Py_DECREF(key); goto done; }
+    Py_DECREF(key);
+    PyObject *v = PySequence_GetItem(views, i);
+    if (!v) goto done;
+    const int rc = PyObject_SetAttr(obj, s_position, v);
+    Py_DECREF(v);
+    if (rc < 0) goto done;
+  }
+  result = Py_None; Py_INCREF(result);
+done:
+  PyBuffer_Release(&b_ids);
+  return result;
+}
+
 static PyMethodDef methods[] = {
   {"walk_window", walk_window, METH_VARARGS, "walk a keyframe window into flat observation arrays"},
   {"gather_positions", gather_positions, METH_VARARGS, "copy MapPoint.position of the given ids into (n,3)"},
   {"scatter_positions", scatter_positions, METH_VARARGS, "write rows of (n,3) into MapPoint.position in place where it is a (3,1) float64 array"},
+  {"rebind_positions", rebind_positions, METH_VARARGS, "map_points[ids[i]].position = views[i] (a fresh (3,1) array per landmark, as the reference)"},
   {"count_present", count_present, METH_VARARGS, "how many of the ids are keys of the map-point dict"},
   {NULL, NULL, 0, NULL}};
 

@@ -171,3 +171,36 @@ def test_small_solver_is_bit_reproducible_and_honours_the_options():
             s.solve()
         s.set_problem(p)
         assert s.solve()["final_cost"] > 0
+
+
+def test_small_solver_on_a_reused_handle_with_fewer_landmarks():
+    """One Solver kept across windows (BundleAdjuster.run's default use, src/pipeline.py:39,99): a window of 100 landmarks,
+    then one of 97 with the same number of cameras -- the same 16-column padding of V.  The second solve must not see
+    the columns the first one left for points 97..99: results bit-equal to a fresh handle, and on the oracle's dense LM."""
+    big = make_problem(5, 100, 4, seed=21, outlier_frac=0.03)
+    keep = big.pt_idx < 97
+    small = type(big)(big.cams, big.pts[:97], big.cam_idx[keep], big.pt_idx[keep], big.uv[keep], big.K4, big.fixed_cam)
+    kw = dict(loss="huber", max_iters=6, ftol=0.0, xtol=0.0, gtol=0.0)
+    with hip_backend.Solver(0) as fresh:
+        fresh.set_problem(small)
+        want = fresh.solve(**kw)
+        want_tr = fresh.trace()
+        want_cams, want_pts = fresh.get_params()
+    with hip_backend.Solver(0) as s:
+        s.set_problem(big)
+        first = s.solve(**kw)
+        assert first["pcg_iterations"] == 0 and first["final_cost"] < first["initial_cost"]
+        s.set_problem(small)
+        got = s.solve(**kw)
+        got_tr = s.trace()
+        cams, pts = s.get_params()
+    assert got["pcg_iterations"] == 0
+    assert got["final_cost"] == want["final_cost"] and got["final_sse"] == want["final_sse"]
+    assert [t["cost_trial"] for t in got_tr] == [t["cost_trial"] for t in want_tr]
+    assert np.array_equal(cams, want_cams) and np.array_equal(pts, want_pts)
+    ref = o.lm_solve(small.cams, small.pts, small.cam_idx, small.pt_idx, small.uv, small.K4, fixed_cam=small.fixed_cam,
+                     loss="huber", max_iters=6, ftol=0.0, xtol=0.0, gtol=0.0, linear_solver="dense")
+    for t, h in zip(got_tr, ref["history"]):
+        assert abs(t["cost_trial"] - h["cost_new"]) <= 1e-9 * h["cost_new"], (t, h)
+        assert bool(t["accepted"]) == bool(h["rho"] > 0)
+    assert abs(got["final_cost"] - ref["cost"]) <= 1e-9 * ref["cost"]

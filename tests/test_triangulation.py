@@ -15,10 +15,10 @@ from oracle import ba_oracle as o
 K = np.array([[912.7820434570312, 0.0, 650.2929077148438], [0.0, 913.0294189453125, 362.7241516113281], [0.0, 0.0, 1.0]])
 
 
-def _scene(n, seed, noise=0.0, behind=0):
+def _scene(n, seed, noise=0.0, behind=0, baseline=0.4, rot=1.0):
     rng = np.random.default_rng(seed)
-    R = rvecs_to_matrices(np.array([[0.02, -0.05, 0.01]]))[0]
-    t = np.array([[-0.4], [0.03], [0.05]])
+    R = rvecs_to_matrices(rot * np.array([[0.02, -0.05, 0.01]]))[0]
+    t = baseline * np.array([[-1.0], [0.075], [0.125]])
     X = np.stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(5, 20, n)], axis=1)
     X[:behind, 2] *= -1.0                                        # points behind both cameras
     x1 = X @ K.T
@@ -60,6 +60,19 @@ def test_device_triangulation_matches_the_oracle():
             ref, vref = o.triangulate_points(K, R, t, p1, p2)
             np.testing.assert_array_equal(valid, vref)
             assert np.abs(xyz - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+        # low-parallax pairs (a keyframe right after the last one): baselines of 1 cm, 1 mm, 0.1 mm.  The DLT system is
+        # then nearly rank-2; the device works on A itself (one-sided Jacobi SVD), not on A^T A, and stays on the
+        # oracle's LAPACK SVD -- also in WHICH points it keeps (z > 0 in both cameras, src/pipeline.py:328-334)
+        for base in (1e-2, 1e-3, 1e-4):
+            Rb, tb, Xb, q1, q2 = _scene(3000, 6, 0.3, 40, baseline=base, rot=0.1)
+            xyz_b, valid_b = s.triangulate(K, Rb, tb, q1, q2)
+            ref_b, vref_b = o.triangulate_points(K, Rb, tb, q1, q2)
+            scale = max(1.0, np.abs(ref_b).max())
+            assert np.abs(xyz_b - ref_b).max() <= 1e-8 * scale, base
+            z2 = (ref_b @ Rb.T + tb.ravel())[:, 2]
+            decided = (np.abs(ref_b[:, 2]) > 1e-7 * scale) & (np.abs(z2) > 1e-7 * scale)      # not on the z = 0 knife edge
+            np.testing.assert_array_equal(valid_b[decided], vref_b[decided])
+            assert decided.mean() > 0.99
         # the reference-shaped wrapper: (3, kept) array, kept indices, its log line; empty input -> (None, None)
         buf = io.StringIO()
         with redirect_stdout(buf):

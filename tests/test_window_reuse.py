@@ -127,15 +127,32 @@ def test_native_write_back_in_place_and_rebinding():
     for m in mps.values():
         gm.add_map_point(m)
     gm.add_keyframe(Keyframe(id=7, R=np.eye(3), t=np.zeros((3, 1)), keypoints=[], descriptors=None, observations=[], img=None))
-    ba = ba_mod.BundleAdjuster(np.eye(3), window_size=2)
     x = np.concatenate([[0.1, 0.2, 0.3], [1.0, 2.0, 3.0], (pts + 100).ravel()])
+    # opt-in in-place write-back: arrays that already are (3,1) float64 keep their identity
+    held = {i: gm.map_points[i].position for i in (0, 5)}
+    ba = ba_mod.BundleAdjuster(np.eye(3), window_size=2, inplace_writeback=True)
     ba._update_map(gm, x, [7], [0, 1, 2, 3, 4, 5])
     for i in range(6):
         pos = gm.map_points[i].position
         assert isinstance(pos, np.ndarray) and pos.shape == (3, 1) and pos.dtype == np.float64
         np.testing.assert_array_equal(pos.ravel(), pts[i] + 100)
+    assert all(gm.map_points[i].position is held[i] for i in (0, 5))
     assert gm.keyframes[7].R.shape == (3, 3) and gm.keyframes[7].t.shape == (3, 1)
     np.testing.assert_array_equal(gm.keyframes[7].t.ravel(), [1.0, 2.0, 3.0])
+    # default: every landmark is REBOUND to a fresh (3,1) array like in the reference (src/bundle_adjuster.py:239-240);
+    # an array somebody held before the run (a snapshot, an alias) keeps the numbers it had
+    before = {i: gm.map_points[i].position for i in range(6)}
+    snapshot = {i: before[i].copy() for i in range(6)}
+    ba = ba_mod.BundleAdjuster(np.eye(3), window_size=2)
+    x2 = np.concatenate([[0.1, 0.2, 0.3], [1.0, 2.0, 3.0], (pts + 200).ravel()])
+    ba._update_map(gm, x2, [7], [0, 1, 2, 3, 4, 5])
+    for i in range(6):
+        pos = gm.map_points[i].position
+        assert pos is not before[i] and pos.shape == (3, 1) and pos.dtype == np.float64
+        np.testing.assert_array_equal(pos.ravel(), pts[i] + 200)
+        np.testing.assert_array_equal(before[i], snapshot[i])
+    with pytest.raises(KeyError):
+        _mapwalk.rebind_positions(gm.map_points, np.array([99], dtype=np.int64), np.zeros((1, 3, 1)))
 
 
 def test_run_sends_parameters_only_when_the_structure_is_unchanged(monkeypatch):

@@ -30,4 +30,4 @@ for rep in range(3):      # 0: cold (walk + sorts + upload); 1, 2: the window is
           f"({ba.last_summary['iterations']} LM it) | {buf.getvalue().strip().splitlines()[-1].strip()} | cache {ba._window.hits}")
 x = np.concatenate([prob.cams[1:, :3].ravel(), prob.cams[1:, 3:].ravel(), prob.pts.ravel()])     # prob: every keyframe of the map
 mp_ids = np.array(sorted(g.map_points), dtype=np.int64)
-t = time.time(); ba._update_map(g, x, ids[1:], mp_ids); print(f"  _update_map alone (native, in place): {1e3*(time.time()-t):.1f} ms")
+t = time.time(); ba._update_map(g, x, ids[1:], mp_ids); print(f"  _update_map alone (native rebind): {1e3*(time.time()-t):.1f} ms")
