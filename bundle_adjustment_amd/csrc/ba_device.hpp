@@ -21,9 +21,12 @@ constexpr int CS = 24;   // doubles of state per camera: R[9] t[3] M[9] pad[3]
 constexpr double DBL_EPS = 2.220446049250313e-16;
 constexpr double DIAG_FLOOR = 1e-12;
 
-// index of (i,j), i<=j, in the packed upper triangle of a symmetric 6x6 / 3x3
-__host__ __device__ constexpr int U6(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
-__host__ __device__ constexpr int S6(int i, int j) { return i <= j ? U6(i, j) : U6(j, i); }
+// index of (i,j), i<=j, in the packed upper triangle of a symmetric NB x NB block (row-major: 00 01 .. 0(NB-1) 11 ..).
+// Camera blocks are 6x6 for the reference's pinhole (rvec | t) and 9x9 for the BAL camera (rvec | t | f k1 k2).
+__host__ __device__ constexpr int UT(int nb, int i, int j) { return i * nb - (i * (i - 1)) / 2 + (j - i); }
+__host__ __device__ constexpr int ST(int nb, int i, int j) { return i <= j ? UT(nb, i, j) : UT(nb, j, i); }
+__host__ __device__ constexpr int U6(int i, int j) { return UT(6, i, j); }
+__host__ __device__ constexpr int S6(int i, int j) { return ST(6, i, j); }
 __host__ __device__ constexpr int U3(int i, int j) { return i * 3 - (i * (i - 1)) / 2 + (j - i); }
 __host__ __device__ constexpr int S3(int i, int j) { return i <= j ? U3(i, j) : U3(j, i); }
 
@@ -159,68 +162,73 @@ __device__ inline void sym3_mul(const double* __restrict__ h, const double* __re
   o[2] = h[2] * v[0] + h[4] * v[1] + h[5] * v[2];
 }
 
-__device__ inline void sym6_mul(const double* __restrict__ h, const double* __restrict__ v, double* __restrict__ o) {
+template <int NB>
+__device__ inline void symN_mul(const double* __restrict__ h, const double* __restrict__ v, double* __restrict__ o) {
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < NB; ++i) {
     double s = 0;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) s += h[S6(i, j)] * v[j];
+    for (int j = 0; j < NB; ++j) s += h[ST(NB, i, j)] * v[j];
     o[i] = s;
   }
 }
+__device__ inline void sym6_mul(const double* __restrict__ h, const double* __restrict__ v, double* __restrict__ o) { symN_mul<6>(h, v, o); }
 
-// inverse of a symmetric positive definite 6x6 (packed upper in, packed upper out) by
-// Cholesky; a non-positive pivot is replaced by DIAG_FLOOR so the result stays finite.
-__device__ inline void spd6_inverse(const double* __restrict__ h, double* __restrict__ inv) {
-  double L[6][6];
+// inverse of a symmetric positive definite NB x NB block (packed upper in, packed upper out) by
+// Cholesky; a non-positive pivot is replaced by DIAG_FLOOR so the result stays finite.  Fully unrolled: every
+// index is a compile-time constant, the structural zeros of L and L^-1 never exist.
+template <int NB>
+__device__ inline void spdN_inverse(const double* __restrict__ h, double* __restrict__ inv) {
+  double L[NB][NB];
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < NB; ++i)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) L[i][j] = 0;
+    for (int j = 0; j < NB; ++j) L[i][j] = 0;
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    double s = h[U6(j, j)];
+  for (int j = 0; j < NB; ++j) {
+    double s = h[UT(NB, j, j)];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) if (k < j) s -= L[j][k] * L[j][k];
+    for (int k = 0; k < NB; ++k) if (k < j) s -= L[j][k] * L[j][k];
     s = (s > DIAG_FLOOR) ? s : DIAG_FLOOR;
     const double l = sqrt(s);
     L[j][j] = l;
     const double il = 1.0 / l;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) if (i > j) {
-      double t = h[U6(j, i)];
+    for (int i = 0; i < NB; ++i) if (i > j) {
+      double t = h[UT(NB, j, i)];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) if (k < j) t -= L[i][k] * L[j][k];
+      for (int k = 0; k < NB; ++k) if (k < j) t -= L[i][k] * L[j][k];
       L[i][j] = t * il;
     }
   }
   // Linv (lower)
-  double Li[6][6];
+  double Li[NB][NB];
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < NB; ++i)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) Li[i][j] = 0;
+    for (int j = 0; j < NB; ++j) Li[i][j] = 0;
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
+  for (int j = 0; j < NB; ++j) {
     Li[j][j] = 1.0 / L[j][j];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) if (i > j) {
+    for (int i = 0; i < NB; ++i) if (i > j) {
       double t = 0;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) if (k >= j && k < i) t -= L[i][k] * Li[k][j];
+      for (int k = 0; k < NB; ++k) if (k >= j && k < i) t -= L[i][k] * Li[k][j];
       Li[i][j] = t / L[i][i];
     }
   }
   // inv = Li^T Li
 #pragma unroll
-  for (int i = 0; i < 6; ++i)
+  for (int i = 0; i < NB; ++i)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) if (j >= i) {
+    for (int j = 0; j < NB; ++j) if (j >= i) {
       double t = 0;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) if (k >= j) t += Li[k][i] * Li[k][j];
-      inv[U6(i, j)] = t;
+      for (int k = 0; k < NB; ++k) if (k >= j) t += Li[k][i] * Li[k][j];
+      inv[UT(NB, i, j)] = t;
     }
 }
+__device__ inline void spd6_inverse(const double* __restrict__ h, double* __restrict__ inv) { spdN_inverse<6>(h, inv); }
 
 }  // namespace ba

@@ -34,7 +34,6 @@
 #include "ba_triangulate.hpp"
 #include "ba_coarse.hpp"
 #include "ba_small.hpp"
-#include "ba_bal.hpp"
 
 using namespace ba;
 
@@ -140,6 +139,8 @@ struct ba_handle {
   int device = 0;
   int n_cu = 256;              // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int xcd_ranges = 1;          // point-pass ranges grouped per XCD (BA_XCD_RANGES=0 turns it off; speed only)
+  int model = 0;               // camera model of the running call: 0 = the reference's pinhole (Pinhole), 1 = BAL 9-parameter
+                               // (BalCam, ba_models.hpp); every kernel of the loop is instantiated for both
   int lanes = LPP;             // lanes per point in the point passes: 2, or 4 / 8 / 16 for every point of a smaller problem
   int cam_band = 0;            // camera passes: XCD x takes camera range x (1) or partition x of every camera (0); see group_of_block
   hipStream_t stream = nullptr;
@@ -175,10 +176,7 @@ struct ba_handle {
   char* d_small_host = nullptr;
   size_t h_small_bytes = 0;
   long long small_seq = 0;     // sequence number of h_flags[4], which k_small_lm publishes when its results are written
-  // BAL 9-parameter path (ba_solve_bal, csrc/ba_bal.hpp)
-  DBuf<double> bal_intr[2], bal_partL, bal_HccBc, bal_Hd, bal_Minv, bal_part9, bal_x, bal_r, bal_z, bal_p, bal_q, bal_misc, bal_partB, bal_partG, bal_partA, bal_vt, bal_s;
-  DBuf<char> bal_st;
-  long long bal_seq = 0;       // sequence number of h_flags[6]
+  DBuf<double> intr[2];        // per-camera intrinsics (f, k1, k2) of the BAL model, current / trial like cams[]
   DBuf<double> small_V, small_gS;   // k_small_lm: V = W L (49 x 3 Np_pad, zero where unwritten), per-wave partial V V^T
   int small_np_pad = -1;
   // two-level preconditioner for band-structured problems (ba_coarse.hpp): structures built by ba_set_problem
@@ -192,9 +190,9 @@ struct ba_handle {
   DBuf<double> verdict;        // PCG verdict words {gamma, zeta, finished, -} x 2 iteration parities (point pass -> camera pass, vector kernel)
   int cam_segl = 64;           // lanes per (camera, partition) segment in the PCG camera pass (BA_CAM_SEGL, tuning)
   int nblkP = 1, ppb = 1, nblkV = 1;
-  size_t lds_bytes = 0;
+  size_t lds_bytes_m[2] = {0, 0};   // dynamic LDS of the point passes (largest window that fits), per camera model (row strides differ)
   bool jac_f32 = false;        // PCG passes recompute the Jacobian blocks in fp32 (ba_options.jacobian_precision = 1)
-  bool all_lds = true;         // every point-pass workgroup's camera window fits in LDS
+  bool all_lds_m[2] = {true, true};  // every point-pass workgroup's camera window fits in LDS, per camera model
   // pinned host mirror for scalars
   double* h_scal = nullptr;
   double* d_scal_host = nullptr;   // device-side address of h_scal (host-mapped, coherent)
@@ -282,14 +280,18 @@ static int create_impl(ba_handle* h, int device_id) {
   memset(h->h_flags, 0, 8 * sizeof(long long));
   HIPCHECK(hipHostGetDevicePointer((void**)&h->d_flags, h->h_flags, 0));
 #define BA_BIG_LDS(K) HIPCHECK(allow_big_lds(K))
-#define BA_BIG_LDS_LIN(R, L) BA_BIG_LDS((k_pt_linearize<R, L, 2>)); BA_BIG_LDS((k_pt_linearize<R, L, 4>));        \
-  BA_BIG_LDS((k_pt_linearize<R, L, 8>)); BA_BIG_LDS((k_pt_linearize<R, L, 16>)); BA_BIG_LDS((k_pt_linearize_both<R, L>))
-#define BA_BIG_LDS_SCH1(R, M, L, LN) BA_BIG_LDS((k_pt_schur<R, M, L, LN, double>)); BA_BIG_LDS((k_pt_schur<R, M, L, LN, float>))
-#define BA_BIG_LDS_SCH(R, M, L) BA_BIG_LDS_SCH1(R, M, L, 2); BA_BIG_LDS_SCH1(R, M, L, 4); BA_BIG_LDS_SCH1(R, M, L, 8);     \
-  BA_BIG_LDS_SCH1(R, M, L, 16); BA_BIG_LDS((k_pt_schur_both<R, M, L, double>)); BA_BIG_LDS((k_pt_schur_both<R, M, L, float>))
-  BA_BIG_LDS_LIN(true, true); BA_BIG_LDS_LIN(true, false); BA_BIG_LDS_LIN(false, true); BA_BIG_LDS_LIN(false, false);
-  BA_BIG_LDS_SCH(true, 0, true); BA_BIG_LDS_SCH(true, 0, false); BA_BIG_LDS_SCH(false, 0, true); BA_BIG_LDS_SCH(false, 0, false);
-  BA_BIG_LDS_SCH(true, 1, true); BA_BIG_LDS_SCH(true, 1, false); BA_BIG_LDS_SCH(false, 1, true); BA_BIG_LDS_SCH(false, 1, false);
+#define BA_BIG_LDS_LIN(CM, R, L) BA_BIG_LDS((k_pt_linearize<CM, R, L, 2>)); BA_BIG_LDS((k_pt_linearize<CM, R, L, 4>));        \
+  BA_BIG_LDS((k_pt_linearize<CM, R, L, 8>)); BA_BIG_LDS((k_pt_linearize<CM, R, L, 16>)); BA_BIG_LDS((k_pt_linearize_both<CM, R, L>))
+#define BA_BIG_LDS_SCH1(CM, R, M, L, LN) BA_BIG_LDS((k_pt_schur<CM, R, M, L, LN, double>)); BA_BIG_LDS((k_pt_schur<CM, R, M, L, LN, float>))
+#define BA_BIG_LDS_SCH(CM, R, M, L) BA_BIG_LDS_SCH1(CM, R, M, L, 2); BA_BIG_LDS_SCH1(CM, R, M, L, 4); BA_BIG_LDS_SCH1(CM, R, M, L, 8);     \
+  BA_BIG_LDS_SCH1(CM, R, M, L, 16); BA_BIG_LDS((k_pt_schur_both<CM, R, M, L, double>)); BA_BIG_LDS((k_pt_schur_both<CM, R, M, L, float>))
+#define BA_BIG_LDS_MODEL(CM)                                                                                                            \
+  BA_BIG_LDS_LIN(CM, true, true); BA_BIG_LDS_LIN(CM, true, false); BA_BIG_LDS_LIN(CM, false, true); BA_BIG_LDS_LIN(CM, false, false);   \
+  BA_BIG_LDS_SCH(CM, true, 0, true); BA_BIG_LDS_SCH(CM, true, 0, false); BA_BIG_LDS_SCH(CM, false, 0, true); BA_BIG_LDS_SCH(CM, false, 0, false); \
+  BA_BIG_LDS_SCH(CM, true, 1, true); BA_BIG_LDS_SCH(CM, true, 1, false); BA_BIG_LDS_SCH(CM, false, 1, true); BA_BIG_LDS_SCH(CM, false, 1, false)
+  BA_BIG_LDS_MODEL(Pinhole);
+  BA_BIG_LDS_MODEL(BalCam);
+#undef BA_BIG_LDS_MODEL
 #undef BA_BIG_LDS_SCH
 #undef BA_BIG_LDS_SCH1
 #undef BA_BIG_LDS_LIN
@@ -343,10 +345,7 @@ extern "C" int ba_destroy(ba_handle* h) {
   h->st.release();
   h->tri.release();
   h->small_V.release();
-  { DBuf<double>* bb[] = {&h->bal_intr[0], &h->bal_intr[1], &h->bal_partL, &h->bal_HccBc, &h->bal_Hd, &h->bal_Minv, &h->bal_part9, &h->bal_x,
-                          &h->bal_r, &h->bal_z, &h->bal_p, &h->bal_q, &h->bal_misc, &h->bal_partB, &h->bal_partG, &h->bal_partA, &h->bal_vt, &h->bal_s};
-    for (auto b : bb) b->release(); }
-  h->bal_st.release();
+  h->intr[0].release(); h->intr[1].release();
   h->small_gS.release();
   h->small_np_pad = -1;
   h->run_beg.release(); h->run_pt.release(); h->run_agg.release(); h->run_pairs.release();
@@ -814,13 +813,18 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   const int long_per_blk = PT_THREADS / LPP_LONG;
   h->nblkL = (h->n_long + long_per_blk - 1) / long_per_blk;
   std::vector<int2> win(h->nblkP + h->nblkL);
-  size_t max_win = 0;
-  h->all_lds = true;
+  // a window is staged in LDS when its rows fit; the row stride depends on the camera model (18 doubles for the
+  // reference's pinhole, 26 for the BAL camera), so the LDS size and the "every window fits" flag are kept per model
+  size_t max_win[2] = {0, 0};
+  const size_t row_bytes[2] = {Pinhole::TA * sizeof(double), BalCam::TA * sizeof(double)};
+  h->all_lds_m[0] = h->all_lds_m[1] = true;
   auto window_of = [&](int lo, int hi) {
     if (hi < lo) { lo = 0; hi = -1; }
-    const size_t bytes = (size_t)(hi - lo + 1) * TA * sizeof(double);
-    if (bytes <= (size_t)LDS_TAB_BYTES) max_win = std::max(max_win, bytes);
-    else h->all_lds = false;
+    for (int m = 0; m < 2; ++m) {
+      const size_t bytes = (size_t)(hi - lo + 1) * row_bytes[m];
+      if (bytes <= (size_t)LDS_TAB_BYTES) max_win[m] = std::max(max_win[m], bytes);
+      else h->all_lds_m[m] = false;
+    }
     return make_int2(lo, hi - lo + 1);
   };
   for (int b = 0; b < h->nblkP; ++b) {
@@ -835,7 +839,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
       for (int j = pt_off[long_pts[q]]; j < pt_off[long_pts[q] + 1]; ++j) { lo = std::min(lo, p_cam[j]); hi = std::max(hi, p_cam[j]); }
     win[h->nblkP + b] = window_of(lo, hi);
   }
-  h->lds_bytes = max_win;
+  h->lds_bytes_m[0] = max_win[0]; h->lds_bytes_m[1] = max_win[1];
   stage("long tracks + windows");
   const size_t nobs1 = std::max(No, 1), np1 = std::max(Np, 1);
   HIPCHECK(h->offk.alloc((size_t)Nc * (NPART + 1))); HIPCHECK(h->pt_off.alloc(Np + 1));
@@ -855,23 +859,28 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     HIPCHECK(hipMemsetAsync(h->ptab[k].p, 0, PT * np1 * sizeof(double), h->stream));
   }
   HIPCHECK(h->stage.alloc(3 * np1));
-  HIPCHECK(h->camA[0].alloc(TA * (size_t)Nc)); HIPCHECK(h->camA[1].alloc(TA * (size_t)Nc));
-  HIPCHECK(h->HccBc.alloc(27 * (size_t)Nc + 8));   // Hcc (21 Nc) | bc (6 Nc): one all-reduce
+  // per-camera buffers are sized for the larger camera model (BAL: 9 parameters, 45 + 9 sums, 26-double table rows)
+  constexpr size_t NBX = BalCam::NB, NHX = BalCam::NH, NLX = BalCam::NL;
+  HIPCHECK(h->camA[0].alloc(TA_MAX * (size_t)Nc)); HIPCHECK(h->camA[1].alloc(TA_MAX * (size_t)Nc));
+  HIPCHECK(h->intr[0].alloc(3 * (size_t)Nc)); HIPCHECK(h->intr[1].alloc(3 * (size_t)Nc));
+  HIPCHECK(hipMemsetAsync(h->intr[0].p, 0, 3 * (size_t)Nc * sizeof(double), h->stream));
+  HIPCHECK(hipMemsetAsync(h->intr[1].p, 0, 3 * (size_t)Nc * sizeof(double), h->stream));
+  HIPCHECK(h->HccBc.alloc(NLX * (size_t)Nc + 8));   // Hcc (NH Nc) | bc (NB Nc): one all-reduce
   for (int k = 0; k < 2; ++k) {
     HIPCHECK(h->Hpp[k].alloc(6 * np1)); HIPCHECK(h->bp[k].alloc(3 * np1)); HIPCHECK(h->Hppinv[k].alloc(6 * np1));
     HIPCHECK(h->y0[k].alloc(3 * np1));
   }
   h->pb = 0;
-  HIPCHECK(h->Hccd.alloc(21 * (size_t)Nc)); HIPCHECK(h->Minv.alloc(21 * (size_t)Nc));
+  HIPCHECK(h->Hccd.alloc(NHX * (size_t)Nc)); HIPCHECK(h->Minv.alloc(NHX * (size_t)Nc));
   HIPCHECK(h->partR.alloc(2 * (size_t)NPART * Nc));
-  HIPCHECK(h->partL[0].alloc(27 * (size_t)NPART * Nc)); HIPCHECK(h->partL[1].alloc(27 * (size_t)NPART * Nc));
-  HIPCHECK(h->part6.alloc(6 * (size_t)NPART * Nc + 8));   // + the u.y word: one all-reduce carries both
-  HIPCHECK(h->partE.alloc(21 * (size_t)NPART * Nc));
+  HIPCHECK(h->partL[0].alloc(NLX * (size_t)NPART * Nc)); HIPCHECK(h->partL[1].alloc(NLX * (size_t)NPART * Nc));
+  HIPCHECK(h->part6.alloc(NBX * (size_t)NPART * Nc + 8));   // + the u.y word: one all-reduce carries both
+  HIPCHECK(h->partE.alloc(NHX * (size_t)NPART * Nc));
   HIPCHECK(h->partA.alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partB.alloc(4 * (size_t)(h->nblkP + h->nblkL)));
   HIPCHECK(h->partC.alloc(5 * (size_t)h->nblkV)); HIPCHECK(h->partV.alloc(4 * (size_t)h->nblkV));
   HIPCHECK(h->partG[0].alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partG[1].alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partGc.alloc(h->nblkV));
   DBuf<double>* v6[] = {&h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin};
-  for (auto b : v6) HIPCHECK(b->alloc(6 * (size_t)Nc));
+  for (auto b : v6) HIPCHECK(b->alloc(NBX * (size_t)Nc));
   HIPCHECK(h->scal.alloc(64));
   if (h->two_level_ok) {
     const size_t nc6 = 6 * (size_t)h->n_agg;
@@ -887,8 +896,8 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(h->st.alloc(2));
   HIPCHECK(h->verdict.alloc(8));
   HIPCHECK(hipMemsetAsync(h->verdict.p, 0, 8 * sizeof(double), h->stream));
-  HIPCHECK(hipMemsetAsync(h->camA[0].p, 0, TA * (size_t)Nc * sizeof(double), h->stream));
-  HIPCHECK(hipMemsetAsync(h->camA[1].p, 0, TA * (size_t)Nc * sizeof(double), h->stream));
+  HIPCHECK(hipMemsetAsync(h->camA[0].p, 0, TA_MAX * (size_t)Nc * sizeof(double), h->stream));
+  HIPCHECK(hipMemsetAsync(h->camA[1].p, 0, TA_MAX * (size_t)Nc * sizeof(double), h->stream));
   h->lb = 0;
   stage("allocations");
   HIPCHECK(hipMemcpyAsync(h->offk.p, offk.data(), offk.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
@@ -914,12 +923,13 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   return BA_OK;
 }
 
-static double* bc_ptr(ba_handle* h) { return h->HccBc.p + 21 * (size_t)h->Nc; }
-// part6 buffer: [u.y word, pad | NPART x Nc x 6 partial sums]; the u.y word sits in FRONT of partition 0 so that a
-// multi-rank job all-reduces it together with the folded partition (one contiguous message)
-constexpr int GMAX_HOST_SLOT = 40;   // word of the host-mapped scalar block that k_absmax2 writes (k_scalars uses [0, S_COUNT))
-static double* uy_ptr(ba_handle* h) { return h->part6.p; }
-static double* p6_ptr(ba_handle* h) { return h->part6.p + 2; }
+// block sizes of the running camera model
+static int nb_of(const ba_handle* h) { return h->model ? BalCam::NB : Pinhole::NB; }
+static int nh_of(const ba_handle* h) { return h->model ? BalCam::NH : Pinhole::NH; }
+static int nl_of(const ba_handle* h) { return h->model ? BalCam::NL : Pinhole::NL; }
+static size_t lds_of(const ba_handle* h) { return h->lds_bytes_m[h->model]; }
+static bool all_lds_of(const ba_handle* h) { return h->all_lds_m[h->model]; }
+static double* bc_ptr(ba_handle* h) { return h->HccBc.p + nh_of(h) * (size_t)h->Nc; }
 static int cam_grid(ba_handle* h, int segl = 64) { const int cpb = 64 * WPB / segl; return ((h->Nc + cpb - 1) / cpb) * NPART; }
 static int row_grid(ba_handle* h) { return ((h->Nc + ROWS - 1) / ROWS) * NPART; }
 
@@ -933,7 +943,8 @@ extern "C" int ba_set_params(ba_handle* h, const double* cams, const double* pts
     HIPCHECK(hipMemcpyAsync(h->stage.p, pts, 3 * (size_t)h->Np * sizeof(double), hipMemcpyHostToDevice, h->stream));
     BA_LAUNCH(k_pack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->stage.p, h->slot.p, h->Np, h->ptab[0].p);
   }
-  BA_LAUNCH(k_cam_prepare, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->cams[0].p, h->cs[0].p, h->camA[0].p, h->Nc);
+  BA_LAUNCH(k_cam_prepare<Pinhole>, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->cams[0].p, (const double*)h->intr[0].p,
+            h->cs[0].p, h->camA[0].p, h->Nc);
   BA_SYNC(h);
   h->have_params = true;
   h->linearized = false;
@@ -985,8 +996,22 @@ extern "C" int ba_get_rotations(ba_handle* h, double* R) {
 }
 
 // ---------------------------------------------------------------------- launch helpers
+// Every helper dispatches on the camera model of the running call (h->model): the same kernel templates, instantiated
+// for the reference's pinhole and for the BAL camera (ba_models.hpp).
+#define BA_BY_MODEL(CALL_T)                      \
+  do {                                           \
+    if (h->model) CALL_T(BalCam);                \
+    else CALL_T(Pinhole);                        \
+  } while (0)
+
 static void launch_residual(ba_handle* h, int which, bool robust, double fscale, double* r_out) {
   Scope sc(h, BA_K_RESIDUAL);
+  if (h->model) {
+    auto kern = robust ? k_cam_residual_bal<true> : k_cam_residual_bal<false>;
+    BA_LAUNCH(kern, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[which].p, (const double*)h->intr[which].p, h->ptab[which].p,
+              h->offk.p, h->c_pt.p, h->c_uv.p, h->c_orig.p, fscale, h->Nc, h->cam_band, r_out, h->partR.p);
+    return;
+  }
   auto kern = robust ? k_cam_residual<true> : k_cam_residual<false>;
   BA_LAUNCH(kern, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[which].p, h->ptab[which].p, h->offk.p,
                      h->c_pt.p, h->c_uv.p, h->c_orig.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, h->cam_band, r_out,
@@ -1034,18 +1059,26 @@ static int wait_flag(ba_handle* h, int idx, long long target) {
 }
 // camera half of the linearisation at parameter set `which`, into buffer set `buf`
 // cost: also the cost partials at that parameter set (partR) -- the pass then doubles as the trial-cost evaluation
+template <class CM>
+static void launch_lin_cam_t(ba_handle* h, int which, int buf, bool robust, double fscale, bool cost) {
+  auto kern = robust ? (cost ? k_camrow_linearize<CM, true, true> : k_camrow_linearize<CM, true, false>)
+                     : (cost ? k_camrow_linearize<CM, false, true> : k_camrow_linearize<CM, false, false>);
+  BA_LAUNCH(kern, dim3(row_grid(h)), dim3(ROW_LANES * ROWS), 0, h->stream, h->cs[which].p, (const double*)h->intr[which].p,
+                     h->ptab[which].p, h->offk.p, h->c_pt.p, h->c_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc,
+                     h->cam_band, h->c_w[buf].p, h->c_ptf[buf].p, h->partL[buf].p, h->partR.p);
+}
 static void launch_lin_cam(ba_handle* h, int which, int buf, bool robust, double fscale, bool cost = false) {
   Scope sc(h, BA_K_LINEARIZE_CAM);
-  auto kern = robust ? (cost ? k_camrow_linearize<true, true> : k_camrow_linearize<true, false>)
-                     : (cost ? k_camrow_linearize<false, true> : k_camrow_linearize<false, false>);
-  BA_LAUNCH(kern, dim3(row_grid(h)), dim3(ROW_LANES * ROWS), 0, h->stream, h->cs[which].p, h->ptab[which].p, h->offk.p,
-                     h->c_pt.p, h->c_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, h->cam_band, h->c_w[buf].p,
-                     h->c_ptf[buf].p, h->partL[buf].p, h->partR.p);
+#define CALL_T(CM) launch_lin_cam_t<CM>(h, which, buf, robust, fscale, cost)
+  BA_BY_MODEL(CALL_T);
+#undef CALL_T
 }
 static void launch_lin_finalize(ba_handle* h) {
   Scope sc(h, BA_K_MISC);
-  BA_LAUNCH(k_lin_finalize, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->partL[h->lb].p, h->cs[h->cur].p,
-                     h->Nc, h->fixed, h->HccBc.p, bc_ptr(h));
+#define CALL_T(CM) BA_LAUNCH(k_lin_finalize<CM::NB>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->partL[h->lb].p, \
+                             h->cs[h->cur].p, h->Nc, h->fixed, h->HccBc.p, bc_ptr(h))
+  BA_BY_MODEL(CALL_T);
+#undef CALL_T
 }
 static PtWork pt_work(ba_handle* h) {        // every point; long tracks skipped when they have a launch of their own
   return PtWork{nullptr, h->Np, h->nblkL ? h->long_thr : 0x7fffffff, 0, h->ppb, h->xcd_ranges};
@@ -1053,19 +1086,18 @@ static PtWork pt_work(ba_handle* h) {        // every point; long tracks skipped
 static PtWork pt_work_long(ba_handle* h) { return PtWork{h->long_pts.p, h->n_long, 0x7fffffff, h->nblkP, PT_THREADS / LPP_LONG, 0}; }
 // point half at parameter set `w` into point-buffer set `pbuf`, with the damped inverse / y0 at `lambda` fused in
 // (lam_dev != null: the damping is read from that device word instead -- a speculated pass, see ba_solve)
-static void launch_lin_pt(ba_handle* h, int w, int pbuf, bool robust, double fscale, double lambda, const double* lam_dev = nullptr) {
-  if (h->Np == 0) return;
-  Scope sc(h, BA_K_LINEARIZE_PT);
+template <class CM>
+static void launch_lin_pt_t(ba_handle* h, int w, int pbuf, bool robust, double fscale, double lambda, const double* lam_dev) {
 #define LP_HEAD h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_uv.p, h->blk_win.p
 #define LP_TAIL h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, lambda, lam_dev, h->Hpp[pbuf].p, h->bp[pbuf].p, h->p_w[pbuf].p,      \
                 h->p_camf[pbuf].p, h->Hppinv[pbuf].p, h->y0[pbuf].p, h->partG[pbuf].p
-#define LP_LAUNCH(R, L, LN, G, WK) BA_LAUNCH((k_pt_linearize<R, L, LN>), dim3(G), dim3(PT_THREADS), h->lds_bytes, h->stream, LP_HEAD, WK, LP_TAIL)
-#define LP_BOTH(R, L) BA_LAUNCH((k_pt_linearize_both<R, L>), dim3(h->nblkP + h->nblkL), dim3(PT_THREADS), h->lds_bytes, h->stream, \
+#define LP_LAUNCH(R, L, LN, G, WK) BA_LAUNCH((k_pt_linearize<CM, R, L, LN>), dim3(G), dim3(PT_THREADS), lds_of(h), h->stream, LP_HEAD, WK, LP_TAIL)
+#define LP_BOTH(R, L) BA_LAUNCH((k_pt_linearize_both<CM, R, L>), dim3(h->nblkP + h->nblkL), dim3(PT_THREADS), lds_of(h), h->stream, \
                                          LP_HEAD, wk, h->nblkP, wl, LP_TAIL)
   const PtWork wk = pt_work(h), wl = pt_work_long(h);
   if (h->nblkL) {          // short and long tracks in one launch
-    if (h->all_lds) { if (robust) LP_BOTH(true, true); else LP_BOTH(false, true); }
-    else            { if (robust) LP_BOTH(true, false); else LP_BOTH(false, false); }
+    if (all_lds_of(h)) { if (robust) LP_BOTH(true, true); else LP_BOTH(false, true); }
+    else               { if (robust) LP_BOTH(true, false); else LP_BOTH(false, false); }
   } else {
 #define LP_ONE(R, L)                                             \
   do {                                                           \
@@ -1076,8 +1108,8 @@ static void launch_lin_pt(ba_handle* h, int w, int pbuf, bool robust, double fsc
       default: LP_LAUNCH(R, L, 2, h->nblkP, wk); break;          \
     }                                                            \
   } while (0)
-    if (h->all_lds) { if (robust) LP_ONE(true, true); else LP_ONE(false, true); }
-    else            { if (robust) LP_ONE(true, false); else LP_ONE(false, false); }
+    if (all_lds_of(h)) { if (robust) LP_ONE(true, true); else LP_ONE(false, true); }
+    else               { if (robust) LP_ONE(true, false); else LP_ONE(false, false); }
 #undef LP_ONE
   }
 #undef LP_BOTH
@@ -1085,71 +1117,81 @@ static void launch_lin_pt(ba_handle* h, int w, int pbuf, bool robust, double fsc
 #undef LP_HEAD
 #undef LP_TAIL
 }
+static void launch_lin_pt(ba_handle* h, int w, int pbuf, bool robust, double fscale, double lambda, const double* lam_dev = nullptr) {
+  if (h->Np == 0) return;
+  Scope sc(h, BA_K_LINEARIZE_PT);
+#define CALL_T(CM) launch_lin_pt_t<CM>(h, w, pbuf, robust, fscale, lambda, lam_dev)
+  BA_BY_MODEL(CALL_T);
+#undef CALL_T
+}
 static void launch_point_invert(ba_handle* h, double lambda) {
   if (h->Np == 0) return;
   Scope sc(h, BA_K_POINT_INVERT);
   BA_LAUNCH(k_point_invert, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp[h->pb].p, h->bp[h->pb].p, lambda,
                      h->Np, h->Hppinv[h->pb].p, h->y0[h->pb].p, h->ptab[h->cur].p);
 }
+// part6 buffer: [u.y word, pad | NPART x Nc x NB partial sums]; the u.y word sits in FRONT of partition 0 so that a
+// multi-rank job all-reduces it together with the folded partition (one contiguous message)
+constexpr int GMAX_HOST_SLOT = 40;   // word of the host-mapped scalar block that receives max |gradient| (k_scalars uses [0, S_COUNT))
+static double* uy_ptr(ba_handle* h) { return h->part6.p; }
+static double* p6_ptr(ba_handle* h) { return h->part6.p + 2; }
 // camera pass of the Schur product on the y slot of the current point table
 //   diag: also the Schur-Jacobi blocks; pcg: iteration k with early exit
-static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int k, double tol2, int min_iters) {
-  Scope sc(h, diag ? BA_K_PRECOND : BA_K_SCHUR_CAM);
+template <class CM>
+static void launch_cam_schur_t(ba_handle* h, bool robust, bool diag, bool pcg, int k) {
   const int w = h->cur;
-#define CS_ARGS h->cs[w].p, h->ptab[w].p, h->offk.p, (robust ? h->c_ptf[h->lb].p : h->c_pt.p), h->c_w[h->lb].p, h->K4[0], h->K4[1], h->Nc, h->cam_band, h->fixed,        \
+#define CS_ARGS h->cs[w].p, (const double*)h->intr[w].p, h->ptab[w].p, h->offk.p, (robust ? h->c_ptf[h->lb].p : h->c_pt.p), h->c_w[h->lb].p,  \
+                h->K4[0], h->K4[1], h->Nc, h->cam_band, h->fixed,                                                                 \
                 p6_ptr(h), k, (const double*)h->verdict.p, h->partA.p, (h->Np > 0 ? h->nblkP + h->nblkL : 0), uy_ptr(h)
-  (void)tol2; (void)min_iters;
   const int segl = pcg ? h->cam_segl : 64;
   const dim3 g(cam_grid(h, segl) + (pcg ? 1 : 0)), b(64 * WPB);
 #define CS_PCG(R, JT)                                                                                       \
   do {                                                                                                      \
-    if (segl == 16) BA_LAUNCH((k_cam_schur<R, true, JT, 16>), g, b, 0, h->stream, CS_ARGS);        \
-    else if (segl == 32) BA_LAUNCH((k_cam_schur<R, true, JT, 32>), g, b, 0, h->stream, CS_ARGS);   \
-    else BA_LAUNCH((k_cam_schur<R, true, JT, 64>), g, b, 0, h->stream, CS_ARGS);                   \
+    if (segl == 16) BA_LAUNCH((k_cam_schur<CM, R, true, JT, 16>), g, b, 0, h->stream, CS_ARGS);        \
+    else if (segl == 32) BA_LAUNCH((k_cam_schur<CM, R, true, JT, 32>), g, b, 0, h->stream, CS_ARGS);   \
+    else BA_LAUNCH((k_cam_schur<CM, R, true, JT, 64>), g, b, 0, h->stream, CS_ARGS);                   \
   } while (0)
   if (diag) {
-    auto kern = robust ? k_camrow_schur_diag<true> : k_camrow_schur_diag<false>;
-    BA_LAUNCH(kern, dim3(row_grid(h)), dim3(ROW_LANES * ROWS), 0, h->stream, h->cs[w].p, h->ptab[w].p, h->offk.p,
-                       (robust ? h->c_ptf[h->lb].p : h->c_pt.p), h->c_w[h->lb].p, h->Hppinv[h->pb].p, h->K4[0], h->K4[1], h->Nc,
-                       h->cam_band, h->fixed, p6_ptr(h), h->partE.p);
+    auto kern = robust ? k_camrow_schur_diag<CM, true> : k_camrow_schur_diag<CM, false>;
+    BA_LAUNCH(kern, dim3(row_grid(h)), dim3(ROW_LANES * ROWS), 0, h->stream, h->cs[w].p, (const double*)h->intr[w].p, h->ptab[w].p,
+                       h->offk.p, (robust ? h->c_ptf[h->lb].p : h->c_pt.p), h->c_w[h->lb].p, h->Hppinv[h->pb].p, h->K4[0],
+                       h->K4[1], h->Nc, h->cam_band, h->fixed, p6_ptr(h), h->partE.p);
   } else if (pcg) {
     if (h->jac_f32) { if (robust) CS_PCG(true, float); else CS_PCG(false, float); }
     else            { if (robust) CS_PCG(true, double); else CS_PCG(false, double); }
   } else {
-    if (robust) BA_LAUNCH((k_cam_schur<true, false, double, 64>), g, b, 0, h->stream, CS_ARGS);
-    else        BA_LAUNCH((k_cam_schur<false, false, double, 64>), g, b, 0, h->stream, CS_ARGS);
+    if (robust) BA_LAUNCH((k_cam_schur<CM, true, false, double, 64>), g, b, 0, h->stream, CS_ARGS);
+    else        BA_LAUNCH((k_cam_schur<CM, false, false, double, 64>), g, b, 0, h->stream, CS_ARGS);
   }
 #undef CS_PCG
 #undef CS_ARGS
 }
+static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int k, double tol2, int min_iters) {
+  Scope sc(h, diag ? BA_K_PRECOND : BA_K_SCHUR_CAM);
+  (void)tol2; (void)min_iters;
+#define CALL_T(CM) launch_cam_schur_t<CM>(h, robust, diag, pcg, k)
+  BA_BY_MODEL(CALL_T);
+#undef CALL_T
+}
 // point pass with the camera vector in vtil; mode 0 = PCG iteration k, mode 1 = back substitution
 // gmax_out (first PCG probe behind a fresh linearisation): host-mapped word that receives max |gradient|
-static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double tol2, int min_iters, long long flag_base = 0,
-                            double* gmax_out = nullptr) {
-  if (h->Np == 0) {
-    // an empty landmark shard (multi-rank): no point pass, but the PCG probe's verdict is still owed
-    if (mode == 0 && flag_base > 0) {
-      Scope sc(h, BA_K_SCHUR_PT);
-      BA_LAUNCH(k_pcg_probe, dim3(1), dim3(64), 0, h->stream, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->d_flags,
-                flag_base, h->verdict.p, (const double*)h->partGc.p, h->nblkV, gmax_out);
-    }
-    return;
-  }
-  Scope sc(h, mode == 0 ? BA_K_SCHUR_PT : BA_K_BACKSUB);
+template <class CM>
+static void launch_pt_schur_t(ba_handle* h, bool robust, int mode, int k, double tol2, int min_iters, long long flag_base,
+                              double* gmax_out) {
   const int w = h->cur;
 #define PS_HEAD h->camA[w].p, h->ptab[w].p, h->pt_off.p, (robust ? h->p_camf[h->pb].p : h->p_cam.p), h->p_w[h->pb].p,                 \
                 h->Hppinv[h->pb].p, h->blk_win.p
 #define PS_TAIL h->K4[0], h->K4[1], h->fixed, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0[h->pb].p,     \
                 h->Hpp[h->pb].p, h->bp[h->pb].p, h->ptab[1 - w].p, h->partB.p, flag, flag_base, h->verdict.p,                      \
                 (const double*)h->partG[h->pb].p, h->nblkP + h->nblkL, (const double*)h->partGc.p, h->nblkV, gmax_out
-  const size_t lds = h->lds_bytes + (size_t)h->debug_lds_extra;
+  const size_t lds = lds_of(h) + (size_t)h->debug_lds_extra;
   long long* flag = (mode == 0 && flag_base > 0) ? h->d_flags : (long long*)nullptr;
   // data with long tracks: short and long tracks in one launch (workgroup 0 publishes the verdict)
 #define PS_ONE(R, M, L, LN, JT) \
-  BA_LAUNCH((k_pt_schur<R, M, L, LN, JT>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, PS_HEAD, wk, PS_TAIL)
+  BA_LAUNCH((k_pt_schur<CM, R, M, L, LN, JT>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, PS_HEAD, wk, PS_TAIL)
 #define PS_LAUNCH(R, M, L, JT)                                                                                              \
   do {                                                                                                                      \
-    if (h->nblkL) BA_LAUNCH((k_pt_schur_both<R, M, L, JT>), dim3(h->nblkP + h->nblkL), dim3(PT_THREADS), lds,      \
+    if (h->nblkL) BA_LAUNCH((k_pt_schur_both<CM, R, M, L, JT>), dim3(h->nblkP + h->nblkL), dim3(PT_THREADS), lds,  \
                                      h->stream, PS_HEAD, wk, h->nblkP, wl, PS_TAIL);                                        \
     else {                                                                                                                  \
       switch (h->lanes) {                                                                                                   \
@@ -1168,13 +1210,29 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
   } while (0)
   const PtWork wk = pt_work(h), wl = pt_work_long(h);
   const bool f32 = h->jac_f32 && flag_base > 0;       // only inside the PCG loop of ba_solve
-  if (h->all_lds) { if (robust) PS_MODE(true, true); else PS_MODE(false, true); }
-  else            { if (robust) PS_MODE(true, false); else PS_MODE(false, false); }
+  if (all_lds_of(h)) { if (robust) PS_MODE(true, true); else PS_MODE(false, true); }
+  else               { if (robust) PS_MODE(true, false); else PS_MODE(false, false); }
 #undef PS_MODE
 #undef PS_LAUNCH
 #undef PS_ONE
 #undef PS_HEAD
 #undef PS_TAIL
+}
+static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double tol2, int min_iters, long long flag_base = 0,
+                            double* gmax_out = nullptr) {
+  if (h->Np == 0) {
+    // an empty landmark shard (multi-rank): no point pass, but the PCG probe's verdict is still owed
+    if (mode == 0 && flag_base > 0) {
+      Scope sc(h, BA_K_SCHUR_PT);
+      BA_LAUNCH(k_pcg_probe, dim3(1), dim3(64), 0, h->stream, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->d_flags,
+                flag_base, h->verdict.p, (const double*)h->partGc.p, h->nblkV, gmax_out);
+    }
+    return;
+  }
+  Scope sc(h, mode == 0 ? BA_K_SCHUR_PT : BA_K_BACKSUB);
+#define CALL_T(CM) launch_pt_schur_t<CM>(h, robust, mode, k, tol2, min_iters, flag_base, gmax_out)
+  BA_BY_MODEL(CALL_T);
+#undef CALL_T
 }
 
 // multi-rank: a buffer of NPART per-partition partial sums is folded in place (partition 0 <- the sum
@@ -1190,13 +1248,13 @@ static int fold_and_reduce(ba_handle* h, double* parts, size_t n_per_part, doubl
   return allreduce(h, msg, msg_count);
 }
 static int exchange_partL(ba_handle* h, int buf) {
-  return fold_and_reduce(h, h->partL[buf].p, 27 * (size_t)h->Nc, h->partL[buf].p, 27 * (size_t)h->Nc);
+  return fold_and_reduce(h, h->partL[buf].p, nl_of(h) * (size_t)h->Nc, h->partL[buf].p, nl_of(h) * (size_t)h->Nc);
 }
 static int exchange_schur(ba_handle* h, bool with_diag) {
   if (!h->multi) return BA_OK;
   // the message starts at the u.y word in front of partition 0
-  if (int rc = fold_and_reduce(h, p6_ptr(h), 6 * (size_t)h->Nc, uy_ptr(h), 2 + 6 * (size_t)h->Nc)) return rc;
-  if (with_diag) return fold_and_reduce(h, h->partE.p, 21 * (size_t)h->Nc, h->partE.p, 21 * (size_t)h->Nc);
+  if (int rc = fold_and_reduce(h, p6_ptr(h), nb_of(h) * (size_t)h->Nc, uy_ptr(h), 2 + nb_of(h) * (size_t)h->Nc)) return rc;
+  if (with_diag) return fold_and_reduce(h, h->partE.p, nh_of(h) * (size_t)h->Nc, h->partE.p, nh_of(h) * (size_t)h->Nc);
   return BA_OK;
 }
 // finalize = true: fold the fresh camera-half partials into Hcc | bc inside the same kernel
@@ -1205,8 +1263,13 @@ static void launch_pcg_setup(ba_handle* h, double lambda, bool schur_diag, bool 
 #define SU_ARGS h->partL[h->lb].p, h->HccBc.p, bc_ptr(h), p6_ptr(h), h->partE.p, NPART, h->cs[h->cur].p, lambda,           \
                 schur_diag ? 1 : 0, h->Nc, h->fixed, h->Hccd.p, h->Minv.p, h->gvec.p, h->x.p, h->r.p, h->p.p, h->s.p,     \
                 h->z.p, h->camA[h->cur].p, h->partV.p, h->st.p, h->partGc.p, (h->two_level ? h->coarse_rc.p : (double*)nullptr)
-  if (finalize) BA_LAUNCH((k_pcg_setup<true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);
-  else          BA_LAUNCH((k_pcg_setup<false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);
+#define CALL_T(CM)                                                                                               \
+  do {                                                                                                           \
+    if (finalize) BA_LAUNCH((k_pcg_setup<CM, true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);    \
+    else          BA_LAUNCH((k_pcg_setup<CM, false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);   \
+  } while (0)
+  BA_BY_MODEL(CALL_T);
+#undef CALL_T
 #undef SU_ARGS
 }
 
@@ -1507,279 +1570,82 @@ static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// BAL 9-parameter camera: linearisation hook and the solve step (csrc/ba_bal.hpp).  Cameras (rvec, t) and points are the
-// handle's (ba_set_params / ba_get_params); the per-camera (f, k1, k2) travel with the call.  K4 of ba_set_problem is
-// not used.  Single rank.
-static int bal_alloc(ba_handle* h) {
-  const size_t Nc = (size_t)h->Nc, nbP = ((size_t)h->Np + BAL_PTS_PER_BLOCK - 1) / BAL_PTS_PER_BLOCK;
-  for (int k = 0; k < 2; ++k) HIPCHECK(h->bal_intr[k].alloc(3 * Nc));
-  HIPCHECK(h->bal_partL.alloc((size_t)NPART * Nc * BLIN));
-  HIPCHECK(h->bal_HccBc.alloc(Nc * (BH + BC)));
-  HIPCHECK(h->bal_Hd.alloc(Nc * BF));
-  HIPCHECK(h->bal_Minv.alloc(Nc * BF));
-  HIPCHECK(h->bal_part9.alloc((size_t)NPART * Nc * BC));
-  DBuf<double>* v[] = {&h->bal_x, &h->bal_r, &h->bal_z, &h->bal_p, &h->bal_q, &h->bal_vt, &h->bal_s};
-  for (auto b : v) HIPCHECK(b->alloc(Nc * BC));
-  HIPCHECK(h->bal_misc.alloc(16 + 2 * (Nc / BAL_PREP_WG + 1)));      // [0..3] spare | [4..8] camera-side step sums | [16..] cost partials of k_bal_prep
-  HIPCHECK(h->bal_partB.alloc(4 * (nbP ? nbP : 1)));
-  HIPCHECK(h->bal_partG.alloc(nbP ? nbP : 1));
-  HIPCHECK(h->bal_st.alloc(2 * sizeof(BalPcg)));
-  HIPCHECK(h->bal_partA.alloc(4 * (Nc / BAL_CAMS_PER_WG + 1)));      // gamma | zeta partials of the PCG step, two parities
+// BAL 9-parameter camera [rvec | t | f k1 k2] (BASELINE config 5 is stated on a BAL problem; the
+// reference's only camera is cv2.projectPoints(..., distCoeffs=None), src/bundle_adjuster.py:67).  Cameras (rvec, t) and
+// points are the handle's (ba_set_params / ba_get_params); the per-camera (f, k1, k2) travel with the call.  K4 of
+// ba_set_problem is not used.  The entry points switch the handle to the BalCam instantiation of every kernel
+// (ba_models.hpp) for the duration of the call: same LM / Schur / PCG loop, same device-side verdicts and speculation,
+// same multi-rank exchange, 9x9 camera blocks.
+static int bal_enter(ba_handle* h, const double* intr) {
+  HIPCHECK(hipMemcpyAsync(h->intr[h->cur].p, intr, 3 * (size_t)h->Nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  h->model = 1;
+  h->linearized = false;
+  BA_LAUNCH(k_cam_prepare<BalCam>, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->cams[h->cur].p, (const double*)h->intr[h->cur].p,
+            h->cs[h->cur].p, h->camA[h->cur].p, h->Nc);
   return BA_OK;
 }
-static int bal_nblk_pt(const ba_handle* h) { return (h->Np + BAL_PTS_PER_BLOCK - 1) / BAL_PTS_PER_BLOCK; }
-// camera half + point half at parameter set `w`
-static void bal_launch_lin(ba_handle* h, int w, bool robust, double fs) {
-  {
-    Scope sc(h, BA_K_LINEARIZE_CAM);
-    auto kc = robust ? k_bal_lin_cam<true> : k_bal_lin_cam<false>;
-    BA_LAUNCH(kc, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[w].p, h->bal_intr[w].p, h->ptab[w].p, h->offk.p, h->c_pt.p,
-              h->c_uv.p, fs, h->Nc, h->cam_band, h->fixed, h->bal_partL.p);
-  }
-  if (h->Np > 0) {
-    Scope sc(h, BA_K_LINEARIZE_PT);
-    auto kp = robust ? k_bal_lin_pt<true> : k_bal_lin_pt<false>;
-    BA_LAUNCH(kp, dim3(bal_nblk_pt(h)), dim3(BAL_PT_THREADS), 0, h->stream, h->cs[w].p, h->bal_intr[w].p, h->ptab[w].p, h->pt_off.p,
-              h->p_cam.p, h->p_uv.p, fs, h->Np, h->Hpp[0].p, h->bp[0].p, h->bal_partG.p);
-  }
+// back to the pinhole layout of the camera table (what every other entry point reads), at the current parameters
+static void bal_leave(ba_handle* h) {
+  h->model = 0;
+  h->linearized = false;                      // the linearisation buffers hold 9-parameter blocks
+  BA_LAUNCH(k_cam_prepare<Pinhole>, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->cams[h->cur].p, (const double*)h->intr[h->cur].p,
+            h->cs[h->cur].p, h->camA[h->cur].p, h->Nc);
 }
 
 extern "C" int ba_linearize_bal(ba_handle* h, const double* intr, int32_t loss, double f_scale, double* Hcc, double* bc,
                                 double* Hpp, double* bp) {
   if (!h || !intr) return fail(BA_ERR_INVALID, "null argument");
   if (!h->have_params) return fail(BA_ERR_STATE, "ba_set_problem / ba_set_params first");
-  if (h->multi) return fail(BA_ERR_STATE, "the BAL path runs on a single rank");
   if (loss != BA_LOSS_LINEAR && loss != BA_LOSS_HUBER) return fail(BA_ERR_INVALID, "unknown loss %d", loss);
   if (!(f_scale > 0)) return fail(BA_ERR_INVALID, "f_scale must be positive");
   if (set_device(h)) return BA_ERR_HIP;
-  if (int rc = bal_alloc(h)) return rc;
-  const int w = h->cur;
-  HIPCHECK(hipMemcpyAsync(h->bal_intr[w].p, intr, 3 * (size_t)h->Nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  bal_launch_lin(h, w, loss == BA_LOSS_HUBER, f_scale);
-  BA_LAUNCH(k_bal_prep, dim3((h->Nc + BAL_PREP_WG - 1) / BAL_PREP_WG), dim3(BAL_PREP_WG), 0, h->stream, h->bal_partL.p, 1, 0.0, h->Nc,
-            h->fixed, h->bal_HccBc.p, h->bal_Hd.p, h->bal_misc.p + 16);
-  h->linearized = false;                      // the 6-parameter linearisation buffers were overwritten (Hpp, bp)
-  if (Hcc || bc) {
-    std::vector<double> tmp((size_t)h->Nc * (BH + BC));
-    HIPCHECK(hipMemcpyAsync(tmp.data(), h->bal_HccBc.p, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (int rc = bal_enter(h, intr)) return rc;
+  auto body = [&]() -> int {
+    launch_lin_cam(h, h->cur, h->lb, loss == BA_LOSS_HUBER, f_scale);
+    if (int rc = exchange_partL(h, h->lb)) return rc;
+    launch_lin_finalize(h);
+    launch_lin_pt(h, h->cur, h->pb, loss == BA_LOSS_HUBER, f_scale, 1.0);
+    if (Hcc) HIPCHECK(hipMemcpyAsync(Hcc, h->HccBc.p, BalCam::NH * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (bc) HIPCHECK(hipMemcpyAsync(bc, bc_ptr(h), BalCam::NB * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if ((Hpp || bp) && h->Np) {
+      HIPCHECK(h->rbuf.alloc(6 * (size_t)h->Np));
+      if (Hpp) {
+        BA_LAUNCH(k_unpermute_rows, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp[h->pb].p, h->slot.p, h->Np, 6, h->rbuf.p);
+        HIPCHECK(hipMemcpyAsync(Hpp, h->rbuf.p, 6 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      }
+      if (bp) {
+        BA_LAUNCH(k_unpermute_rows, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->bp[h->pb].p, h->slot.p, h->Np, 3, h->stage.p);
+        HIPCHECK(hipMemcpyAsync(bp, h->stage.p, 3 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      }
+    }
     BA_SYNC(h);
-    for (int c = 0; c < h->Nc; ++c) {
-      if (Hcc) memcpy(Hcc + (size_t)c * BH, tmp.data() + (size_t)c * (BH + BC), BH * sizeof(double));
-      if (bc) memcpy(bc + (size_t)c * BC, tmp.data() + (size_t)c * (BH + BC) + BH, BC * sizeof(double));
-    }
-  }
-  if ((Hpp || bp) && h->Np) {
-    HIPCHECK(h->rbuf.alloc(6 * (size_t)h->Np));
-    if (Hpp) {
-      BA_LAUNCH(k_unpermute_rows, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp[0].p, h->slot.p, h->Np, 6, h->rbuf.p);
-      HIPCHECK(hipMemcpyAsync(Hpp, h->rbuf.p, 6 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    }
-    if (bp) {
-      BA_LAUNCH(k_unpermute_rows, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->bp[0].p, h->slot.p, h->Np, 3, h->stage.p);
-      HIPCHECK(hipMemcpyAsync(bp, h->stage.p, 3 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    }
-  }
-  BA_SYNC(h);
-  return BA_OK;
+    return BA_OK;
+  };
+  const int rc = body();
+  const std::string msg = g_err;
+  if (rc != BA_OK) { (void)hipStreamSynchronize(h->stream); h->launch_err = hipSuccess; }
+  bal_leave(h);
+  (void)hipStreamSynchronize(h->stream);
+  g_err = msg;
+  return rc;
 }
 
-static int solve_bal_impl(ba_handle* h, double* intr, const ba_options* opts, ba_summary* sum) {
-  if (!h->have_params) return fail(BA_ERR_STATE, "ba_set_problem / ba_set_params first");
-  if (h->multi) return fail(BA_ERR_STATE, "the BAL path runs on a single rank");
-  if (opts->loss != BA_LOSS_LINEAR && opts->loss != BA_LOSS_HUBER) return fail(BA_ERR_INVALID, "unknown loss");
-  if (!(opts->f_scale > 0) || opts->max_iters < 0 || opts->pcg_max_iters < 1 || !(opts->initial_lambda > 0))
-    return fail(BA_ERR_INVALID, "bad options");
-  if (set_device(h)) return BA_ERR_HIP;
-  if (int rc = bal_alloc(h)) return rc;
-  memset(sum, 0, sizeof *sum);
-  h->trace.clear();
-  h->linearized = false;
-  const bool robust = opts->loss == BA_LOSS_HUBER;
-  const bool schur_diag = opts->preconditioner != BA_PRECOND_JACOBI;      // (two-level is a 6-parameter feature: Schur-Jacobi here)
-  const double fs = opts->f_scale, tol2 = opts->pcg_tol * opts->pcg_tol;
-  const int Nc = h->Nc, nbP = bal_nblk_pt(h), n_prep = (Nc + BAL_PREP_WG - 1) / BAL_PREP_WG;
-  const int nwg = (Nc + BAL_CAMS_PER_WG - 1) / BAL_CAMS_PER_WG;              // workgroups of the PCG step kernel
-  std::vector<double> cost_part(2 * (size_t)n_prep);
-  double* const hs = h->h_scal + 32;                     // host-mapped results of this path: 16 doubles
-  double* const ds = h->d_scal_host + 32;
-  long long* const dflag = h->d_flags + 6;
-  const double t_begin = now_s();
-  HIPCHECK(hipMemcpyAsync(h->bal_intr[h->cur].p, intr, 3 * (size_t)Nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
-
-  double lambda = opts->initial_lambda, nu = 2.0, cost = 0.0, sse = 0.0;
-  int it = 0, acc_n = 0, status = 0;
-  bool need_lin = true;
-  if (h->Np == 0 || h->Nobs == 0) { sum->status = 1; return BA_OK; }
-  while (it < opts->max_iters || it == 0) {
-    const int cur = h->cur, tr = 1 - cur;
-    const double t0 = now_s();
-    if (need_lin) bal_launch_lin(h, cur, robust, fs);
-    {
-      Scope sc(h, BA_K_PRECOND);
-      BA_LAUNCH(k_bal_prep, dim3(n_prep), dim3(BAL_PREP_WG), 0, h->stream, h->bal_partL.p, need_lin ? 1 : 0, lambda, Nc, h->fixed,
-                h->bal_HccBc.p, h->bal_Hd.p, h->bal_misc.p + 16);
-      BA_LAUNCH(k_point_invert, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->Hpp[0].p, h->bp[0].p, lambda, h->Np, h->Hppinv[0].p,
-                h->y0[0].p, h->ptab[cur].p);
-      if (schur_diag) {                                   // partL is free again: k_bal_prep has folded it into HccBc
-        auto ks = robust ? k_bal_cam_sdiag<true> : k_bal_cam_sdiag<false>;
-        BA_LAUNCH(ks, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->offk.p,
-                  h->c_pt.p, h->c_uv.p, fs, Nc, h->cam_band, h->fixed, h->Hppinv[0].p, h->bal_partL.p);
-      }
-      BA_LAUNCH(k_bal_minv, dim3((Nc + 255) / 256), dim3(256), 0, h->stream, h->bal_Hd.p,
-                schur_diag ? (const double*)h->bal_partL.p : (const double*)nullptr, Nc, h->fixed, h->bal_Minv.p);
-    }
-    {                                                   // W y0 -> right-hand side, PCG start
-      Scope sc(h, BA_K_SCHUR_CAM);
-      auto kc = robust ? k_bal_cam_schur<true> : k_bal_cam_schur<false>;
-      BA_LAUNCH(kc, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->offk.p,
-                h->c_pt.p, h->c_uv.p, fs, Nc, h->cam_band, h->fixed, h->bal_part9.p, (const BalPcg*)nullptr, (const double*)nullptr, 0,
-                (double*)nullptr);
-    }
-    long long seq = ++h->bal_seq;
-    if (it == 0 && need_lin)                            // initial cost rides along: the camera half summed r^2 and the rho terms
-      HIPCHECK(hipMemcpyAsync(cost_part.data(), h->bal_misc.p + 16, cost_part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    {
-      Scope sc(h, BA_K_PCG_UPDATE);
-      BA_LAUNCH(k_bal_pcg_init, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->bal_HccBc.p, h->bal_part9.p, h->bal_Hd.p, h->bal_Minv.p,
-                h->bal_partG.p, nbP, Nc, h->fixed, h->bal_x.p, h->bal_r.p, h->bal_z.p, h->bal_p.p, h->bal_s.p, (BalPcg*)h->bal_st.p,
-                h->bal_partA.p, nwg, ds, dflag, seq, (const double*)h->cs[cur].p, h->bal_vt.p);
-    }
-    if (int rc = wait_flag(h, 6, seq)) return rc;
-    if (it == 0) {
-      BA_SYNC(h);                                       // the cost partials (a copy, not a mapped store)
-      double s0 = 0.0, s1 = 0.0;
-      for (int w = 0; w < n_prep; ++w) { s0 += cost_part[2 * w]; s1 += cost_part[2 * w + 1]; }
-      sse = s0; cost = 0.5 * s1;
-      sum->initial_sse = sse; sum->initial_cost = cost;
-      if (!std::isfinite(cost)) return fail(BA_ERR_NUMERIC, "non-finite cost at the initial parameters");
-      if (opts->max_iters == 0) break;
-    }
-    const double rz0 = hs[0], gmax = hs[1];
-    if (!std::isfinite(gmax)) return fail(BA_ERR_NUMERIC, "non-finite gradient at LM iteration %d", it + 1);
-    if (need_lin && gmax <= opts->gtol) { status = 3; break; }
-    const double t1 = now_s();
-    sum->seconds_linearize += t1 - t0;
-    // ---- PCG on the reduced camera system: iteration k + 1 is queued before k's verdict is read (kernels queued past
-    //      the end find the state's done flag and return), so the device never waits for the host
-    int k = 0;
-    if (rz0 > 0.0) {
-      auto kp = robust ? k_bal_pt_schur<true, 0> : k_bal_pt_schur<false, 0>;
-      auto kc = robust ? k_bal_cam_schur<true> : k_bal_cam_schur<false>;
-      BalPcg* st = (BalPcg*)h->bal_st.p;
-      double* uy = h->bal_misc.p + 9;
-      const long long base4 = (h->bal_seq / 4 + 1) * 4;   // verdict words: base4 + 4 (k + 1) + verdict, above every word published so far
-      int enq = -1;
-      auto enqueue = [&](int kk) {                        // S z_kk by the two passes, then the step that uses it
-        enq = kk;
-        {
-          Scope sc(h, BA_K_SCHUR_PT);
-          BA_LAUNCH(kp, dim3(nbP), dim3(BAL_PT_THREADS), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->pt_off.p,
-                    h->p_cam.p, h->p_uv.p, fs, h->Np, h->fixed, h->bal_vt.p, h->Hppinv[0].p, h->y0[0].p, h->Hpp[0].p, h->bp[0].p,
-                    (double*)nullptr, h->bal_partB.p, (const BalPcg*)(st + (kk & 1)));
-        }
-        {
-          Scope sc(h, BA_K_SCHUR_CAM);
-          BA_LAUNCH(kc, dim3(cam_grid(h) + 1), dim3(64 * WPB), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->offk.p,
-                    h->c_pt.p, h->c_uv.p, fs, Nc, h->cam_band, h->fixed, h->bal_part9.p, (const BalPcg*)(st + (kk & 1)),
-                    (const double*)h->bal_partB.p, nbP, uy);
-        }
-        Scope sc(h, BA_K_PCG_UPDATE);
-        BA_LAUNCH(k_bal_cg_step, dim3(nwg), dim3(BAL_VEC_WG), 0, h->stream, kk, st, h->bal_Hd.p, h->bal_Minv.p, h->bal_part9.p,
-                  (const double*)uy, (const double*)(h->bal_partA.p + 2 * nwg * (kk & 1)), nwg, Nc, h->fixed, tol2, opts->pcg_min_iters,
-                  h->bal_x.p, h->bal_r.p, h->bal_p.p, h->bal_s.p, h->bal_z.p, h->bal_partA.p + 2 * nwg * ((kk + 1) & 1), dflag, base4,
-                  (const double*)h->cs[cur].p, h->bal_vt.p);
-      };
-      enqueue(0);
-      while (true) {
-        if (k + 1 < opts->pcg_max_iters) enqueue(k + 1);
-        if (int rc = wait_flag(h, 6, base4 + 4 * (long long)(k + 1))) return rc;
-        const long long word = h->h_flags[6] - base4;     // a later step may have published already: then this one said "go on"
-        const int verdict = (word / 4 == k + 1) ? (int)(word % 4) : 1;
-        if (verdict != 1) break;                          // converged after k iterations / broke down: k iterations stand
-        ++k;
-        if (k >= opts->pcg_max_iters) break;
-      }
-      h->bal_seq = base4 + 4 * (long long)(enq + 2);      // past every word a queued iteration can still publish
-    }
-    sum->pcg_iterations += k;
-    const double t2 = now_s();
-    sum->seconds_pcg += t2 - t1;
-    // ---- step: trial cameras, back substitution, trial cost, sums to the host
-    {
-      Scope sc(h, BA_K_MISC);
-      BA_LAUNCH(k_bal_update, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->cams[cur].p, h->bal_intr[cur].p, h->bal_x.p, h->bal_r.p,
-                h->bal_HccBc.p, Nc, h->fixed, h->cams[tr].p, h->bal_intr[tr].p, h->cs[tr].p, h->bal_misc.p + 4,
-                (const double*)h->cs[cur].p, h->bal_vt.p);
-    }
-    {
-      Scope sc(h, BA_K_BACKSUB);
-      auto kb = robust ? k_bal_pt_schur<true, 1> : k_bal_pt_schur<false, 1>;
-      BA_LAUNCH(kb, dim3(nbP), dim3(BAL_PT_THREADS), 0, h->stream, h->cs[cur].p, h->bal_intr[cur].p, h->ptab[cur].p, h->pt_off.p, h->p_cam.p,
-                h->p_uv.p, fs, h->Np, h->fixed, h->bal_vt.p, h->Hppinv[0].p, h->y0[0].p, h->Hpp[0].p, h->bp[0].p, h->ptab[tr].p,
-                h->bal_partB.p, (const BalPcg*)nullptr);
-    }
-    {
-      Scope sc(h, BA_K_RESIDUAL);
-      auto kr = robust ? k_cam_residual_bal<true> : k_cam_residual_bal<false>;
-      BA_LAUNCH(kr, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[tr].p, (const double*)h->bal_intr[tr].p, h->ptab[tr].p,
-                h->offk.p, h->c_pt.p, h->c_uv.p, h->c_orig.p, fs, Nc, h->cam_band, (double*)nullptr, h->partR.p);
-    }
-    seq = ++h->bal_seq;
-    BA_LAUNCH(k_bal_step_sums, dim3(1), dim3(BAL_VEC_THREADS), 0, h->stream, h->bal_misc.p + 4, h->bal_partB.p, nbP, h->partR.p, Nc, ds, dflag, seq);
-    if (int rc = wait_flag(h, 6, seq)) return rc;
-    // ---- verdict, the rules of ba_solve / oracle.lm_solve
-    const double gTd = hs[0] + hs[5], dDd = hs[1] + hs[6], step2 = hs[2] + hs[7], x2 = hs[3] + hs[8], dcr = hs[4];
-    const double sse_new = hs[9], cost_new = 0.5 * hs[10];
-    const double model = 0.5 * (lambda * dDd - gTd + dcr);
-    const double rho = (model > 0.0 && std::isfinite(cost_new)) ? (cost - cost_new) / model : -1.0;
-    ++it;
-    ba_iter_record rec;
-    memset(&rec, 0, sizeof rec);
-    rec.iteration = it; rec.accepted = (rho > 0.0 && std::isfinite(cost_new)) ? 1 : 0; rec.pcg_iterations = k;
-    rec.cost = cost; rec.cost_trial = cost_new; rec.sse_trial = sse_new; rec.lambda = lambda; rec.gain_ratio = rho;
-    rec.step_norm = std::sqrt(step2); rec.seconds = now_s() - t0;
-    h->trace.push_back(rec);
-    bool stop = false;
-    if (rec.accepted) {
-      const double dcost = cost - cost_new;
-      h->cur = tr;
-      cost = cost_new; sse = sse_new;
-      ++acc_n;
-      const double t = 2.0 * rho - 1.0;
-      lambda = std::max(lambda * std::max(1.0 / 3.0, 1.0 - t * t * t), 1e-12);
-      nu = 2.0;
-      need_lin = true;
-      if (dcost <= opts->ftol * cost_new) { status = 1; stop = true; }
-    } else {
-      if (!std::isfinite(cost_new) && lambda >= 1e12)
-        return fail(BA_ERR_NUMERIC, "non-finite trial cost up to the largest damping (LM iteration %d)", it);
-      lambda = std::min(lambda * nu, 1e12);
-      nu *= 2.0;
-      need_lin = false;
-    }
-    sum->seconds_update += now_s() - t2;
-    if (!stop && std::sqrt(step2) <= opts->xtol * (opts->xtol + std::sqrt(x2))) { status = 2; stop = true; }
-    if (stop) break;
-    if (it >= opts->max_iters) { status = 0; break; }
-  }
-  // the multi-kernel entry points read the packed camera table of the current set: rebuild it from the result
-  BA_LAUNCH(k_cam_prepare, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->cams[h->cur].p, h->cs[h->cur].p, h->camA[h->cur].p, h->Nc);
-  HIPCHECK(hipMemcpyAsync(intr, h->bal_intr[h->cur].p, 3 * (size_t)Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  BA_SYNC(h);
-  sum->iterations = it; sum->accepted = acc_n; sum->status = status;
-  sum->final_sse = sse; sum->final_cost = cost; sum->final_lambda = lambda;
-  sum->seconds_total = now_s() - t_begin;
-  return BA_OK;
-}
-
+static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum);
 extern "C" int ba_solve_bal(ba_handle* h, double* intr, const ba_options* opts, ba_summary* sum) {
   if (!h || !intr || !opts || !sum) return fail(BA_ERR_INVALID, "null argument");
-  const int rc = solve_bal_impl(h, intr, opts, sum);
-  if (rc != BA_OK) {                                   // leave the handle usable: drain the stream, forget what was half done
-    (void)hipStreamSynchronize(h->stream);
-    h->launch_err = hipSuccess;
-    h->linearized = false;
-  }
+  if (!h->have_params) return fail(BA_ERR_STATE, "ba_set_problem / ba_set_params first");
+  if (set_device(h)) return BA_ERR_HIP;
+  if (int rc = bal_enter(h, intr)) { h->model = 0; return rc; }
+  int rc = ba_solve(h, opts, sum);            // (ba_solve drains the stream and clears the per-solve modes on failure)
+  const std::string msg = g_err;
+  // the adjusted (f, k1, k2) of the accepted parameter set -- also after a failed solve: the last accepted step stands
+  if (hipMemcpyAsync(intr, h->intr[h->cur].p, 3 * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess && rc == BA_OK)
+    rc = fail(BA_ERR_HIP, "copying the intrinsics back failed");
+  // a failure in the middle of the loop may have left the camera state of the current set behind its parameters
+  // (k_cam_update writes both for the TRIAL set; the current set is always complete) -- rebuilt here either way
+  bal_leave(h);
+  if (hipStreamSynchronize(h->stream) != hipSuccess && rc == BA_OK) rc = fail(BA_ERR_HIP, "stream synchronise failed");
+  if (rc != BA_OK && !msg.empty()) g_err = msg;
   return rc;
 }
 
@@ -1798,8 +1664,9 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   // above) have nothing to act on, and no per-solve mode of the multi-kernel path is left switched on behind it
   h->jac_f32 = false;
   h->two_level = false;
-  if (small_applies(h, opts)) return small_solve(h, opts, sum);
-  if (opts->preconditioner == BA_PRECOND_TWO_LEVEL && !h->two_level_ok)
+  if (h->model == 0 && small_applies(h, opts)) return small_solve(h, opts, sum);
+  // (the coarse level is built for the pinhole's 6x6 blocks; the BAL camera runs Schur-Jacobi under that option)
+  if (h->model == 0 && opts->preconditioner == BA_PRECOND_TWO_LEVEL && !h->two_level_ok)
     return fail(BA_ERR_STATE, "the two-level preconditioner needs a band-structured problem on a single rank "
                               "(ba_set_problem found none for this one)");
   h->jac_f32 = opts->jacobian_precision == 1;
@@ -1807,7 +1674,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   Range r_solve("ba_solve");
   const bool robust = opts->loss == BA_LOSS_HUBER;
   const bool schur_diag = opts->preconditioner != BA_PRECOND_JACOBI;
-  h->two_level = opts->preconditioner == BA_PRECOND_TWO_LEVEL;
+  h->two_level = opts->preconditioner == BA_PRECOND_TWO_LEVEL && h->model == 0;
   const double fs = opts->f_scale;
   const int Nc = h->Nc;
   h->profile = opts->profile != 0;
@@ -1896,12 +1763,14 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
                   opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA[h->cur].p, h->partV.p, h->nblkV, h->st.p, \
                   h->d_flags, base, (const double*)h->verdict.p
       if (h->two_level) {
-        BA_LAUNCH(k_pcg_step<true>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, h->coarse_rc.p);
+        BA_LAUNCH((k_pcg_step<Pinhole, true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, h->coarse_rc.p);
         BA_LAUNCH(k_pcg_coarse, dim3(h->n_agg), dim3(VEC_BLOCK), 0, h->stream, kk, (const double*)h->coarseEinv.p,
                   (const double*)h->coarse_rc.p, h->n_agg, (const double*)h->Hccd.p, (const double*)h->cs[h->cur].p, Nc, h->fixed,
                   (const double*)h->r.p, h->z.p, h->camA[h->cur].p, h->partV.p, h->nblkV, (const double*)h->verdict.p, 1);
+      } else if (h->model) {
+        BA_LAUNCH((k_pcg_step<BalCam, false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, (double*)nullptr);
       } else {
-        BA_LAUNCH(k_pcg_step<false>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, (double*)nullptr);
+        BA_LAUNCH((k_pcg_step<Pinhole, false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, (double*)nullptr);
       }
 #undef STEP_ARGS
       return BA_OK;
@@ -1931,9 +1800,11 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     Range r_step("step");
     {
       Scope sc(h, BA_K_MISC);
-      BA_LAUNCH(k_cam_update, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->cams[h->cur].p, h->x.p, h->r.p,
-                         h->HccBc.p, bc_ptr(h), h->cs[h->cur].p, Nc, h->fixed, h->cams[1 - h->cur].p, h->cs[1 - h->cur].p,
-                         h->camA[h->cur].p, h->camA[1 - h->cur].p, h->partC.p);
+#define UPD_ARGS h->cams[h->cur].p, (const double*)h->intr[h->cur].p, h->x.p, h->r.p, h->HccBc.p, bc_ptr(h), h->cs[h->cur].p, Nc, h->fixed, \
+                 h->cams[1 - h->cur].p, h->intr[1 - h->cur].p, h->cs[1 - h->cur].p, h->camA[h->cur].p, h->camA[1 - h->cur].p, h->partC.p
+      if (h->model) BA_LAUNCH(k_cam_update<BalCam>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, UPD_ARGS);
+      else          BA_LAUNCH(k_cam_update<Pinhole>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, UPD_ARGS);
+#undef UPD_ARGS
     }
     launch_pt_schur(h, robust, 1, 0, 0.0, 0);
     // Speculation: unless this is the last iteration, the cost at the trial point comes out of the camera half of

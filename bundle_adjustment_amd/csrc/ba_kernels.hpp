@@ -30,6 +30,7 @@
 #pragma once
 #include "ba_device.hpp"
 #include "ba_dpp.hpp"
+#include "ba_models.hpp"
 
 namespace ba {
 
@@ -53,7 +54,8 @@ __device__ int g_dbg_mode;      // diagnostic variants of the camera pass's gath
 constexpr int NPART = 8;         // point partitions (= XCDs)
 constexpr int WPB = 4;           // waves (= cameras) per workgroup in camera passes
 constexpr int PT = 8;            // doubles per point record
-constexpr int TA = 18;           // doubles per camera in camA: R[9] t[3] vtil[6]
+constexpr int TA = Pinhole::TA;  // doubles per camera in camA, the reference's pinhole: R[9] t[3] vtil[6]
+constexpr int TA_MAX = BalCam::TA; // the widest row of any camera model (ba_models.hpp): what the table buffers are sized for
 constexpr int PT_THREADS = 1024; // threads per workgroup in point passes
 constexpr int LPP = 2;           // lanes per point in point passes (short tracks)
 constexpr int LPP_LONG = 16;     // one DPP row per point for long tracks (threshold chosen per problem)
@@ -98,12 +100,13 @@ enum { S_SSE = 0, S_RHO = 1, S_PT_GD = 2, S_PT_DDD = 3, S_PT_DD = 4, S_PT_XX = 5
 // -------------------------------------------------------------------------------------
 // small per-camera / per-point kernels
 // -------------------------------------------------------------------------------------
-__global__ void k_cam_prepare(const double* __restrict__ cams, double* __restrict__ cs, double* __restrict__ camA,
-                              int n_cams) {
+template <class CM>
+__global__ void k_cam_prepare(const double* __restrict__ cams, const double* __restrict__ intr, double* __restrict__ cs,
+                              double* __restrict__ camA, int n_cams) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= n_cams) return;
   camera_state(cams + 6 * c, cs + CS * c);
-  for (int q = 0; q < 12; ++q) camA[TA * c + q] = cs[CS * c + q];
+  CM::table_row(cs + CS * c, intr + 3 * (size_t)c, camA + CM::TA * (size_t)c);      // (the pinhole ignores intr)
 }
 
 // In-place fold of nparts per-partition partial-sum arrays of n values each (multi-rank jobs, ahead of
@@ -272,60 +275,66 @@ __device__ inline void cam_jac_rows(const Geom& g, double X0, double X1, double 
   J1[3] = 0.0;    J1[4] = -g.d11; J1[5] = -g.d12;
 }
 
-// symmetric congruence H = T^T A T, T = diag(M, I6-3), A given as full 6x6
-__device__ inline void m_congruence(const double* __restrict__ M, double (&A)[6][6]) {
-  double B[6][6];
-  for (int i = 0; i < 6; ++i) {
+// symmetric congruence H = T^T A T, T = diag(M, I(NB-3)), A given as full NB x NB
+template <int NB>
+__device__ inline void m_congruence(const double* __restrict__ M, double (&A)[NB][NB]) {
+  double B[NB][NB];
+  for (int i = 0; i < NB; ++i) {
     for (int j = 0; j < 3; ++j) B[i][j] = A[i][0] * M[j] + A[i][1] * M[3 + j] + A[i][2] * M[6 + j];
-    for (int j = 3; j < 6; ++j) B[i][j] = A[i][j];
+    for (int j = 3; j < NB; ++j) B[i][j] = A[i][j];
   }
-  for (int j = 0; j < 6; ++j) {
+  for (int j = 0; j < NB; ++j) {
     const double h0 = M[0] * B[0][j] + M[3] * B[1][j] + M[6] * B[2][j];
     const double h1 = M[1] * B[0][j] + M[4] * B[1][j] + M[7] * B[2][j];
     const double h2 = M[2] * B[0][j] + M[5] * B[1][j] + M[8] * B[2][j];
     A[0][j] = h0; A[1][j] = h1; A[2][j] = h2;
-    A[3][j] = B[3][j]; A[4][j] = B[4][j]; A[5][j] = B[5][j];
+    for (int i = 3; i < NB; ++i) A[i][j] = B[i][j];
   }
 }
 
 // Combine the NPART partial sums of k_camrow_linearize (fixed order), apply M:
-//   Hcc[c] (21) = Jc^T w Jc,  bc[c] (6) = Jc^T w r  (zero for the fixed camera).
-// a[27] = the camera's pre-M sums (21 of Jc^T w Jc, upper triangle; 6 of Jc^T w r), M from its state
+//   Hcc[c] (NH) = Jc^T w Jc,  bc[c] (NB) = Jc^T w r  (zero for the fixed camera).
+// a[NH + NB] = the camera's pre-M sums (NH of Jc^T w Jc, upper triangle; NB of Jc^T w r), M from its state
+template <int NB>
 __device__ inline void lin_finalize_sums(const double* __restrict__ a, const double* __restrict__ M, bool fixed,
                                          double* __restrict__ H, double* __restrict__ b) {
+  constexpr int NH = NB * (NB + 1) / 2;
   if (fixed) {
-    for (int q = 0; q < 21; ++q) H[q] = 0.0;
-    for (int q = 0; q < 6; ++q) b[q] = 0.0;
+    for (int q = 0; q < NH; ++q) H[q] = 0.0;
+    for (int q = 0; q < NB; ++q) b[q] = 0.0;
     return;
   }
-  double A[6][6];
-  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) A[i][j] = a[S6(i, j)];
-  m_congruence(M, A);
-  for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) H[U6(i, j)] = A[i][j];
-  b[0] = M[0] * a[21] + M[3] * a[22] + M[6] * a[23];
-  b[1] = M[1] * a[21] + M[4] * a[22] + M[7] * a[23];
-  b[2] = M[2] * a[21] + M[5] * a[22] + M[8] * a[23];
-  b[3] = a[24]; b[4] = a[25]; b[5] = a[26];
+  double A[NB][NB];
+  for (int i = 0; i < NB; ++i) for (int j = 0; j < NB; ++j) A[i][j] = a[ST(NB, i, j)];
+  m_congruence<NB>(M, A);
+  for (int i = 0; i < NB; ++i) for (int j = i; j < NB; ++j) H[UT(NB, i, j)] = A[i][j];
+  b[0] = M[0] * a[NH] + M[3] * a[NH + 1] + M[6] * a[NH + 2];
+  b[1] = M[1] * a[NH] + M[4] * a[NH + 1] + M[7] * a[NH + 2];
+  b[2] = M[2] * a[NH] + M[5] * a[NH + 1] + M[8] * a[NH + 2];
+  for (int q = 3; q < NB; ++q) b[q] = a[NH + q];
 }
+template <int NB>
 __device__ inline void lin_finalize_camera(const double* __restrict__ partL, const double* __restrict__ cam, int n_cams,
                                            int c, int fixed_cam, double* __restrict__ H, double* __restrict__ b) {
-  double a[27];
-  for (int q = 0; q < 27; ++q) a[q] = 0.0;
+  constexpr int NL = NB * (NB + 1) / 2 + NB;
+  double a[NL];
+  for (int q = 0; q < NL; ++q) a[q] = 0.0;
   if (c != fixed_cam) {
     for (int k = 0; k < NPART; ++k) {
-      const double* src = partL + ((size_t)k * n_cams + c) * 27;
-      for (int q = 0; q < 27; ++q) a[q] += src[q];
+      const double* src = partL + ((size_t)k * n_cams + c) * NL;
+      for (int q = 0; q < NL; ++q) a[q] += src[q];
     }
   }
-  lin_finalize_sums(a, cam + 12, c == fixed_cam, H, b);
+  lin_finalize_sums<NB>(a, cam + 12, c == fixed_cam, H, b);
 }
 // stand-alone form (multi-rank jobs all-reduce Hcc|bc between this and k_pcg_setup; test hook)
+template <int NB>
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_lin_finalize(const double* __restrict__ partL, const double* __restrict__ cs, int n_cams, int fixed_cam,
                double* __restrict__ Hcc, double* __restrict__ bc) {
   const int c = vec_camera(n_cams);
   if (c >= n_cams) return;
-  lin_finalize_camera(partL, cs + CS * c, n_cams, c, fixed_cam, Hcc + 21 * c, bc + 6 * c);
+  lin_finalize_camera<NB>(partL, cs + CS * c, n_cams, c, fixed_cam, Hcc + (NB * (NB + 1) / 2) * (size_t)c, bc + NB * (size_t)c);
 }
 
 // K4b: camera pass of the Schur product, pre-M:  part6[(k*Nc + c)*6 + ..] = sum Jc^T w (Jp y_p)
@@ -381,13 +390,14 @@ __device__ inline double seg_sum_dpp(double x) {    // the last lane of every SE
   if (SEGL == 64) x += dpp_f64<DPP_ROW_BCAST31, 0xc>(x);
   return x;
 }
-template <bool ROBUST, bool PCG, typename JT, int SEGL>
+template <class CM, bool ROBUST, bool PCG, typename JT, int SEGL>
 __global__ void __launch_bounds__(64 * WPB)
-k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
-            const int* __restrict__ c_pt, const double2* __restrict__ c_w,
+k_cam_schur(const double* __restrict__ cs, const double* __restrict__ intr, const double* __restrict__ ptab,
+            const int* __restrict__ offk, const int* __restrict__ c_pt, const double2* __restrict__ c_w,
             double fx, double fy, int n_cams, int band, int fixed_cam, double* __restrict__ part6,
             int kit, const double* __restrict__ verdict, const double* __restrict__ partA, int nblkA,
             double* __restrict__ uy) {
+  constexpr int NB = CM::NB;
   static_assert(SEGL == 16 || SEGL == 32 || SEGL == 64, "16, 32 or 64 lanes per segment");
   constexpr int CPB = 64 * WPB / SEGL;         // cameras per workgroup
   // segment bounds and camera state are fetched before the PCG verdict is known: one round trip
@@ -401,15 +411,13 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
   const int lane = threadIdx.x % SEGL;
   const bool live = !extra && c < n_cams;
   int beg = 0, end = 0;
-  JT cam[12];                                  // Jacobian blocks in JT (double, or float for config 5)
+  JT cam[CM::CAM];                             // Jacobian blocks in JT (double, or float for config 5)
 #pragma unroll
-  for (int q = 0; q < 12; ++q) cam[q] = (JT)0;
+  for (int q = 0; q < CM::CAM; ++q) cam[q] = (JT)0;
   if (live) {
     beg = offk[c * (NPART + 1) + k];
     end = offk[c * (NPART + 1) + k + 1];
-    const double* camd = cs + CS * c;
-#pragma unroll
-    for (int q = 0; q < 12; ++q) cam[q] = (JT)camd[q];
+    CM::template load_cam<JT>(cs, intr, c, cam);
   }
   if (PCG) {
     double g, z;
@@ -428,7 +436,9 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
   if (SEGL == 64 && !live) return;             // (narrower segments: dead lanes idle through the reduction)
   if (PCG) BA_STAMP(1, 2);
   const JT fxj = (JT)fx, fyj = (JT)fy;
-  double acc[6] = {0, 0, 0, 0, 0, 0};          // sums always in fp64
+  double acc[NB];                              // sums always in fp64
+#pragma unroll
+  for (int q = 0; q < NB; ++q) acc[q] = 0.0;
   if (live && c != fixed_cam) {
     int i = beg + lane;
     int pf = (i < end) ? c_pt[i] : 0;          // ROBUST: the flagged copy of c_pt
@@ -451,27 +461,22 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ ptab, cons
       double2 wn = make_double2(1.0, 1.0);                 // next weight, only where it is not (1, 1)
       if (ROBUST && pn < 0) wn = c_w[in];
       const JT X0 = (JT)Xd.x, X1 = (JT)Xd.y, X2 = (JT)Xd.z, Y0 = (JT)Yd.x, Y1 = (JT)Yd.y, Y2 = (JT)Yd.z;
-      GeomT<JT> g;
-      obs_geom_fast<JT>(cam, X0, X1, X2, fxj, fyj, g);
-      const JT s0 = -(g.P[0] * Y0 + g.P[1] * Y1 + g.P[2] * Y2) * (JT)w.x;
-      const JT s1 = -(g.P[3] * Y0 + g.P[4] * Y1 + g.P[5] * Y2) * (JT)w.y;
-      const JT e0 = g.P[0] * s0 + g.P[3] * s1, e1 = g.P[1] * s0 + g.P[4] * s1, e2 = g.P[2] * s0 + g.P[5] * s1;
-      acc[0] += (double)(e1 * X2 - e2 * X1);
-      acc[1] += (double)(e2 * X0 - e0 * X2);
-      acc[2] += (double)(e0 * X1 - e1 * X0);
-      acc[3] -= (double)(g.d00 * s0);
-      acc[4] -= (double)(g.d11 * s1);
-      acc[5] -= (double)(g.d02 * s0 + g.d12 * s1);
+      typename CM::template Obs<JT> g;
+      CM::template geom<true, JT, JT>(cam, X0, X1, X2, fxj, fyj, g);
+      const JT* Pm = CM::pm(g);
+      const JT s0 = -(Pm[0] * Y0 + Pm[1] * Y1 + Pm[2] * Y2) * (JT)w.x;       // w (Jp y), Jp = -Pm
+      const JT s1 = -(Pm[3] * Y0 + Pm[4] * Y1 + Pm[5] * Y2) * (JT)w.y;
+      CM::jct_accumulate(g, X0, X1, X2, s0, s1, acc);
       i = in; pf = pn; w = wn;
     }
   }
   if (PCG) BA_STAMP(1, 3);
 #pragma unroll
-  for (int q = 0; q < 6; ++q) acc[q] = seg_sum_dpp<SEGL>(acc[q]);
+  for (int q = 0; q < NB; ++q) acc[q] = seg_sum_dpp<SEGL>(acc[q]);
   if (live && lane == SEGL - 1) {
-    double* dst = part6 + ((size_t)k * n_cams + c) * 6;
+    double* dst = part6 + ((size_t)k * n_cams + c) * NB;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) dst[q] = acc[q];
+    for (int q = 0; q < NB; ++q) dst[q] = acc[q];
   }
   if (PCG) { BA_STAMP(1, 6); BA_STAMP(1, 7); }
 }
@@ -504,32 +509,28 @@ __device__ inline double row_sum_dpp(double x) {     // the last lane of every s
   if (ROW_LANES == 32) x += dpp_f64<DPP_ROW_BCAST15, 0xa>(x);     // odd rows add the total of the row before
   return x;
 }
-__device__ inline void load_cam12(const double* __restrict__ cs, int c, double (&cam)[12]) {
-  const double2* cp = (const double2*)(cs + CS * (size_t)c);
-#pragma unroll
-  for (int q = 0; q < 6; ++q) { const double2 t = cp[q]; cam[2 * q] = t.x; cam[2 * q + 1] = t.y; }
-}
 
 // K2a: camera half of the normal equations, pre-M: partL[(k*Nc + c)*27 ..] = 21 sums of Jc^T w Jc (upper triangle), 6 of Jc^T w r;
 // IRLS weights and flagged indices of camera-ordered observations when ROBUST
 // COST: also the cost partials of K1 (partR[(k*Nc + c)*2 + {0,1}] = sum r^2, sum rho-term), so that the pass at a
 // TRIAL point is the trial-cost evaluation and the camera half of the next linearisation in one (ba_solve).
-template <bool ROBUST, bool COST>
+template <class CM, bool ROBUST, bool COST>
 __global__ void __launch_bounds__(ROW_LANES * ROWS)
-k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
-                   const int* __restrict__ c_pt, const double2* __restrict__ c_uv,
+k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ intr, const double* __restrict__ ptab,
+                   const int* __restrict__ offk, const int* __restrict__ c_pt, const double2* __restrict__ c_uv,
                    double fx, double fy, double cx, double cy, double hub_c, int n_cams, int band,
                    double2* __restrict__ c_w, int* __restrict__ c_ptf, double* __restrict__ partL,
                    double* __restrict__ partR) {
+  constexpr int NB = CM::NB, NH = CM::NH, NL = CM::NL;
   RowSeg s;
   row_segment(offk, n_cams, band, s);
-  constexpr int NACC = COST ? 29 : 27;
+  constexpr int NACC = COST ? NL + 2 : NL;
   double acc[NACC];
 #pragma unroll
   for (int q = 0; q < NACC; ++q) acc[q] = 0.0;
   if (s.live) {
-    double cam[12];
-    load_cam12(cs, s.c, cam);
+    double cam[CM::CAM];
+    CM::load_cam_vec(cs, intr, s.c, cam);
     int i = s.beg + s.l16;
     int p = (i < s.end) ? c_pt[i] : 0;
     double2 uv = (i < s.end) ? c_uv[i] : make_double2(0, 0);
@@ -538,62 +539,63 @@ k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ pta
       const int pn = (in < s.end) ? c_pt[in] : 0;
       const double2 uvn = (in < s.end) ? c_uv[in] : make_double2(0, 0);
       const double4 X = *(const double4*)(ptab + PT * (size_t)p);
-      Geom g;
-      obs_geom(cam, X.x, X.y, X.z, fx, fy, g);
-      const double ru = uv.x - (g.xh * fx + cx);
-      const double rv = uv.y - (g.yh * fy + cy);
+      typename CM::template Obs<double> g;
+      CM::template geom<false, double, double>(cam, X.x, X.y, X.z, fx, fy, g);
+      double ru, rv;
+      CM::residual(g, uv.x, uv.y, fx, fy, cx, cy, ru, rv);
       double w0 = 1.0, w1 = 1.0;
-      if (COST) acc[27] += ru * ru + rv * rv;
+      if (COST) acc[NL] += ru * ru + rv * rv;
       if (ROBUST) {
         double t0, t1;
         huber(ru, hub_c, t0, w0);
         huber(rv, hub_c, t1, w1);
-        if (COST) acc[28] += t0 + t1;
+        if (COST) acc[NL + 1] += t0 + t1;
         const int pfl = flagged_index(p, w0, w1);
         c_ptf[i] = pfl;
         if (pfl < 0) c_w[i] = make_double2(w0, w1);        // unflagged weights are never read
       }
-      double J0[6], J1[6];
-      cam_jac_rows(g, X.x, X.y, X.z, J0, J1);
+      double J0[NB], J1[NB];
+      CM::jac_rows(g, X.x, X.y, X.z, J0, J1);
 #pragma unroll
-      for (int a = 0; a < 6; ++a) {
+      for (int a = 0; a < NB; ++a) {
         const double wa0 = w0 * J0[a], wa1 = w1 * J1[a];
 #pragma unroll
-        for (int b = a; b < 6; ++b) acc[U6(a, b)] += wa0 * J0[b] + wa1 * J1[b];
-        acc[21 + a] += wa0 * ru + wa1 * rv;
+        for (int b = a; b < NB; ++b) acc[UT(NB, a, b)] += wa0 * J0[b] + wa1 * J1[b];
+        acc[NH + a] += wa0 * ru + wa1 * rv;
       }
       i = in; p = pn; uv = uvn;
     }
   }
-  if (COST && !ROBUST) acc[28] = acc[27];
+  if (COST && !ROBUST) acc[NL + 1] = acc[NL];
 #pragma unroll
   for (int q = 0; q < NACC; ++q) acc[q] = row_sum_dpp(acc[q]);
   if (s.live && s.l16 == ROW_LANES - 1) {
-    double* o = partL + ((size_t)s.k * n_cams + s.c) * 27;
+    double* o = partL + ((size_t)s.k * n_cams + s.c) * NL;
 #pragma unroll
-    for (int q = 0; q < 27; ++q) o[q] = acc[q];
+    for (int q = 0; q < NL; ++q) o[q] = acc[q];
     if (COST) {
       double* r2 = partR + ((size_t)s.k * n_cams + s.c) * 2;
-      r2[0] = acc[27]; r2[1] = acc[28];
+      r2[0] = acc[NL]; r2[1] = acc[NL + 1];
     }
   }
 }
 
 // right-hand side + Schur-Jacobi blocks (row form of k_cam_schur<.., DIAG = true, PCG = false>)
-template <bool ROBUST>
+template <class CM, bool ROBUST>
 __global__ void __launch_bounds__(ROW_LANES * ROWS)
-k_camrow_schur_diag(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
-                    const int* __restrict__ c_pt, const double2* __restrict__ c_w, const double* __restrict__ Hppinv,
-                    double fx, double fy, int n_cams, int band, int fixed_cam, double* __restrict__ part6,
-                    double* __restrict__ partE) {
+k_camrow_schur_diag(const double* __restrict__ cs, const double* __restrict__ intr, const double* __restrict__ ptab,
+                    const int* __restrict__ offk, const int* __restrict__ c_pt, const double2* __restrict__ c_w,
+                    const double* __restrict__ Hppinv, double fx, double fy, int n_cams, int band, int fixed_cam,
+                    double* __restrict__ part6, double* __restrict__ partE) {
+  constexpr int NB = CM::NB, NH = CM::NH, NL = CM::NL;
   RowSeg s;
   row_segment(offk, n_cams, band, s);
-  double acc[27];
+  double acc[NL];
 #pragma unroll
-  for (int q = 0; q < 27; ++q) acc[q] = 0.0;
+  for (int q = 0; q < NL; ++q) acc[q] = 0.0;
   if (s.live && s.c != fixed_cam) {
-    double cam[12];
-    load_cam12(cs, s.c, cam);
+    double cam[CM::CAM];
+    CM::load_cam_vec(cs, intr, s.c, cam);
     int i = s.beg + s.l16;
     int pf = (i < s.end) ? c_pt[i] : 0;          // ROBUST: the flagged copy of c_pt
     double2 w = make_double2(1.0, 1.0);
@@ -606,47 +608,49 @@ k_camrow_schur_diag(const double* __restrict__ cs, const double* __restrict__ pt
       const double4 Y = *(const double4*)(ptab + PT * (size_t)p + 4);
       double2 wn = make_double2(1.0, 1.0);
       if (ROBUST && pn < 0) wn = c_w[in];
-      Geom g;
-      obs_geom(cam, X.x, X.y, X.z, fx, fy, g);
-      const double s0 = -(g.P[0] * Y.x + g.P[1] * Y.y + g.P[2] * Y.z) * w.x;
-      const double s1 = -(g.P[3] * Y.x + g.P[4] * Y.y + g.P[5] * Y.z) * w.y;
-      const double e0 = g.P[0] * s0 + g.P[3] * s1, e1 = g.P[1] * s0 + g.P[4] * s1, e2 = g.P[2] * s0 + g.P[5] * s1;
-      acc[0] += e1 * X.z - e2 * X.y;
-      acc[1] += e2 * X.x - e0 * X.z;
-      acc[2] += e0 * X.y - e1 * X.x;
-      acc[3] -= g.d00 * s0;
-      acc[4] -= g.d11 * s1;
-      acc[5] -= g.d02 * s0 + g.d12 * s1;
+      typename CM::template Obs<double> g;
+      CM::template geom<false, double, double>(cam, X.x, X.y, X.z, fx, fy, g);
+      const double* Pm = CM::pm(g);
+      const double s0 = -(Pm[0] * Y.x + Pm[1] * Y.y + Pm[2] * Y.z) * w.x;
+      const double s1 = -(Pm[3] * Y.x + Pm[4] * Y.y + Pm[5] * Y.z) * w.y;
+      {
+        double a9[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) a9[q] = acc[q];
+        CM::jct_accumulate(g, X.x, X.y, X.z, s0, s1, a9);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) acc[q] = a9[q];
+      }
       double hi[6];
       const double2* hp = (const double2*)(Hppinv + 6 * (size_t)p);
       const double2 h01 = hp[0], h23 = hp[1], h45 = hp[2];
       hi[0] = h01.x; hi[1] = h01.y; hi[2] = h23.x; hi[3] = h23.y; hi[4] = h45.x; hi[5] = h45.y;
       double t0[3], t1[3];
-      sym3_mul(hi, g.P, t0);
-      sym3_mul(hi, g.P + 3, t1);
-      const double G00 = w.x * w.x * (g.P[0] * t0[0] + g.P[1] * t0[1] + g.P[2] * t0[2]);
-      const double G01 = w.x * w.y * (g.P[0] * t1[0] + g.P[1] * t1[1] + g.P[2] * t1[2]);
-      const double G11 = w.y * w.y * (g.P[3] * t1[0] + g.P[4] * t1[1] + g.P[5] * t1[2]);
-      double J0[6], J1[6];
-      cam_jac_rows(g, X.x, X.y, X.z, J0, J1);
+      sym3_mul(hi, Pm, t0);
+      sym3_mul(hi, Pm + 3, t1);
+      const double G00 = w.x * w.x * (Pm[0] * t0[0] + Pm[1] * t0[1] + Pm[2] * t0[2]);
+      const double G01 = w.x * w.y * (Pm[0] * t1[0] + Pm[1] * t1[1] + Pm[2] * t1[2]);
+      const double G11 = w.y * w.y * (Pm[3] * t1[0] + Pm[4] * t1[1] + Pm[5] * t1[2]);
+      double J0[NB], J1[NB];
+      CM::jac_rows(g, X.x, X.y, X.z, J0, J1);
 #pragma unroll
-      for (int a = 0; a < 6; ++a) {
+      for (int a = 0; a < NB; ++a) {
         const double l0 = J0[a] * G00 + J1[a] * G01, l1 = J0[a] * G01 + J1[a] * G11;
 #pragma unroll
-        for (int b = a; b < 6; ++b) acc[6 + U6(a, b)] += l0 * J0[b] + l1 * J1[b];
+        for (int b = a; b < NB; ++b) acc[NB + UT(NB, a, b)] += l0 * J0[b] + l1 * J1[b];
       }
       i = in; pf = pn; w = wn;
     }
   }
 #pragma unroll
-  for (int q = 0; q < 27; ++q) acc[q] = row_sum_dpp(acc[q]);
+  for (int q = 0; q < NL; ++q) acc[q] = row_sum_dpp(acc[q]);
   if (s.live && s.l16 == ROW_LANES - 1) {
-    double* o6 = part6 + ((size_t)s.k * n_cams + s.c) * 6;
+    double* o6 = part6 + ((size_t)s.k * n_cams + s.c) * NB;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) o6[q] = acc[q];
-    double* oe = partE + ((size_t)s.k * n_cams + s.c) * 21;
+    for (int q = 0; q < NB; ++q) o6[q] = acc[q];
+    double* oe = partE + ((size_t)s.k * n_cams + s.c) * NH;
 #pragma unroll
-    for (int q = 0; q < 21; ++q) oe[q] = acc[6 + q];
+    for (int q = 0; q < NH; ++q) oe[q] = acc[NB + q];
   }
 }
 
@@ -673,10 +677,10 @@ __device__ inline void combine_wy(const double* __restrict__ part6, int nparts, 
 // workgroup).  The window is staged in LDS when it fits (use_lds, workgroup-uniform), else rows
 // are gathered from L2.  ROWLEN 12 reads R|t only.
 constexpr int LDS_TAB_BYTES = 150 * 1024;
-template <int ROWLEN>
+template <int ROWLEN, int STRIDE>
 __device__ inline void load_cam_row(bool use_lds, const double* __restrict__ tab, const double* __restrict__ camA,
                                     int lo, int c, double (&row)[ROWLEN]) {
-  const double2* src = use_lds ? (const double2*)(tab + TA * (c - lo)) : (const double2*)(camA + TA * (size_t)c);
+  const double2* src = use_lds ? (const double2*)(tab + STRIDE * (c - lo)) : (const double2*)(camA + STRIDE * (size_t)c);
 #pragma unroll
   for (int q = 0; q < ROWLEN / 2; ++q) { const double2 t = src[q]; row[2 * q] = t.x; row[2 * q + 1] = t.y; }
 }
@@ -690,10 +694,11 @@ constexpr int FILL_BATCH = 9;
 // The copy in two halves: fill_cam_table_issue starts it, fill_cam_table_wait ends it (wait + workgroup barrier); what a
 // kernel does in between overlaps the copy's round trips.  SKIP_WAVE0: wave 0 has other work in between (the PCG probe)
 // and takes no share of the copy -- its probe loads would otherwise queue behind its share.
-template <int BLOCK, bool SKIP_WAVE0 = false>
+template <int BLOCK, int STRIDE, bool SKIP_WAVE0 = false>
 __device__ inline void fill_cam_table_issue(double* __restrict__ tab, const double* __restrict__ camA, int lo, int n) {
-  const double2* src = (const double2*)(camA + TA * (size_t)lo);
-  const int total = n * TA / 2;
+  static_assert(STRIDE % 2 == 0, "table rows are copied and read 16 bytes at a time");
+  const double2* src = (const double2*)(camA + STRIDE * (size_t)lo);
+  const int total = n * STRIDE / 2;
 #if BA_FILL_DMA
   // LDS-DMA (global_load_lds_dwordx4, gfx950): 16 bytes per lane straight into LDS at (wave-uniform base) + lane * 16,
   // no staging registers and no ds_write issue slots; a wave copies whole 1 KB pieces, the lanes past the end of the
@@ -736,9 +741,9 @@ __device__ inline void fill_cam_table_wait() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 }
-template <int BLOCK>
+template <int BLOCK, int STRIDE>
 __device__ inline void fill_cam_table(double* __restrict__ tab, const double* __restrict__ camA, int lo, int n) {
-  fill_cam_table_issue<BLOCK>(tab, camA, lo, n);
+  fill_cam_table_issue<BLOCK, STRIDE>(tab, camA, lo, n);
   fill_cam_table_wait();
 }
 // deterministic workgroup sum of N values held by every wave's lane 0 -> thread 0
@@ -792,7 +797,7 @@ __device__ inline double lanes_sum(double x) {      // last lane of every LANES-
 // K2b: point half of the normal equations.  Hpp[p] (6) = sum P^T w P, bp[p] (3) = -sum P^T w r,
 // IRLS weights of point-ordered observations (p_w) when ROBUST; K3 fused: damped inverse and y0.
 // Body for workgroup `bid` of `nblk`: LANES lanes per point (LPP short tracks, LPP_LONG long ones).
-template <bool ROBUST, bool ALL_LDS, int LANES>
+template <class CM, bool ROBUST, bool ALL_LDS, int LANES>
 __device__ __forceinline__ void
 pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,
                   const int* __restrict__ p_cam, const double2* __restrict__ p_uv, const int2* __restrict__ blk_win,
@@ -807,8 +812,8 @@ pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, co
   const double lambda = lam_dev ? lam_dev[0] : lambda_arg;
   const int rb = pt_range_of_block(bid, nblk, wk.xcd_ranges);
   const int2 win = blk_win[wk.blk_base + rb];
-  const bool use_lds = ALL_LDS || (size_t)win.y * TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
-  if (use_lds) fill_cam_table<PT_THREADS>(tab, camA, win.x, win.y);
+  const bool use_lds = ALL_LDS || (size_t)win.y * CM::TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
+  if (use_lds) fill_cam_table<PT_THREADS, CM::TA>(tab, camA, win.x, win.y);
   const int sub = threadIdx.x % LANES;
   const int send = min(wk.n_slots, (rb + 1) * wk.slots_per_block);
   for (int sb = rb * wk.slots_per_block; sb < send; sb += PT_THREADS / LANES) {
@@ -829,12 +834,13 @@ pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, co
         const int jn = j + LANES;
         const int cn = (jn < end) ? p_cam[jn] : 0;
         const double2 uvn = (jn < end) ? p_uv[jn] : make_double2(0, 0);
-        double row[12];
-        load_cam_row<12>(use_lds, tab, camA, win.x, c, row);
-        Geom g;
-        obs_geom(row, X.x, X.y, X.z, fx, fy, g);
-        const double ru = uv.x - (g.xh * fx + cx);
-        const double rv = uv.y - (g.yh * fy + cy);
+        double row[CM::LIN_ROW];
+        load_cam_row<CM::LIN_ROW, CM::TA>(use_lds, tab, camA, win.x, c, row);
+        typename CM::template Obs<double> g;
+        CM::template geom<false, double, double>(row, X.x, X.y, X.z, fx, fy, g);
+        double ru, rv;
+        CM::residual(g, uv.x, uv.y, fx, fy, cx, cy, ru, rv);
+        const double* Pm = CM::pm(g);
         double w0 = 1.0, w1 = 1.0;
         if (ROBUST) {
           double t;
@@ -846,10 +852,10 @@ pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, co
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-          const double wa0 = w0 * g.P[q], wa1 = w1 * g.P[3 + q];
+          const double wa0 = w0 * Pm[q], wa1 = w1 * Pm[3 + q];
 #pragma unroll
-          for (int r = q; r < 3; ++r) a[U3(q, r)] += wa0 * g.P[r] + wa1 * g.P[3 + r];
-          a[6 + q] -= wa0 * ru + wa1 * rv;       // Jp = -P
+          for (int r = q; r < 3; ++r) a[U3(q, r)] += wa0 * Pm[r] + wa1 * Pm[3 + r];
+          a[6 + q] -= wa0 * ru + wa1 * rv;       // Jp = -Pm
         }
         j = jn; c = cn; uv = uvn;
       }
@@ -890,23 +896,23 @@ pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, co
                     double* __restrict__ Hpp, double* __restrict__ bp, double2* __restrict__ p_w, int* __restrict__ p_camf,      \
                     double* __restrict__ Hppinv, double* __restrict__ y0, double* __restrict__ partG
 // one kind of track per launch
-template <bool ROBUST, bool ALL_LDS, int LANES>
+template <class CM, bool ROBUST, bool ALL_LDS, int LANES>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_linearize(BA_LIN_PARAMS, PtWork wk, BA_LIN_TAIL) {
-  pt_linearize_body<ROBUST, ALL_LDS, LANES>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wk, blockIdx.x, gridDim.x, fx, fy, cx, cy,
+  pt_linearize_body<CM, ROBUST, ALL_LDS, LANES>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wk, blockIdx.x, gridDim.x, fx, fy, cx, cy,
                                             hub_c, lambda, lam_dev, Hpp, bp, p_w, p_camf, Hppinv, y0, partG);
 }
 // short and long tracks in one launch: workgroups [0, nblk_short) take the range list with LPP lanes
 // per point, the rest the long-track list with a DPP row per point (saves a launch per pass on data
 // with long tracks)
-template <bool ROBUST, bool ALL_LDS>
+template <class CM, bool ROBUST, bool ALL_LDS>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_linearize_both(BA_LIN_PARAMS, PtWork wk, int nblk_short, PtWork wl, BA_LIN_TAIL) {
   if ((int)blockIdx.x < nblk_short)
-    pt_linearize_body<ROBUST, ALL_LDS, LPP>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wk, blockIdx.x, nblk_short, fx, fy, cx, cy,
+    pt_linearize_body<CM, ROBUST, ALL_LDS, LPP>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wk, blockIdx.x, nblk_short, fx, fy, cx, cy,
                                             hub_c, lambda, lam_dev, Hpp, bp, p_w, p_camf, Hppinv, y0, partG);
   else
-    pt_linearize_body<ROBUST, ALL_LDS, LPP_LONG>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wl, blockIdx.x - nblk_short,
+    pt_linearize_body<CM, ROBUST, ALL_LDS, LPP_LONG>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wl, blockIdx.x - nblk_short,
                                                  gridDim.x - nblk_short, fx, fy, cx, cy, hub_c, lambda, lam_dev, Hpp, bp, p_w,
                                                  p_camf, Hppinv, y0, partG);
 }
@@ -978,7 +984,7 @@ k_pcg_probe(int kit, const PcgState* __restrict__ st, const double* __restrict__
   (void)pcg_probe(kit, st, partV, nblkV, tol2, min_iters, host_flag, flag_base, verdict, nullptr, 0, partGc, nGc, gmax_out);
 }
 
-template <bool ROBUST, int MODE, bool ALL_LDS, int LANES, typename JT>
+template <class CM, bool ROBUST, int MODE, bool ALL_LDS, int LANES, typename JT>
 __device__ __forceinline__ void
 pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,
               const int* __restrict__ p_cam, const double2* __restrict__ p_w, const double* __restrict__ Hppinv,
@@ -1005,13 +1011,13 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
     beg0 = pt_off[p0];
     end0 = pt_off[p0 + 1];
   }
-  const bool use_lds = ALL_LDS || (size_t)win.y * TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
+  const bool use_lds = ALL_LDS || (size_t)win.y * CM::TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
   bool table_ready = !use_lds;
   // The table copy starts BEFORE the PCG verdict is known: the copy does not depend on it (the previous kernel of the
   // stream wrote the table), and its round trips hide the probe's.  A launch that turns out to be past the end of PCG
   // pays for a copy it does not use -- one launch per LM iteration against a round trip saved in every working one.
   __shared__ int s_fin;
-  if (use_lds) fill_cam_table_issue<PT_THREADS, MODE == 0>(tab, camA, win.x, win.y);
+  if (use_lds) fill_cam_table_issue<PT_THREADS, CM::TA, MODE == 0>(tab, camA, win.x, win.y);
   if (MODE == 0) {
     // wave 0 sums the vector kernel's partials and decides for the workgroup while the other waves copy
     if (threadIdx.x < 64) {
@@ -1070,21 +1076,21 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
         if (ROBUST && cn < 0) wn = p_w[jn];
         const int cc = ROBUST ? (c & IDX_MASK) : c;
         if (cc != fixed_cam) {
-          double rowd[TA];
-          load_cam_row<TA>(use_lds, tab, camA, win.x, cc, rowd);
-          JT row[TA];                            // Jacobian blocks in JT (double, or float for config 5)
+          double rowd[CM::SCH_ROW];
+          load_cam_row<CM::SCH_ROW, CM::TA>(use_lds, tab, camA, win.x, cc, rowd);
+          JT row[CM::SCH_ROW];                   // Jacobian blocks in JT (double, or float for config 5)
 #pragma unroll
-          for (int q = 0; q < TA; ++q) row[q] = (JT)rowd[q];
-          const JT* v = row + 12;
+          for (int q = 0; q < CM::SCH_ROW; ++q) row[q] = (JT)rowd[q];
           const JT X0 = (JT)X.x, X1 = (JT)X.y, X2 = (JT)X.z;
-          GeomT<JT> g;
-          obs_geom_fast<JT>(row, X0, X1, X2, (JT)fx, (JT)fy, g);
-          const JT q0 = X1 * v[2] - X2 * v[1], q1 = X2 * v[0] - X0 * v[2], q2 = X0 * v[1] - X1 * v[0];
-          const JT s0 = (g.P[0] * q0 + g.P[1] * q1 + g.P[2] * q2 - (g.d00 * v[3] + g.d02 * v[5])) * (JT)w.x;
-          const JT s1 = (g.P[3] * q0 + g.P[4] * q1 + g.P[5] * q2 - (g.d11 * v[4] + g.d12 * v[5])) * (JT)w.y;
-          u[0] -= (double)(g.P[0] * s0 + g.P[3] * s1);      // sums always in fp64
-          u[1] -= (double)(g.P[1] * s0 + g.P[4] * s1);
-          u[2] -= (double)(g.P[2] * s0 + g.P[5] * s1);
+          typename CM::template Obs<JT> g;
+          CM::template geom<true, JT, JT>(row, X0, X1, X2, (JT)fx, (JT)fy, g);
+          JT s0, s1;
+          CM::jc_times(g, X0, X1, X2, row + CM::VOFF, s0, s1);      // Jc vt
+          s0 *= (JT)w.x; s1 *= (JT)w.y;
+          const JT* Pm = CM::pm(g);
+          u[0] -= (double)(Pm[0] * s0 + Pm[3] * s1);        // Jp^T (.), Jp = -Pm; sums always in fp64
+          u[1] -= (double)(Pm[1] * s0 + Pm[4] * s1);
+          u[2] -= (double)(Pm[2] * s0 + Pm[5] * s1);
         }
         j = jn; c = cn; cn = cnn; w = wn;
       }
@@ -1141,21 +1147,21 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
                     int nGc, double* __restrict__ gmax_out
 #define BA_SCH_TAIL_ARGS fx, fy, fixed_cam, partA, kit, st, partV, nblkV, tol2, min_iters, y0, Hpp, bp, ptab_trial, partB,       \
                          host_flag, flag_base, verdict, partG, nG, partGc, nGc, gmax_out
-template <bool ROBUST, int MODE, bool ALL_LDS, int LANES, typename JT>
+template <class CM, bool ROBUST, int MODE, bool ALL_LDS, int LANES, typename JT>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_schur(BA_SCH_PARAMS, PtWork wk, BA_SCH_TAIL) {
-  pt_schur_body<ROBUST, MODE, ALL_LDS, LANES, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk, blockIdx.x, gridDim.x,
+  pt_schur_body<CM, ROBUST, MODE, ALL_LDS, LANES, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk, blockIdx.x, gridDim.x,
                                                   BA_SCH_TAIL_ARGS);
 }
 // short and long tracks in one launch (see k_pt_linearize_both)
-template <bool ROBUST, int MODE, bool ALL_LDS, typename JT>
+template <class CM, bool ROBUST, int MODE, bool ALL_LDS, typename JT>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_schur_both(BA_SCH_PARAMS, PtWork wk, int nblk_short, PtWork wl, BA_SCH_TAIL) {
   if ((int)blockIdx.x < nblk_short)
-    pt_schur_body<ROBUST, MODE, ALL_LDS, LPP, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk, blockIdx.x, nblk_short,
+    pt_schur_body<CM, ROBUST, MODE, ALL_LDS, LPP, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk, blockIdx.x, nblk_short,
                                                   BA_SCH_TAIL_ARGS);
   else
-    pt_schur_body<ROBUST, MODE, ALL_LDS, LPP_LONG, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wl,
+    pt_schur_body<CM, ROBUST, MODE, ALL_LDS, LPP_LONG, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wl,
                                                        blockIdx.x - nblk_short, gridDim.x - nblk_short, BA_SCH_TAIL_ARGS);
 }
 #undef BA_SCH_PARAMS
@@ -1165,11 +1171,13 @@ k_pt_schur_both(BA_SCH_PARAMS, PtWork wk, int nblk_short, PtWork wl, BA_SCH_TAIL
 // -------------------------------------------------------------------------------------
 // reduced-camera-system vector kernels (one thread per camera)
 // -------------------------------------------------------------------------------------
-__device__ inline void write_vtil(const double* __restrict__ M, const double (&v)[6], double* __restrict__ dst) {
+template <int NB>
+__device__ inline void write_vtil(const double* __restrict__ M, const double (&v)[NB], double* __restrict__ dst) {
   dst[0] = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
   dst[1] = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
   dst[2] = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
-  dst[3] = v[3]; dst[4] = v[4]; dst[5] = v[5];
+#pragma unroll
+  for (int q = 3; q < NB; ++q) dst[q] = v[q];
 }
 
 // ---- cooperative staging for the camera-vector kernels ---------------------------------------------
@@ -1209,14 +1217,15 @@ __device__ inline void slice_write_back(double* __restrict__ dst, const double* 
 }
 constexpr int VC = VEC_CAMS;
 static_assert(VEC_CAMS == 16, "the staging below is laid out for 16 cameras per camera-vector workgroup");
+constexpr int slice_chunks(int doubles) { return (doubles + 127) / 128; }      // double2 per lane that cover a slice
 
 // PCG setup at damping lambda: Hccd = Hcc + lam Dc (fixed camera: identity), Schur-Jacobi
 // or Jacobi preconditioner Minv = (Hccd - E)^-1, right-hand side g = -(bc - W y0), and the
 // (FINALIZE: first folds the fresh linearisation partials into Hcc | bc, single rank)
 // first PCG vectors: x = 0, r = g, z = Minv r, p = s = 0, vtil, gamma/zeta partials.
 // E / Wy0 come either as NPART partial sums (nparts = NPART) or already folded and
-// all-reduced (nparts = 1).
-template <bool FINALIZE>
+// all-reduced (nparts = 1).  CM: the camera model (block size NB = 6 or 9, table row layout).
+template <class CM, bool FINALIZE>
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* __restrict__ bc, const double* __restrict__ part6,
             const double* __restrict__ partE, int nparts, const double* __restrict__ cs, double lambda,
@@ -1224,13 +1233,14 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
             double* __restrict__ gvec, double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
             double* __restrict__ s, double* __restrict__ z, double* __restrict__ vtil,
             double* __restrict__ partV, PcgState* __restrict__ st, double* __restrict__ partGc, double* __restrict__ rc) {
+  constexpr int NB = CM::NB, NH = CM::NH, NL = CM::NL;
   // (rc != null: two-level preconditioner -- also the aggregate's restricted right-hand side; z, partV and vtil written
   // here are then the single-level ones and are redone by k_pcg_coarse once E^-1 exists)
-  // LDS image of the workgroup's VC cameras.  Inputs: partition-folded sums (a: 27 of the linearisation when
-  // FINALIZE, e: 21 Schur-Jacobi, w6: 6 of W y0), Hcc | bc (when not FINALIZE), cs.  Outputs staged for a
+  // LDS image of the workgroup's VC cameras.  Inputs: partition-folded sums (a: NL of the linearisation when
+  // FINALIZE, e: NH Schur-Jacobi, w6: NB of W y0), Hcc | bc (when not FINALIZE), cs.  Outputs staged for a
   // coalesced write-back: Hcc | bc (FINALIZE), Hccd, Minv, g = r, z (x = p = s = 0 written directly).
-  __shared__ double l_a[27 * VC], l_e[21 * VC], l_w6[6 * VC], l_cs[CS * VC], l_hcc[21 * VC], l_bc[6 * VC],
-      l_hd[21 * VC], l_mi[21 * VC], l_g[6 * VC], l_z[6 * VC];
+  __shared__ double l_a[NL * VC], l_e[NH * VC], l_w6[NB * VC], l_cs[CS * VC], l_hcc[NH * VC], l_bc[NB * VC],
+      l_hd[NH * VC], l_mi[NH * VC], l_g[NB * VC], l_z[NB * VC];
   const int c0 = blockIdx.x * VC;
   const int nc = min(VC, n_cams - c0);
   const int c = vec_camera(n_cams);
@@ -1238,13 +1248,13 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
   // ---- cooperative loads: every word of the workgroup's slices, lane-strided and coalesced; the partition
   // sums run k = 0, 1, ... in every element (the same fixed order as a thread-per-camera loop)
   {
-    double2 vc[3], vh[3], vb[1];
+    double2 vc[slice_chunks(CS * VC)], vh[slice_chunks(NH * VC)], vb[slice_chunks(NB * VC)];
     slice_load(VecSlice{cs + CS * (size_t)c0, CS * nc}, vc);
     if (!FINALIZE) {
-      slice_load(VecSlice{Hcc + 21 * (size_t)c0, 21 * nc}, vh);
-      slice_load(VecSlice{bc + 6 * (size_t)c0, 6 * nc}, vb);
+      slice_load(VecSlice{Hcc + NH * (size_t)c0, NH * nc}, vh);
+      slice_load(VecSlice{bc + NB * (size_t)c0, NB * nc}, vb);
     }
-    constexpr int NA = (27 * VC + 63) / 64, NE = (21 * VC + 63) / 64, NW = (6 * VC + 63) / 64;
+    constexpr int NA = (NL * VC + 63) / 64, NE = (NH * VC + 63) / 64, NW = (NB * VC + 63) / 64;
     double sa[NA], se[NE], sw[NW];
 #pragma unroll
     for (int j = 0; j < NA; ++j) sa[j] = 0.0;
@@ -1252,13 +1262,13 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
     for (int j = 0; j < NE; ++j) se[j] = 0.0;
 #pragma unroll
     for (int j = 0; j < NW; ++j) sw[j] = 0.0;
-    const int la = 27 * nc, le = 21 * nc, lw = 6 * nc;
+    const int la = NL * nc, le = NH * nc, lw = NB * nc;
 #pragma unroll 2
     for (int k = 0; k < NPART; ++k) {
       double ta[NA], te[NE], tw[NW];
-      const double* pa = partL + ((size_t)k * n_cams + c0) * 27;
-      const double* pe = partE + ((size_t)k * n_cams + c0) * 21;
-      const double* pw = part6 + ((size_t)k * n_cams + c0) * 6;
+      const double* pa = partL + ((size_t)k * n_cams + c0) * NL;
+      const double* pe = partE + ((size_t)k * n_cams + c0) * NH;
+      const double* pw = part6 + ((size_t)k * n_cams + c0) * NB;
 #pragma unroll
       for (int j = 0; j < NA; ++j) { const int i = j * 64 + lane; ta[j] = (FINALIZE && i < la) ? pa[i] : 0.0; }
 #pragma unroll
@@ -1273,84 +1283,86 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
       for (int j = 0; j < NW; ++j) sw[j] += tw[j];
     }
 #pragma unroll
-    for (int j = 0; j < NA; ++j) { const int i = j * 64 + lane; if (i < 27 * VC) l_a[i] = sa[j]; }
+    for (int j = 0; j < NA; ++j) { const int i = j * 64 + lane; if (i < NL * VC) l_a[i] = sa[j]; }
 #pragma unroll
-    for (int j = 0; j < NE; ++j) { const int i = j * 64 + lane; if (i < 21 * VC) l_e[i] = se[j]; }
+    for (int j = 0; j < NE; ++j) { const int i = j * 64 + lane; if (i < NH * VC) l_e[i] = se[j]; }
 #pragma unroll
-    for (int j = 0; j < NW; ++j) { const int i = j * 64 + lane; if (i < 6 * VC) l_w6[i] = sw[j]; }
+    for (int j = 0; j < NW; ++j) { const int i = j * 64 + lane; if (i < NB * VC) l_w6[i] = sw[j]; }
     slice_store_lds(l_cs, CS * VC, vc);
     if (!FINALIZE) {
-      slice_store_lds(l_hcc, 21 * VC, vh);
-      slice_store_lds(l_bc, 6 * VC, vb);
+      slice_store_lds(l_hcc, NH * VC, vh);
+      slice_store_lds(l_bc, NB * VC, vb);
     }
   }
   __syncthreads();
   double acc[2] = {0, 0};
-  double gsum[6] = {0, 0, 0, 0, 0, 0};
+  double gsum[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) gsum[q] = 0.0;
   double gmc = 0.0;
   const int t = threadIdx.x;
   if (c < n_cams) {
     const double* M = l_cs + CS * t + 12;
     const bool fixed = c == fixed_cam;
-    if (FINALIZE) lin_finalize_sums(l_a + 27 * t, M, fixed, l_hcc + 21 * t, l_bc + 6 * t);
-    double h[21], m[21], inv[21];
-    for (int q = 0; q < 21; ++q) h[q] = l_hcc[21 * t + q];
+    if (FINALIZE) lin_finalize_sums<NB>(l_a + NL * t, M, fixed, l_hcc + NH * t, l_bc + NB * t);
+    double h[NH], m[NH], inv[NH];
+    for (int q = 0; q < NH; ++q) h[q] = l_hcc[NH * t + q];
     if (fixed) {
-      for (int q = 0; q < 21; ++q) h[q] = 0.0;
-      for (int i = 0; i < 6; ++i) h[U6(i, i)] = 1.0;
+      for (int q = 0; q < NH; ++q) h[q] = 0.0;
+      for (int i = 0; i < NB; ++i) h[UT(NB, i, i)] = 1.0;
     } else {
-      for (int i = 0; i < 6; ++i) h[U6(i, i)] += lambda * fmax(h[U6(i, i)], DIAG_FLOOR);
+      for (int i = 0; i < NB; ++i) h[UT(NB, i, i)] += lambda * fmax(h[UT(NB, i, i)], DIAG_FLOOR);
     }
-    for (int q = 0; q < 21; ++q) { l_hd[21 * t + q] = h[q]; m[q] = h[q]; }
+    for (int q = 0; q < NH; ++q) { l_hd[NH * t + q] = h[q]; m[q] = h[q]; }
     if (use_schur_diag && !fixed) {
-      double A[6][6];
-      for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) A[i][j] = l_e[21 * t + S6(i, j)];
-      m_congruence(M, A);
-      for (int i = 0; i < 6; ++i) for (int j = i; j < 6; ++j) m[U6(i, j)] -= A[i][j];
+      double A[NB][NB];
+      for (int i = 0; i < NB; ++i) for (int j = 0; j < NB; ++j) A[i][j] = l_e[NH * t + ST(NB, i, j)];
+      m_congruence<NB>(M, A);
+      for (int i = 0; i < NB; ++i) for (int j = i; j < NB; ++j) m[UT(NB, i, j)] -= A[i][j];
     }
-    spd6_inverse(m, inv);
-    for (int q = 0; q < 21; ++q) l_mi[21 * t + q] = inv[q];
-    double wy[6], g[6], zz[6], hz[6];
+    spdN_inverse<NB>(m, inv);
+    for (int q = 0; q < NH; ++q) l_mi[NH * t + q] = inv[q];
+    double wy[NB], g[NB], zz[NB], hz[NB];
     {
-      const double* a = l_w6 + 6 * t;
+      const double* a = l_w6 + NB * t;
       wy[0] = M[0] * a[0] + M[3] * a[1] + M[6] * a[2];
       wy[1] = M[1] * a[0] + M[4] * a[1] + M[7] * a[2];
       wy[2] = M[2] * a[0] + M[5] * a[1] + M[8] * a[2];
-      wy[3] = a[3]; wy[4] = a[4]; wy[5] = a[5];
+      for (int q = 3; q < NB; ++q) wy[q] = a[q];
     }
-    for (int q = 0; q < 6; ++q) g[q] = fixed ? 0.0 : -(l_bc[6 * t + q] - wy[q]);
-    for (int q = 0; q < 6; ++q) gmc = nanmax(gmc, fabs(l_bc[6 * t + q]));     // max |bc| (gtol test)
-    sym6_mul(inv, g, zz);
-    sym6_mul(h, zz, hz);
-    for (int q = 0; q < 6; ++q) {
-      l_g[6 * t + q] = g[q];
-      l_z[6 * t + q] = zz[q];
+    for (int q = 0; q < NB; ++q) g[q] = fixed ? 0.0 : -(l_bc[NB * t + q] - wy[q]);
+    for (int q = 0; q < NB; ++q) gmc = nanmax(gmc, fabs(l_bc[NB * t + q]));     // max |bc| (gtol test)
+    symN_mul<NB>(inv, g, zz);
+    symN_mul<NB>(h, zz, hz);
+    for (int q = 0; q < NB; ++q) {
+      l_g[NB * t + q] = g[q];
+      l_z[NB * t + q] = zz[q];
       acc[0] += g[q] * zz[q];
       acc[1] += zz[q] * hz[q];
       gsum[q] = g[q];
     }
-    write_vtil(M, zz, vtil + TA * c + 12);
+    write_vtil<NB>(M, zz, vtil + CM::TA * (size_t)c + CM::VOFF);
   }
   if (rc) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) gsum[q] = wave_total_dpp(gsum[q]);
+    for (int q = 0; q < NB; ++q) gsum[q] = wave_total_dpp(gsum[q]);
     if (threadIdx.x == 0) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) rc[6 * blockIdx.x + q] = gsum[q];
+      for (int q = 0; q < NB; ++q) rc[NB * blockIdx.x + q] = gsum[q];
     }
   }
   __syncthreads();
   // ---- coalesced write-back
   if (FINALIZE) {
-    slice_write_back(Hcc + 21 * (size_t)c0, l_hcc, 21 * nc);
-    slice_write_back(bc + 6 * (size_t)c0, l_bc, 6 * nc);
+    slice_write_back(Hcc + NH * (size_t)c0, l_hcc, NH * nc);
+    slice_write_back(bc + NB * (size_t)c0, l_bc, NB * nc);
   }
-  slice_write_back(Hccd + 21 * (size_t)c0, l_hd, 21 * nc);
-  slice_write_back(Minv + 21 * (size_t)c0, l_mi, 21 * nc);
-  slice_write_back(gvec + 6 * (size_t)c0, l_g, 6 * nc);
-  slice_write_back(r + 6 * (size_t)c0, l_g, 6 * nc);
-  slice_write_back(z + 6 * (size_t)c0, l_z, 6 * nc);
-  for (int i = lane; i < 6 * nc; i += 64) { x[6 * (size_t)c0 + i] = 0.0; p[6 * (size_t)c0 + i] = 0.0; s[6 * (size_t)c0 + i] = 0.0; }
+  slice_write_back(Hccd + NH * (size_t)c0, l_hd, NH * nc);
+  slice_write_back(Minv + NH * (size_t)c0, l_mi, NH * nc);
+  slice_write_back(gvec + NB * (size_t)c0, l_g, NB * nc);
+  slice_write_back(r + NB * (size_t)c0, l_g, NB * nc);
+  slice_write_back(z + NB * (size_t)c0, l_z, NB * nc);
+  for (int i = lane; i < NB * nc; i += 64) { x[NB * (size_t)c0 + i] = 0.0; p[NB * (size_t)c0 + i] = 0.0; s[NB * (size_t)c0 + i] = 0.0; }
 #pragma unroll
   for (int q = 0; q < 2; ++q) acc[q] = wave_total_dpp(acc[q]);
   gmc = wave_nanmax(gmc);
@@ -1376,7 +1388,7 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
 // extra workgroup, or all-reduced in a multi-rank job).
 // COARSE (two-level preconditioner, ba_coarse.hpp): the kernel stops after r and zJ = M_J^-1 r and leaves the
 // aggregate's restricted residual in rc; z, the dot products and vtil are finished by k_pcg_coarse.
-template <bool COARSE>
+template <class CM, bool COARSE>
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __restrict__ uy_src,
            const double* __restrict__ Hccd, const double* __restrict__ Minv, const double* __restrict__ cs,
@@ -1385,8 +1397,9 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
            double* __restrict__ z, double* __restrict__ vtil, double* __restrict__ partV, int nblkV,
            PcgState* __restrict__ st, long long* __restrict__ host_flag, long long flag_base,
            const double* __restrict__ verdict, double* __restrict__ rc) {
+  constexpr int NB = CM::NB, NH = CM::NH;
   // LDS image of the workgroup's cameras: Hccd | Minv | z p s r x | part6[NPART] | cs
-  __shared__ double l_h[21 * VC], l_mi[21 * VC], l_v[5][6 * VC], l_p6[NPART][6 * VC], l_cs[CS * VC];
+  __shared__ double l_h[NH * VC], l_mi[NH * VC], l_v[5][NB * VC], l_p6[NPART][NB * VC], l_cs[CS * VC];
   BA_STAMP(2, 0); BA_STAMP(2, 1);
   const int c0 = blockIdx.x * VC;
   const int nc = min(VC, n_cams - c0);                         // cameras of this workgroup (>= 1)
@@ -1396,22 +1409,23 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
   // early-exit launch wastes the loads)
   const double uy = uy_src[0];
   {
-    double2 vh[3], vm[3], vv[5][1], vp[NPART][1], vc[3];     // 168 | 168 | 48 | 48 | 192 double2 per slice
-    slice_load(VecSlice{Hccd + 21 * (size_t)c0, 21 * nc}, vh);
-    slice_load(VecSlice{Minv + 21 * (size_t)c0, 21 * nc}, vm);
+    double2 vh[slice_chunks(NH * VC)], vm[slice_chunks(NH * VC)], vv[5][slice_chunks(NB * VC)], vp[NPART][slice_chunks(NB * VC)],
+        vc[slice_chunks(CS * VC)];
+    slice_load(VecSlice{Hccd + NH * (size_t)c0, NH * nc}, vh);
+    slice_load(VecSlice{Minv + NH * (size_t)c0, NH * nc}, vm);
     const double* vecs[5] = {z, p, s, r, x};
 #pragma unroll
-    for (int q = 0; q < 5; ++q) slice_load(VecSlice{vecs[q] + 6 * (size_t)c0, 6 * nc}, vv[q]);
+    for (int q = 0; q < 5; ++q) slice_load(VecSlice{vecs[q] + NB * (size_t)c0, NB * nc}, vv[q]);
 #pragma unroll
     for (int kk = 0; kk < NPART; ++kk)
-      slice_load(VecSlice{part6 + ((size_t)kk * n_cams + c0) * 6, kk < nparts ? 6 * nc : 0}, vp[kk]);
+      slice_load(VecSlice{part6 + ((size_t)kk * n_cams + c0) * NB, kk < nparts ? NB * nc : 0}, vp[kk]);
     slice_load(VecSlice{cs + CS * (size_t)c0, CS * nc}, vc);
-    slice_store_lds(l_h, 21 * VC, vh);
-    slice_store_lds(l_mi, 21 * VC, vm);
+    slice_store_lds(l_h, NH * VC, vh);
+    slice_store_lds(l_mi, NH * VC, vm);
 #pragma unroll
-    for (int q = 0; q < 5; ++q) slice_store_lds(l_v[q], 6 * VC, vv[q]);
+    for (int q = 0; q < 5; ++q) slice_store_lds(l_v[q], NB * VC, vv[q]);
 #pragma unroll
-    for (int kk = 0; kk < NPART; ++kk) slice_store_lds(l_p6[kk], 6 * VC, vp[kk]);
+    for (int kk = 0; kk < NPART; ++kk) slice_store_lds(l_p6[kk], NB * VC, vp[kk]);
     slice_store_lds(l_cs, CS * VC, vc);
   }
   double gamma, zeta;
@@ -1444,45 +1458,50 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
   const double alpha = gamma / denom;
   __syncthreads();                                      // the LDS image is complete
   double acc[2] = {0, 0};
-  double rsum[6] = {0, 0, 0, 0, 0, 0};
+  double rsum[NB];
+#pragma unroll
+  for (int q = 0; q < NB; ++q) rsum[q] = 0.0;
   const int t = threadIdx.x;
   if (live) {
     const double* M = l_cs + CS * t + 12;
-    double h[21], mi[21];                               // into registers once: LDS stores below would force re-reads
+    double h[NH], mi[NH];                               // into registers once: LDS stores below would force re-reads
 #pragma unroll
-    for (int q = 0; q < 21; ++q) { h[q] = l_h[21 * t + q]; mi[q] = l_mi[21 * t + q]; }
-    double zz[6], wy[6], pp[6], ss[6], rr[6], xx[6], w[6], hz[6];
+    for (int q = 0; q < NH; ++q) { h[q] = l_h[NH * t + q]; mi[q] = l_mi[NH * t + q]; }
+    double zz[NB], wy[NB], pp[NB], ss[NB], rr[NB], xx[NB], w[NB], hz[NB];
     {
-      double a[6] = {0, 0, 0, 0, 0, 0};
+      double a[NB];
+#pragma unroll
+      for (int q = 0; q < NB; ++q) a[q] = 0.0;
       for (int kk = 0; kk < nparts; ++kk) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) a[q] += l_p6[kk][6 * t + q];
+        for (int q = 0; q < NB; ++q) a[q] += l_p6[kk][NB * t + q];
       }
       wy[0] = M[0] * a[0] + M[3] * a[1] + M[6] * a[2];
       wy[1] = M[1] * a[0] + M[4] * a[1] + M[7] * a[2];
       wy[2] = M[2] * a[0] + M[5] * a[1] + M[8] * a[2];
-      wy[3] = a[3]; wy[4] = a[4]; wy[5] = a[5];
+#pragma unroll
+      for (int q = 3; q < NB; ++q) wy[q] = a[q];
     }
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      zz[q] = l_v[0][6 * t + q]; pp[q] = l_v[1][6 * t + q]; ss[q] = l_v[2][6 * t + q];
-      rr[q] = l_v[3][6 * t + q]; xx[q] = l_v[4][6 * t + q];
+    for (int q = 0; q < NB; ++q) {
+      zz[q] = l_v[0][NB * t + q]; pp[q] = l_v[1][NB * t + q]; ss[q] = l_v[2][NB * t + q];
+      rr[q] = l_v[3][NB * t + q]; xx[q] = l_v[4][NB * t + q];
     }
-    sym6_mul(h, zz, w);
+    symN_mul<NB>(h, zz, w);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
+    for (int q = 0; q < NB; ++q) {
       w[q] -= wy[q];
       pp[q] = zz[q] + beta * pp[q];
       ss[q] = w[q] + beta * ss[q];
       xx[q] = xx[q] + alpha * pp[q];
       rr[q] -= alpha * ss[q];
     }
-    sym6_mul(mi, rr, zz);
-    if (!COARSE) sym6_mul(h, zz, hz);
+    symN_mul<NB>(mi, rr, zz);
+    if (!COARSE) symN_mul<NB>(h, zz, hz);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      l_v[0][6 * t + q] = zz[q]; l_v[1][6 * t + q] = pp[q]; l_v[2][6 * t + q] = ss[q];
-      l_v[3][6 * t + q] = rr[q]; l_v[4][6 * t + q] = xx[q];
+    for (int q = 0; q < NB; ++q) {
+      l_v[0][NB * t + q] = zz[q]; l_v[1][NB * t + q] = pp[q]; l_v[2][NB * t + q] = ss[q];
+      l_v[3][NB * t + q] = rr[q]; l_v[4][NB * t + q] = xx[q];
       if (!COARSE) {
         acc[0] += rr[q] * zz[q];
         acc[1] += zz[q] * hz[q];
@@ -1490,21 +1509,21 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
         rsum[q] = rr[q];
       }
     }
-    if (!COARSE) write_vtil(M, zz, vtil + TA * c + 12);
+    if (!COARSE) write_vtil<NB>(M, zz, vtil + CM::TA * (size_t)c + CM::VOFF);
   }
   if (COARSE) {                                         // restricted residual of this aggregate (= this workgroup)
 #pragma unroll
-    for (int q = 0; q < 6; ++q) rsum[q] = wave_total_dpp(rsum[q]);
+    for (int q = 0; q < NB; ++q) rsum[q] = wave_total_dpp(rsum[q]);
     if (threadIdx.x == 0) {
 #pragma unroll
-      for (int q = 0; q < 6; ++q) rc[6 * blockIdx.x + q] = rsum[q];
+      for (int q = 0; q < NB; ++q) rc[NB * blockIdx.x + q] = rsum[q];
     }
   }
   __syncthreads();
   {                                                     // the five vectors back, coalesced (fixed camera: unchanged image)
     double* vecs[5] = {z, p, s, r, x};
 #pragma unroll
-    for (int q = 0; q < 5; ++q) slice_write_back(vecs[q] + 6 * (size_t)c0, l_v[q], 6 * nc);
+    for (int q = 0; q < 5; ++q) slice_write_back(vecs[q] + NB * (size_t)c0, l_v[q], NB * nc);
   }
   BA_STAMP(2, 3);
 #pragma unroll
@@ -1526,50 +1545,60 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
   BA_STAMP(2, 6); BA_STAMP(2, 7);
 }
 
-// K7a: camera update.  cams_trial = cams + dc, camera state of the trial cameras, vtil =
-// (M dc_r, dc_t) into camA for the back substitution, camera-side scalars ->
-// partC[block][5]: bc.dc, sum Dc dc^2, dc.r_pcg, |dc|^2, |cams|^2
+// K7a: camera update.  cams_trial = cams + dc (BAL: also intr_trial = intr + the last three entries of dc), camera
+// state and table row of the trial cameras, vtil = (M dc_r, dc_t, ..) into camA for the back substitution,
+// camera-side scalars -> partC[block][5]: bc.dc, sum Dc dc^2, dc.r_pcg, |dc|^2, |cams|^2
+template <class CM>
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_cam_update(const double* __restrict__ cams, const double* __restrict__ dc, const double* __restrict__ rpcg,
-             const double* __restrict__ Hcc, const double* __restrict__ bc, const double* __restrict__ cs,
-             int n_cams, int fixed_cam, double* __restrict__ cams_trial, double* __restrict__ cs_trial,
-             double* __restrict__ vtil, double* __restrict__ camA_trial, double* __restrict__ partC) {
-  // LDS image of the workgroup's VC cameras (coalesced staging, see slice_load): cams dc rpcg bc | Hcc | cs,
+k_cam_update(const double* __restrict__ cams, const double* __restrict__ intr, const double* __restrict__ dc,
+             const double* __restrict__ rpcg, const double* __restrict__ Hcc, const double* __restrict__ bc,
+             const double* __restrict__ cs, int n_cams, int fixed_cam, double* __restrict__ cams_trial,
+             double* __restrict__ intr_trial, double* __restrict__ cs_trial, double* __restrict__ vtil,
+             double* __restrict__ camA_trial, double* __restrict__ partC) {
+  constexpr int NB = CM::NB, NH = CM::NH;
+  // LDS image of the workgroup's VC cameras (coalesced staging, see slice_load): cams | dc rpcg bc | Hcc | cs,
   // outputs cams_trial | cs_trial staged for a coalesced write-back
-  __shared__ double l_in[4][6 * VC], l_hcc[21 * VC], l_cs[CS * VC], l_ct[6 * VC], l_cst[CS * VC];
+  __shared__ double l_cam[6 * VC], l_in[3][NB * VC], l_hcc[NH * VC], l_cs[CS * VC], l_ct[6 * VC], l_cst[CS * VC];
   const int c0 = blockIdx.x * VC;
   const int nc = min(VC, n_cams - c0);
   const int c = vec_camera(n_cams);
   {
-    double2 vi[4][1], vh[3], vc[3];
-    const double* ins[4] = {cams, dc, rpcg, bc};
+    double2 v0[slice_chunks(6 * VC)], vi[3][slice_chunks(NB * VC)], vh[slice_chunks(NH * VC)], vc[slice_chunks(CS * VC)];
+    const double* ins[3] = {dc, rpcg, bc};
+    slice_load(VecSlice{cams + 6 * (size_t)c0, 6 * nc}, v0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) slice_load(VecSlice{ins[q] + 6 * (size_t)c0, 6 * nc}, vi[q]);
-    slice_load(VecSlice{Hcc + 21 * (size_t)c0, 21 * nc}, vh);
+    for (int q = 0; q < 3; ++q) slice_load(VecSlice{ins[q] + NB * (size_t)c0, NB * nc}, vi[q]);
+    slice_load(VecSlice{Hcc + NH * (size_t)c0, NH * nc}, vh);
     slice_load(VecSlice{cs + CS * (size_t)c0, CS * nc}, vc);
+    slice_store_lds(l_cam, 6 * VC, v0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) slice_store_lds(l_in[q], 6 * VC, vi[q]);
-    slice_store_lds(l_hcc, 21 * VC, vh);
+    for (int q = 0; q < 3; ++q) slice_store_lds(l_in[q], NB * VC, vi[q]);
+    slice_store_lds(l_hcc, NH * VC, vh);
     slice_store_lds(l_cs, CS * VC, vc);
   }
   __syncthreads();
   double acc[5] = {0, 0, 0, 0, 0};
   const int t = threadIdx.x;
   if (c < n_cams) {
-    double d[6];
-    for (int q = 0; q < 6; ++q) d[q] = (c == fixed_cam) ? 0.0 : l_in[1][6 * t + q];
-    for (int q = 0; q < 6; ++q) {
-      const double xq = l_in[0][6 * t + q];
-      l_ct[6 * t + q] = xq + d[q];
-      acc[0] += l_in[3][6 * t + q] * d[q];
-      acc[1] += fmax(l_hcc[21 * t + U6(q, q)], DIAG_FLOOR) * d[q] * d[q];
-      acc[2] += d[q] * ((c == fixed_cam) ? 0.0 : l_in[2][6 * t + q]);
+    double d[NB];
+    for (int q = 0; q < NB; ++q) d[q] = (c == fixed_cam) ? 0.0 : l_in[0][NB * t + q];
+    double it3[3] = {0.0, 0.0, 0.0};                   // trial intrinsics (models with per-camera intrinsics)
+    for (int q = 0; q < NB; ++q) {
+      const double xq = q < 6 ? l_cam[6 * t + q] : intr[3 * (size_t)c + (q - 6)];
+      if (q < 6) l_ct[6 * t + q] = xq + d[q];
+      else it3[q - 6] = xq + d[q];
+      acc[0] += l_in[2][NB * t + q] * d[q];
+      acc[1] += fmax(l_hcc[NH * t + UT(NB, q, q)], DIAG_FLOOR) * d[q] * d[q];
+      acc[2] += d[q] * ((c == fixed_cam) ? 0.0 : l_in[1][NB * t + q]);
       acc[3] += d[q] * d[q];
       acc[4] += xq * xq;
     }
-    write_vtil(l_cs + CS * t + 12, d, vtil + TA * c + 12);
+    if (NB > 6) {
+      for (int q = 0; q < NB - 6; ++q) intr_trial[3 * (size_t)c + q] = it3[q];
+    }
+    write_vtil<NB>(l_cs + CS * t + 12, d, vtil + CM::TA * (size_t)c + CM::VOFF);
     camera_state(l_ct + 6 * t, l_cst + CS * t);
-    for (int q = 0; q < 12; ++q) camA_trial[TA * c + q] = l_cst[CS * t + q];
+    CM::table_row(l_cst + CS * t, it3, camA_trial + CM::TA * (size_t)c);
   }
   __syncthreads();
   slice_write_back(cams_trial + 6 * (size_t)c0, l_ct, 6 * nc);

@@ -125,7 +125,7 @@ def make_config(name, seed=0, **overrides):
 
 
 def make_bal_like(n_cams=1723, n_pts=156502, n_obs_target=678718, seed=0, K4=REF_K4,
-                  image_wh=IMAGE_WH, pixel_sigma=0.5):
+                  image_wh=IMAGE_WH, pixel_sigma=0.5, return_truth=False):
     """BAL 'Ladybug'-like topology with the reference's shared-intrinsics 6-DoF camera:
     cameras along a long street-like path, each point visible only from a band of
     consecutive cameras around where it was first seen, track lengths long-tailed
@@ -165,7 +165,48 @@ def make_bal_like(n_cams=1723, n_pts=156502, n_obs_target=678718, seed=0, K4=REF
     uv = (uv + rng.normal(0.0, pixel_sigma, size=uv.shape)).astype(np.float32).astype(np.float64)
     cams0 = _perturb_cameras(rng, rvec, centre, 0.003, 0.02)
     pts0 = pts_true + rng.normal(0.0, 0.05, size=pts_true.shape)
-    return BAProblem(cams0, pts0, cam_idx.astype(np.int32), pt_idx.astype(np.int32), uv, K4.copy(), 0).validate()
+    prob = BAProblem(cams0, pts0, cam_idx.astype(np.int32), pt_idx.astype(np.int32), uv, K4.copy(), 0).validate()
+    if return_truth:
+        return prob, cams_true, pts_true
+    return prob
+
+
+def bal_project(cams9, pts, cam_idx, pt_idx):
+    """Pixels of the BAL camera [rvec | t | f k1 k2] (bal.py): P = R X + t, p = -P.xy / P.z, f (1 + k1 |p|^2 + k2 |p|^4) p.
+    Host-side numpy, used to synthesise BAL problems."""
+    R = rvecs_to_matrices(cams9[:, :3])
+    P = np.einsum('nij,nj->ni', R[cam_idx], pts[pt_idx]) + cams9[cam_idx, 3:6]
+    p = -P[:, :2] / P[:, 2:3]
+    n2 = (p * p).sum(axis=1, keepdims=True)
+    f, k1, k2 = cams9[cam_idx, 6:7], cams9[cam_idx, 7:8], cams9[cam_idx, 8:9]
+    return f * (1.0 + n2 * (k1 + k2 * n2)) * p
+
+
+def make_bal_problem(n_cams=1723, n_pts=156502, n_obs_target=678718, seed=0, pixel_sigma=0.5, focal=900.0):
+    """BASELINE config 5 as a BAL problem: the chain topology of ``make_bal_like`` (Ladybug's counts 1723 / 156 502 /
+    ~679 k; the real file is not available offline) with the BAL 9-parameter camera -- every camera its own focal length
+    (``focal`` +- 2 %) and radial distortion (k1 = -0.03 +- 0.01, k2 = +- 0.003), pixels projected through THAT model
+    plus N(0, pixel_sigma) noise and rounded to float32.  Start: poses and points perturbed as in ``make_bal_like``,
+    focal lengths off by 0.5 %, k1 off by 0.005, k2 = 0.  Returns a ``bal.BALProblem`` (camera 0 is the natural one to
+    hold fixed)."""
+    from .bal import BALProblem, from_pinhole
+    K4 = np.array([focal, focal, 640.0, 360.0])
+    start_pin, cams_true, pts_true = make_bal_like(n_cams, n_pts, n_obs_target, seed=seed, K4=K4, pixel_sigma=0.0,
+                                                   return_truth=True)
+    rng = np.random.default_rng(seed + 7919)
+    truth = from_pinhole(BAProblem(cams_true, pts_true, start_pin.cam_idx, start_pin.pt_idx, start_pin.uv, K4, 0))
+    start = from_pinhole(start_pin)
+    cams_t = truth.cams.copy()
+    cams_t[:, 6] = focal * (1.0 + 0.02 * rng.normal(size=n_cams))
+    cams_t[:, 7] = -0.03 + 0.01 * rng.normal(size=n_cams)
+    cams_t[:, 8] = 0.003 * rng.normal(size=n_cams)
+    uv = bal_project(cams_t, pts_true, truth.cam_idx, truth.pt_idx)
+    uv = (uv + rng.normal(0.0, pixel_sigma, size=uv.shape)).astype(np.float32).astype(np.float64)
+    cams_0 = start.cams.copy()
+    cams_0[:, 6] = cams_t[:, 6] * (1.0 + 0.005 * rng.normal(size=n_cams))
+    cams_0[:, 7] = cams_t[:, 7] + 0.005 * rng.normal(size=n_cams)
+    cams_0[:, 8] = 0.0
+    return BALProblem(cams_0, start.pts.copy(), start.cam_idx.copy(), start.pt_idx.copy(), uv).validate()
 
 
 def problem_to_map(prob: BAProblem, extra_newest=True):

@@ -93,6 +93,27 @@ def projectPoints(objectPoints, rvec, tvec, cameraMatrix, distCoeffs):
         out[i, 0, 0] = X[0]*z*K[0,0] + K[0,2]
         out[i, 0, 1] = X[1]*z*K[1,1] + K[1,2]
     return out, None
+
+# --- what src/pipeline.py (and the modules it imports) needs beyond the two calls above ---------------------------
+NORM_HAMMING = 6          # default argument in src/features.py:26, evaluated when the class body runs
+class DMatch: pass        # annotations in src/pose_estimator.py:7-9, evaluated when the def runs
+class KeyPoint: pass
+
+def triangulatePoints(projMatr1, projMatr2, projPoints1, projPoints2):
+    """OpenCV's linear triangulation (DLT) from its published algorithm: per point the 4x4 system
+    A = [x1 P1[2] - P1[0]; y1 P1[2] - P1[1]; x2 P2[2] - P2[0]; y2 P2[2] - P2[1]], result = right singular vector of the
+    smallest singular value, as a 4 x N array.  OpenCV leaves the vector's sign to its SVD; this stand-in fixes
+    w >= 0 (the repository's convention, csrc/ba_triangulate.hpp) -- the reference's '+ 1e-6' on w makes its output
+    depend on that choice at the 1e-6 / w level: parity unpinned at the cv2 boundary."""
+    P1 = np.asarray(projMatr1, dtype=np.float64); P2 = np.asarray(projMatr2, dtype=np.float64)
+    a = np.asarray(projPoints1, dtype=np.float64); b = np.asarray(projPoints2, dtype=np.float64)
+    n = a.shape[1]
+    out = np.empty((4, n))
+    for i in range(n):
+        A = np.stack([a[0, i] * P1[2] - P1[0], a[1, i] * P1[2] - P1[1], b[0, i] * P2[2] - P2[0], b[1, i] * P2[2] - P2[1]])
+        X = np.linalg.svd(A)[2][3]
+        out[:, i] = -X if X[3] < 0 else X
+    return out
 '''
 
 O3D_STANDIN = '''
@@ -116,6 +137,10 @@ io = _IO()
 
 VIS_STANDIN = '''
 def plot_and_save_sparsity(*a, **k):
+    pass
+def plot_and_save_trajectory_2d(*a, **k):
+    pass
+def plot_and_save_trajectory_3d(*a, **k):
     pass
 '''
 
@@ -352,5 +377,49 @@ def main():
               "rmse", np.sqrt((res.fun ** 2).sum() / len(observations)))
 
 
+def triangulation_goldens():
+    """Section E: the reference's own VisualOdometryPipeline._triangulate_points
+    (src/pipeline.py:315-336), imported unmodified, on three two-view scenes -> tests/golden/tri_scenes.npz: inputs, the
+    returned (3, kept) array, the kept indices and the printed log line.  cv2.triangulatePoints is the stand-in above."""
+    load_reference()
+    import pipeline                                   # noqa: E402  (the reference file; its other imports are the reference's own modules)
+    K = np.array([[912.7820434570312, 0.0, 650.2929077148438],
+                  [0.0, 913.0294189453125, 362.7241516113281], [0.0, 0.0, 1.0]])
+    with contextlib.redirect_stdout(io.StringIO()):
+        vo = pipeline.VisualOdometryPipeline(K, None, None, None, {})
+    import cv2
+    out = {"K": K}
+    scenes = [("wide", 0, 400, 0.4, 0.5), ("behind", 1, 300, 0.3, 0.3), ("degenerate", 2, 200, 0.05, 0.0)]
+    for name, seed, n, base, noise in scenes:
+        rng = np.random.default_rng(40 + seed)
+        R = cv2.Rodrigues(np.array([0.02, -0.05, 0.01]) * (1.0 if name != "degenerate" else 0.2))[0]
+        t = base * np.array([[-1.0], [0.075], [0.125 if name != "behind" else -0.5]])
+        X = np.stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(5, 20, n)], axis=1)
+        if name == "behind":
+            X[:25, 2] *= -1.0                          # behind both cameras
+            X[25:50] = np.stack([rng.uniform(-0.02, 0.02, 25), rng.uniform(-0.02, 0.02, 25), rng.uniform(0.03, 0.12, 25)], axis=1)
+            #  ^ in front of camera 1 (z > 0) but behind camera 2, whose frame is shifted by t_z = -0.15: only the second mask drops them
+        if name == "degenerate":
+            X[:40] *= 1e7                              # points at "infinity": parallel rays, w ~ 0, the + 1e-6 decides
+        x1 = X @ K.T
+        x2 = (X @ R.T + t.ravel()) @ K.T
+        p1 = x1[:, :2] / x1[:, 2:] + rng.normal(0, noise, (n, 2))
+        p2 = x2[:, :2] / x2[:, 2:] + rng.normal(0, noise, (n, 2))
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            pts, idx = vo._triangulate_points(R, t, p1, p2)
+        out.update({f"{name}_R": R, f"{name}_t": t, f"{name}_pts1": p1, f"{name}_pts2": p2, f"{name}_out": pts,
+                    f"{name}_idx": idx, f"{name}_log": np.array(buf.getvalue())})
+        print(name, "kept", len(idx), "of", n, "|", buf.getvalue().strip())
+    with contextlib.redirect_stdout(io.StringIO()):
+        empty = vo._triangulate_points(np.eye(3), np.zeros((3, 1)), np.zeros((0, 2)), np.zeros((0, 2)))
+    assert empty == (None, None)
+    np.savez_compressed(os.path.join(OUT, "tri_scenes.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "tri":
+        triangulation_goldens()                       # only section E
+    else:
+        main()
+        triangulation_goldens()

@@ -81,3 +81,43 @@ def test_device_triangulation_matches_the_oracle():
         assert buf.getvalue() == f"    -> Triangulation: Kept {int(vref.sum())} of {n} points.\n"
         np.testing.assert_allclose(pts.T, ref[vref], rtol=0, atol=1e-9 * np.abs(ref).max())
         assert triangulate_points(K, R, t, np.zeros((0, 2)), np.zeros((0, 2)), solver=s) == (None, None)
+
+
+# ---- pinned by the reference's own function (tests/golden/make_golden.py section E) ------------------------------------------
+SCENES = ("wide", "behind", "degenerate")
+
+
+def _tri_golden():
+    from tests.helpers import load_golden
+    return load_golden("tri_scenes")
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_oracle_triangulation_matches_the_reference_function(name):
+    """tri_scenes.npz holds what the imported, unmodified VisualOdometryPipeline._triangulate_points returned
+    (src/pipeline.py:315-336) for three scenes: a wide baseline, one with points behind both cameras and points in front of
+    the first but behind the second camera (each cheirality mask decides alone), and one with points at infinity where the
+    '+ 1e-6' on w is what is divided by.  (cv2.triangulatePoints itself: the generator's numpy DLT -- parity unpinned at
+    the cv2 boundary.)"""
+    g = _tri_golden()
+    xyz, valid = o.triangulate_points(g["K"], g[name + "_R"], g[name + "_t"], g[name + "_pts1"], g[name + "_pts2"])
+    assert np.array_equal(np.where(valid)[0], g[name + "_idx"])
+    want = g[name + "_out"]
+    assert want.shape == (3, int(valid.sum()))
+    assert np.abs(xyz[valid].T - want).max() <= 1e-10 * np.abs(want).max()
+    assert str(g[name + "_log"]) == f"    -> Triangulation: Kept {int(valid.sum())} of {len(valid)} points.\n"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SCENES)
+def test_device_triangulation_matches_the_reference_function(name):
+    """The drop-in wrapper (same arguments, return value and log line as the reference's method) on the device against
+    the reference's recorded outputs: kept indices identical, points <= 1e-9 relative, the log line byte for byte."""
+    g = _tri_golden()
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        pts, idx = triangulate_points(g["K"], g[name + "_R"], g[name + "_t"], g[name + "_pts1"], g[name + "_pts2"])
+    want = g[name + "_out"]
+    assert np.array_equal(idx, g[name + "_idx"])
+    assert pts.shape == want.shape and np.abs(pts - want).max() <= 1e-9 * np.abs(want).max()
+    assert buf.getvalue() == str(g[name + "_log"])
