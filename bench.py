@@ -34,16 +34,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def algorithmic_bytes(n_cams, n_pts, n_obs):
-    """SURVEY.md 8(d) minimum-traffic model, fp64, int32 indices (bytes)."""
-    P = 24 * n_pts + 48 * n_cams
-    V = 48 * n_cams
+def algorithmic_bytes(n_cams, n_pts, n_obs, cam_params=6):
+    """SURVEY.md 8(d) minimum-traffic model, fp64, int32 indices (bytes).  cam_params: 6 for the reference's pinhole
+    (rvec | t), 9 for the BAL camera (rvec | t | f k1 k2): P = 24 Np + 8 cam_params Nc, V = 8 cam_params Nc, and the
+    packed camera blocks grow from 21 to 45 doubles."""
+    P = 24 * n_pts + 8 * cam_params * n_cams
+    V = 8 * cam_params * n_cams
     Q = 24 * n_pts
     D = 48 * n_pts
+    hcc = 8 * (cam_params * (cam_params + 1) // 2) * n_cams
     b = dict(
         schur_pt=8 * n_obs + P + D + Q + V,            # index pass by point: W^T v, Hpp^-1
         schur_cam=8 * n_obs + P + Q + 3 * V,           # index pass by camera: W y, S v assembly
-        lin=24 * n_obs + P + D + Q + 168 * n_cams + V,
+        lin=24 * n_obs + P + D + Q + hcc + V,
         back=8 * n_obs + P + D + 2 * Q + V,
         evalc=24 * n_obs + P,
     )
@@ -118,6 +121,41 @@ def cpu_baseline_vectorised(prob, n_groups, budget_s=10.0):
                                     f"({t_sweep * 1e3:.1f} ms each), x ({n_groups}+1) sweeps per TRF iteration; LSMR not timed")
 
 
+def cpu_baseline_bal(bal, budget_s=15.0):
+    """--camera bal: the reference has no BAL camera (its only camera is cv2.projectPoints(..., distCoeffs=None),
+    src/bundle_adjuster.py:67), so the CPU figure is the reference's ALGORITHM (scipy TRF with 2-point finite differences over
+    the colour groups of the 0/1 pattern: (n_groups + 1) residual sweeps per iteration, LSMR not timed) on the oracle's
+    vectorised BAL residual -- one host core, numpy."""
+    from oracle import ba_oracle as o
+    from scipy.optimize._numdiff import group_columns
+    from scipy.sparse import coo_matrix
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < 5.0 and n < 50):
+        o.bal_residuals(bal.cams, bal.pts, bal.cam_idx, bal.pt_idx, bal.uv)
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    t_sweep = (time.perf_counter() - t0) / n
+    nobs, nc = bal.n_obs, bal.n_cams
+    rows, cols = [], []
+    r2 = np.repeat(2 * np.arange(nobs), 2) + np.tile([0, 1], nobs)
+    free = np.repeat(bal.cam_idx != 0, 2)
+    for j in range(9):
+        rows.append(r2[free]); cols.append(np.repeat(9 * bal.cam_idx.astype(np.int64) + j, 2)[free])
+    for j in range(3):
+        rows.append(r2); cols.append(np.repeat(9 * nc + 3 * bal.pt_idx.astype(np.int64) + j, 2))
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    tg = time.perf_counter()
+    A = coo_matrix((np.ones(rows.size, dtype=np.int8), (rows, cols)), shape=(2 * nobs, 9 * nc + 3 * bal.n_pts)).tocsr()
+    n_groups = int(group_columns(A).max()) + 1
+    tg = time.perf_counter() - tg
+    return dict(value=1.0 / ((n_groups + 1) * t_sweep), unit="LM iterations/s", cores=1, kind="port", n_groups=n_groups,
+                sample=f"{n} vectorised numpy sweeps of the BAL residual over all {nobs} observations ({t_sweep * 1e3:.1f} ms each), "
+                       f"x ({n_groups}+1) sweeps per TRF iteration (colour groups of the 2x9 / 2x3 pattern by scipy group_columns, "
+                       f"{tg:.1f} s); LSMR not timed; host has {os.cpu_count()} cores")
+
+
 class _stdout_to_stderr:
     """RCCL prints a version banner on file descriptor 1 when a communicator comes up; stdout must carry exactly one JSON
     line, so the descriptor points at stderr while the transport is being set up."""
@@ -140,6 +178,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C3", choices=["C1", "C2", "C3", "C5", "C3x10"])
+    ap.add_argument("--camera", default="pinhole", choices=["pinhole", "bal"],
+                    help="bal (with --config C5): BASELINE config 5 as stated -- the BAL 9-parameter camera [rvec | t | f k1 k2], "
+                         "f / k1 / k2 distinct per camera and adjusted with the poses (ba_solve_bal)")
     ap.add_argument("--loss", default="huber", choices=["huber", "linear"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--pcg-tol", type=float, default=0.1)
@@ -164,7 +205,19 @@ def main():
     from bundle_adjustment_amd.problem import extract_shard, shard_by_landmark
     from bundle_adjustment_amd.synthetic import make_bal_like, make_config
 
-    prob = make_bal_like(seed=args.seed) if args.config == "C5" else make_config(args.config, seed=args.seed)
+    intr0 = None
+    if args.camera == "bal":
+        if args.config != "C5":
+            raise SystemExit("--camera bal is BASELINE config 5: use it with --config C5")
+        from bundle_adjustment_amd.problem import BAProblem
+        from bundle_adjustment_amd.synthetic import make_bal_problem
+        bal = make_bal_problem(seed=args.seed)
+        # the handle's problem upload is camera-model agnostic (poses, points, observation lists); the per-camera
+        # (f, k1, k2) travel with every ba_solve_bal call
+        prob = BAProblem(np.ascontiguousarray(bal.cams[:, :6]), bal.pts, bal.cam_idx, bal.pt_idx, bal.uv, np.array([1.0, 1.0, 0.0, 0.0]), 0)
+        intr0 = np.ascontiguousarray(bal.cams[:, 6:9])
+    else:
+        prob = make_bal_like(seed=args.seed) if args.config == "C5" else make_config(args.config, seed=args.seed)
     n_obs_total = prob.n_obs
     shard = prob
     if world > 1:
@@ -225,9 +278,15 @@ def main():
         solver.set_problem(shard)
 
     # every stopping tolerance off so that exactly K iterations run; gtol is tiny but POSITIVE so that the
-    # per-iteration gradient-norm kernel every production run() launches (k_absmax2) is inside the timed region
+    # per-iteration gradient-norm work of a production run() (per-workgroup maxima folded by the first PCG probe) is inside
+    # the timed region
     kw = dict(loss=args.loss, ftol=0.0, xtol=0.0, gtol=1e-300, pcg_tol=args.pcg_tol, pcg_max_iters=args.pcg_max_iters,
               preconditioner=args.precond, jacobian_precision=1 if args.jacobian == "f32" else 0)
+
+    def run_solve(**k):
+        if intr0 is not None:
+            return solver.solve_bal_resident(intr0.copy(), **k)      # (the copy: ba_solve_bal adjusts the intrinsics in place)
+        return solver.solve(**k)
 
     def barrier():
         solver.synchronize()
@@ -236,7 +295,7 @@ def main():
 
     # warmup: W untimed LM iterations, then restore the initial guess
     if args.warmup > 0:
-        solver.solve(max_iters=args.warmup, **kw)
+        run_solve(max_iters=args.warmup, **kw)
     # timed region: EXACTLY K LM iterations from the same initial guess, bracketed by barrier + device sync on both
     # sides; repeated `--repeats` times (the 5 ms of one repeat is one sample; value = the MEDIAN repeat, max over
     # ranks per repeat), parameters restored outside the timed region between repeats
@@ -245,7 +304,7 @@ def main():
         solver.set_params(shard.cams, shard.pts)
         barrier()
         t0 = time.perf_counter()
-        out = solver.solve(max_iters=args.steps, **kw)
+        out = run_solve(max_iters=args.steps, **kw)
         solver.synchronize()
         dt_rep = time.perf_counter() - t0
         barrier()
@@ -262,22 +321,25 @@ def main():
     # per-kernel durations with HIP events on the solver's stream: same workload again
     solver.set_params(shard.cams, shard.pts)
     solver.profile(reset=True)
-    solver.solve(max_iters=args.steps, profile=1, **kw)
+    run_solve(max_iters=args.steps, profile=1, **kw)
     prof = solver.profile()
-    ab = algorithmic_bytes(prob.n_cams, shard.n_pts, shard.n_obs)
+    ab = algorithmic_bytes(prob.n_cams, shard.n_pts, shard.n_obs, 9 if intr0 is not None else 6)
     dom = max(("schur_pt", "schur_cam"), key=lambda k: prof.get(k, {}).get("total_ms", 0.0))
-    traffic = None
+    traffic, traffic_source = None, None
     if dom in prof and prof[dom].get("working_launches", 0) > 0:
         dom_us = prof[dom]["working_mean_us"]        # launches that exit at once after PCG convergence are left out
         achieved = ab[dom] / (dom_us * 1e-6) / 1e9
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if world == 1 and args.config == "C3" and os.path.exists(tpath):     # the PMC passes were run on this workload only
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                tj = json.load(open(tpath))
+                traffic, traffic_source = tj.get(dom), tj.get("_source", "profiles/traffic.json (rocprofv3 PMC passes of an earlier run of this command)")
             except Exception:
                 traffic = None
         roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                        # traffic is NOT measured by this run: PMC counters need their own rocprofv3 passes (the guide's rule)
+                        traffic_source=traffic_source,
                         algorithmic_bytes_per_launch=ab[dom], mean_launch_us=round(dom_us, 3),
                         launches=prof[dom]["working_launches"], early_exit_launches=prof[dom]["launches"] - prof[dom]["working_launches"],
                         # what rocprofv3 --stats averages: every launch of the kernel, early exits included
@@ -304,17 +366,19 @@ def main():
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline_port(prob)
+            cpu = cpu_baseline_bal(bal) if intr0 is not None else cpu_baseline_port(prob)
         line = {
             "metric": "LM iterations/sec + final reprojection RMSE, 1k cams / 100k pts",   # BASELINE.json; RMSE: config.final_rmse_px
             "value": round(steps_done / dt, 3), "unit": "LM iterations/s", "n_gpus": world, "steps": steps_done,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / max(steps_done, 1), 4),
             "repeats": len(dts), "value_min": round(steps_done / max(dts), 3), "value_max": round(steps_done / min(dts), 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64" if args.jacobian == "f64" else "f64 (f32 Jacobian blocks in the PCG passes)",
+            "dtype": "f64" if args.jacobian == "f64" else "f64 accumulation and solve, f32 Jacobian blocks in the PCG passes",
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {prob.n_cams} cams / {prob.n_pts} pts / {n_obs_total} obs, "
-                                   f"loss={args.loss}, LM+Schur+PCG(tol {args.pcg_tol})",
+                                   f"loss={args.loss}, LM+Schur+PCG(tol {args.pcg_tol})"
+                                   + (", BAL 9-parameter camera (f, k1, k2 per camera, adjusted)" if intr0 is not None else ""),
+                       "camera": args.camera,
                        "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU", "comm": comm_note,
                        "world": world, "transport": transport, "ranks_in_communicator": ranks_up,
                        "devices_visible": ndev, "device_of_rank0": dev,
@@ -328,7 +392,8 @@ def main():
         if cpu is not None:
             ng = cpu.pop("n_groups")
             line["cpu_baseline"] = cpu
-            line["cpu_baseline_vectorised"] = cpu_baseline_vectorised(prob, ng)
+            if intr0 is None:
+                line["cpu_baseline_vectorised"] = cpu_baseline_vectorised(prob, ng)
         print(json.dumps(line), flush=True)
     solver.close()
     if dist is not None:

@@ -187,6 +187,7 @@ struct ba_handle {
   DBuf<int2> run_pairs;
   DBuf<double> coarseU, coarseE, coarseEinv, coarse_rc, coarse_info;
   DBuf<long long> coarseEint;
+  DBuf<long long> dev_seq;     // device word a riding k_scalars publishes the step's sequence number in (ba_kernels.hpp, "riders")
   DBuf<double> verdict;        // PCG verdict words {gamma, zeta, finished, -} x 2 iteration parities (point pass -> camera pass, vector kernel)
   int cam_segl = 64;           // lanes per (camera, partition) segment in the PCG camera pass (BA_CAM_SEGL, tuning)
   int nblkP = 1, ppb = 1, nblkV = 1;
@@ -352,6 +353,7 @@ extern "C" int ba_destroy(ba_handle* h) {
   h->coarseU.release(); h->coarseE.release(); h->coarseEinv.release(); h->coarse_rc.release(); h->coarse_info.release();
   h->coarseEint.release();
   h->verdict.release();
+  h->dev_seq.release();
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->h_flags) (void)hipHostFree(h->h_flags);
   if (h->h_small) (void)hipHostFree(h->h_small);
@@ -896,6 +898,8 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(h->st.alloc(2));
   HIPCHECK(h->verdict.alloc(8));
   HIPCHECK(hipMemsetAsync(h->verdict.p, 0, 8 * sizeof(double), h->stream));
+  HIPCHECK(h->dev_seq.alloc(2));
+  HIPCHECK(hipMemsetAsync(h->dev_seq.p, 0, 2 * sizeof(long long), h->stream));
   HIPCHECK(hipMemsetAsync(h->camA[0].p, 0, TA_MAX * (size_t)Nc * sizeof(double), h->stream));
   HIPCHECK(hipMemsetAsync(h->camA[1].p, 0, TA_MAX * (size_t)Nc * sizeof(double), h->stream));
   h->lb = 0;
@@ -1021,15 +1025,27 @@ static void launch_residual(ba_handle* h, int which, bool robust, double fscale,
 // with_step: also the step partials and the PCG verdict for iteration k; on a single rank the
 // results go straight to the host-mapped mirror (no copy kernel)
 // decide (single rank): the same kernel also computes the gain ratio and the next damping (lm_decide)
+static ScalarsArgs scalars_args(ba_handle* h, bool with_step, int k, double tol2, int min_iters, long long seq, double cost_cur,
+                                double lambda) {
+  const bool direct = with_step && !h->multi;         // results straight into host-mapped memory + sequence word
+  ScalarsArgs a;
+  a.partR = h->partR.p; a.nR = NPART * h->Nc;
+  a.partB = h->partB.p; a.nB = (with_step && h->Np > 0) ? h->nblkP + h->nblkL : 0;
+  a.partC = h->partC.p; a.nC = with_step ? h->nblkV : 0;
+  a.kit = k;
+  a.st = with_step ? (const PcgState*)h->st.p : (const PcgState*)nullptr;
+  a.partV = h->partV.p; a.nblkV = h->nblkV;
+  a.tol2 = tol2; a.min_iters = min_iters;
+  a.scal = h->scal.p; a.scal_host = direct ? h->d_scal_host : (double*)nullptr;
+  a.host_flag = direct ? h->d_flags + 2 : (long long*)nullptr; a.seq = seq;
+  a.decide = direct ? 1 : 0; a.cost_cur = cost_cur; a.lambda = lambda;
+  a.dev_flag = nullptr; a.on = 0;
+  return a;
+}
 static void launch_scalars(ba_handle* h, bool with_step, int k = 0, double tol2 = 0.0, int min_iters = 0, long long seq = 0,
                            double cost_cur = 0.0, double lambda = 0.0) {
   Scope sc(h, BA_K_MISC);
-  const bool direct = with_step && !h->multi;         // results straight into host-mapped memory + sequence word
-  BA_LAUNCH(k_scalars, dim3(1), dim3(1024), 0, h->stream, h->partR.p, NPART * h->Nc, h->partB.p,
-                     (with_step && h->Np > 0) ? h->nblkP + h->nblkL : 0, h->partC.p, with_step ? h->nblkV : 0, k,
-                     with_step ? (const PcgState*)h->st.p : (const PcgState*)nullptr, h->partV.p, h->nblkV, tol2, min_iters,
-                     h->scal.p, direct ? h->d_scal_host : (double*)nullptr, direct ? h->d_flags + 2 : (long long*)nullptr, seq,
-                     direct ? 1 : 0, cost_cur, lambda);
+  BA_LAUNCH(k_scalars, dim3(1), dim3(1024), 0, h->stream, scalars_args(h, with_step, k, tol2, min_iters, seq, cost_cur, lambda));
 }
 // spin on a host-mapped sequence word until it reaches `target` (the device publishes with a
 // system-scope release); a wall-clock limit turns a wedged GPU into an error instead of a hang
@@ -1087,12 +1103,14 @@ static PtWork pt_work_long(ba_handle* h) { return PtWork{h->long_pts.p, h->n_lon
 // point half at parameter set `w` into point-buffer set `pbuf`, with the damped inverse / y0 at `lambda` fused in
 // (lam_dev != null: the damping is read from that device word instead -- a speculated pass, see ba_solve)
 template <class CM>
-static void launch_lin_pt_t(ba_handle* h, int w, int pbuf, bool robust, double fscale, double lambda, const double* lam_dev) {
+static void launch_lin_pt_t(ba_handle* h, int w, int pbuf, bool robust, double fscale, double lambda, const double* lam_dev,
+                            const ScalarsArgs& sa) {
+  const int ride = sa.on;                              // the step's scalar fold + verdict as workgroup 0 of this launch
 #define LP_HEAD h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_uv.p, h->blk_win.p
 #define LP_TAIL h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, lambda, lam_dev, h->Hpp[pbuf].p, h->bp[pbuf].p, h->p_w[pbuf].p,      \
-                h->p_camf[pbuf].p, h->Hppinv[pbuf].p, h->y0[pbuf].p, h->partG[pbuf].p
-#define LP_LAUNCH(R, L, LN, G, WK) BA_LAUNCH((k_pt_linearize<CM, R, L, LN>), dim3(G), dim3(PT_THREADS), lds_of(h), h->stream, LP_HEAD, WK, LP_TAIL)
-#define LP_BOTH(R, L) BA_LAUNCH((k_pt_linearize_both<CM, R, L>), dim3(h->nblkP + h->nblkL), dim3(PT_THREADS), lds_of(h), h->stream, \
+                h->p_camf[pbuf].p, h->Hppinv[pbuf].p, h->y0[pbuf].p, h->partG[pbuf].p, sa
+#define LP_LAUNCH(R, L, LN, G, WK) BA_LAUNCH((k_pt_linearize<CM, R, L, LN>), dim3((G) + ride), dim3(PT_THREADS), lds_of(h), h->stream, LP_HEAD, WK, LP_TAIL)
+#define LP_BOTH(R, L) BA_LAUNCH((k_pt_linearize_both<CM, R, L>), dim3(h->nblkP + h->nblkL + ride), dim3(PT_THREADS), lds_of(h), h->stream, \
                                          LP_HEAD, wk, h->nblkP, wl, LP_TAIL)
   const PtWork wk = pt_work(h), wl = pt_work_long(h);
   if (h->nblkL) {          // short and long tracks in one launch
@@ -1117,10 +1135,14 @@ static void launch_lin_pt_t(ba_handle* h, int w, int pbuf, bool robust, double f
 #undef LP_HEAD
 #undef LP_TAIL
 }
-static void launch_lin_pt(ba_handle* h, int w, int pbuf, bool robust, double fscale, double lambda, const double* lam_dev = nullptr) {
+static void launch_lin_pt(ba_handle* h, int w, int pbuf, bool robust, double fscale, double lambda, const double* lam_dev = nullptr,
+                          const ScalarsArgs* rider = nullptr) {
   if (h->Np == 0) return;
   Scope sc(h, BA_K_LINEARIZE_PT);
-#define CALL_T(CM) launch_lin_pt_t<CM>(h, w, pbuf, robust, fscale, lambda, lam_dev)
+  ScalarsArgs sa;
+  if (rider) sa = *rider;
+  else { memset(&sa, 0, sizeof sa); }
+#define CALL_T(CM) launch_lin_pt_t<CM>(h, w, pbuf, robust, fscale, lambda, lam_dev, sa)
   BA_BY_MODEL(CALL_T);
 #undef CALL_T
 }
@@ -1177,21 +1199,22 @@ static void launch_cam_schur(ba_handle* h, bool robust, bool diag, bool pcg, int
 // gmax_out (first PCG probe behind a fresh linearisation): host-mapped word that receives max |gradient|
 template <class CM>
 static void launch_pt_schur_t(ba_handle* h, bool robust, int mode, int k, double tol2, int min_iters, long long flag_base,
-                              double* gmax_out) {
+                              double* gmax_out, const CamUpdateArgs& cu) {
   const int w = h->cur;
+  const int ride = (mode == 1) ? cu.n_blocks : 0;      // the camera update as extra workgroups of the back substitution
 #define PS_HEAD h->camA[w].p, h->ptab[w].p, h->pt_off.p, (robust ? h->p_camf[h->pb].p : h->p_cam.p), h->p_w[h->pb].p,                 \
                 h->Hppinv[h->pb].p, h->blk_win.p
 #define PS_TAIL h->K4[0], h->K4[1], h->fixed, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0[h->pb].p,     \
                 h->Hpp[h->pb].p, h->bp[h->pb].p, h->ptab[1 - w].p, h->partB.p, flag, flag_base, h->verdict.p,                      \
-                (const double*)h->partG[h->pb].p, h->nblkP + h->nblkL, (const double*)h->partGc.p, h->nblkV, gmax_out
-  const size_t lds = lds_of(h) + (size_t)h->debug_lds_extra;
+                (const double*)h->partG[h->pb].p, h->nblkP + h->nblkL, (const double*)h->partGc.p, h->nblkV, gmax_out, cu
+  const size_t lds = std::max(lds_of(h), ride ? cam_update_lds_doubles<CM>() * sizeof(double) : (size_t)0) + (size_t)h->debug_lds_extra;
   long long* flag = (mode == 0 && flag_base > 0) ? h->d_flags : (long long*)nullptr;
   // data with long tracks: short and long tracks in one launch (workgroup 0 publishes the verdict)
 #define PS_ONE(R, M, L, LN, JT) \
-  BA_LAUNCH((k_pt_schur<CM, R, M, L, LN, JT>), dim3(h->nblkP), dim3(PT_THREADS), lds, h->stream, PS_HEAD, wk, PS_TAIL)
+  BA_LAUNCH((k_pt_schur<CM, R, M, L, LN, JT>), dim3(h->nblkP + ride), dim3(PT_THREADS), lds, h->stream, PS_HEAD, wk, PS_TAIL)
 #define PS_LAUNCH(R, M, L, JT)                                                                                              \
   do {                                                                                                                      \
-    if (h->nblkL) BA_LAUNCH((k_pt_schur_both<CM, R, M, L, JT>), dim3(h->nblkP + h->nblkL), dim3(PT_THREADS), lds,  \
+    if (h->nblkL) BA_LAUNCH((k_pt_schur_both<CM, R, M, L, JT>), dim3(h->nblkP + h->nblkL + ride), dim3(PT_THREADS), lds,  \
                                      h->stream, PS_HEAD, wk, h->nblkP, wl, PS_TAIL);                                        \
     else {                                                                                                                  \
       switch (h->lanes) {                                                                                                   \
@@ -1219,7 +1242,7 @@ static void launch_pt_schur_t(ba_handle* h, bool robust, int mode, int k, double
 #undef PS_TAIL
 }
 static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double tol2, int min_iters, long long flag_base = 0,
-                            double* gmax_out = nullptr) {
+                            double* gmax_out = nullptr, const CamUpdateArgs* rider = nullptr) {
   if (h->Np == 0) {
     // an empty landmark shard (multi-rank): no point pass, but the PCG probe's verdict is still owed
     if (mode == 0 && flag_base > 0) {
@@ -1230,7 +1253,10 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
     return;
   }
   Scope sc(h, mode == 0 ? BA_K_SCHUR_PT : BA_K_BACKSUB);
-#define CALL_T(CM) launch_pt_schur_t<CM>(h, robust, mode, k, tol2, min_iters, flag_base, gmax_out)
+  CamUpdateArgs cu;
+  if (rider) cu = *rider;
+  else memset(&cu, 0, sizeof cu);
+#define CALL_T(CM) launch_pt_schur_t<CM>(h, robust, mode, k, tol2, min_iters, flag_base, gmax_out, cu)
   BA_BY_MODEL(CALL_T);
 #undef CALL_T
 }
@@ -1696,6 +1722,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     return BA_OK;
   }
   const bool debug_poison = getenv("BA_DEBUG_POISON_TRIAL") != nullptr;     // tests: every trial cost comes out NaN
+  const bool riders = getenv("BA_NO_RIDERS") == nullptr;                    // (tuning / tests: the O(Nc) kernels as launches of their own)
   double lambda = opts->initial_lambda, nu = 2.0;
   int it = 0, status = 0;
   bool need_linearize = true;      // a linearisation at the current parameters is needed before the next damped system
@@ -1799,14 +1826,22 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     // ---- step, trial point, gain-ratio scalars
     Range r_step("step");
     {
-      Scope sc(h, BA_K_MISC);
-#define UPD_ARGS h->cams[h->cur].p, (const double*)h->intr[h->cur].p, h->x.p, h->r.p, h->HccBc.p, bc_ptr(h), h->cs[h->cur].p, Nc, h->fixed, \
-                 h->cams[1 - h->cur].p, h->intr[1 - h->cur].p, h->cs[1 - h->cur].p, h->camA[h->cur].p, h->camA[1 - h->cur].p, h->partC.p
-      if (h->model) BA_LAUNCH(k_cam_update<BalCam>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, UPD_ARGS);
-      else          BA_LAUNCH(k_cam_update<Pinhole>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, UPD_ARGS);
-#undef UPD_ARGS
+      // K7a + K6.  The camera update does not feed the back substitution except through the step's vt, which the point
+      // workgroups compute themselves for the rows of their LDS windows: it rides along the same launch as extra
+      // workgroups (ba_kernels.hpp, "riders") whenever every window is staged in LDS; else it is a launch of its own.
+      CamUpdateArgs cu;
+      cu.cams = h->cams[h->cur].p; cu.intr = h->intr[h->cur].p; cu.dc = h->x.p; cu.rpcg = h->r.p; cu.Hcc = h->HccBc.p; cu.bc = bc_ptr(h);
+      cu.cs = h->cs[h->cur].p; cu.cams_trial = h->cams[1 - h->cur].p; cu.intr_trial = h->intr[1 - h->cur].p; cu.cs_trial = h->cs[1 - h->cur].p;
+      cu.vtil = h->camA[h->cur].p; cu.camA_trial = h->camA[1 - h->cur].p; cu.partC = h->partC.p;
+      cu.n_cams = Nc; cu.fixed_cam = h->fixed; cu.n_blocks = h->nblkV;
+      const bool ride = riders && all_lds_of(h) && h->Np > 0;
+      if (!ride) {
+        Scope sc(h, BA_K_MISC);
+        if (h->model) BA_LAUNCH(k_cam_update<BalCam>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, cu);
+        else          BA_LAUNCH(k_cam_update<Pinhole>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, cu);
+      }
+      launch_pt_schur(h, robust, 1, 0, 0.0, 0, 0, nullptr, ride ? &cu : nullptr);
     }
-    launch_pt_schur(h, robust, 1, 0, 0.0, 0);
     // Speculation: unless this is the last iteration, the cost at the trial point comes out of the camera half of
     // the NEXT linearisation computed there (one pass instead of two), into the other c_w / partL buffers; the step's
     // verdict (gain ratio, next damping) is computed on the device right behind it, and while the host reads it the
@@ -1821,13 +1856,20 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     }
     if (debug_poison) BA_LAUNCH(k_poison, dim3(1), dim3(64), 0, h->stream, h->partR.p);
     const long long seq = ++h->step_seq;
-    launch_scalars(h, true, k, tol2, opts->pcg_min_iters, seq, cost, lambda);
+    // the step's scalar fold + verdict: single rank with a speculated point half behind it -> workgroup 0 of that launch
+    // (the point workgroups pick the next damping up through a device word); else a launch of its own
+    const bool ride_scalars = riders && speculated && !h->multi && h->Np > 0;
+    if (!ride_scalars) launch_scalars(h, true, k, tol2, opts->pcg_min_iters, seq, cost, lambda);
     if (h->multi) {           // the six sums over ranks, then the verdict on the all-reduced block; same host-mapped mirror + word
       if (int rc = allreduce(h, h->scal.p, 6)) return rc;
       Scope sc(h, BA_K_MISC);
       BA_LAUNCH(k_decide, dim3(1), dim3(64), 0, h->stream, h->scal.p, cost, lambda, h->d_scal_host, h->d_flags + 2, seq);
     }
-    if (speculated) launch_lin_pt(h, 1 - h->cur, 1 - h->pb, robust, fs, 0.0, h->scal.p + S_LAM_NEXT);
+    if (speculated) {
+      ScalarsArgs sa = scalars_args(h, true, k, tol2, opts->pcg_min_iters, seq, cost, lambda);
+      sa.on = 1; sa.dev_flag = h->dev_seq.p;
+      launch_lin_pt(h, 1 - h->cur, 1 - h->pb, robust, fs, 0.0, h->scal.p + S_LAM_NEXT, ride_scalars ? &sa : nullptr);
+    }
     if (int rc = wait_flag(h, 2, seq)) return rc;
     if (pcg_done_iters < 0) pcg_done_iters = (h->h_scal[S_PCG_FIN] != 0.0) ? (int)h->h_scal[S_PCG_ITERS] : k;
     sum->pcg_iterations += pcg_done_iters;

@@ -767,6 +767,52 @@ __device__ inline void block_combine(double (&v)[M], double* __restrict__ sm) {
   }
 }
 
+// vt = (M v_r, v_t, ..): a camera vector in the form the point passes multiply with (ba_models.hpp)
+template <int NB>
+__device__ inline void write_vtil(const double* __restrict__ M, const double (&v)[NB], double* __restrict__ dst) {
+  dst[0] = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+  dst[1] = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+  dst[2] = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+#pragma unroll
+  for (int q = 3; q < NB; ++q) dst[q] = v[q];
+}
+
+// ---- riders: small one-workgroup-per-unit kernels that run as EXTRA workgroups of a point-pass launch -------------------
+// A point pass occupies one workgroup per compute unit on part of the chip (C3: 196 of 256) and the O(Nc) / O(1) kernels
+// between the passes are pure launch latency on a handful of waves.  Two of them have no dependence on the point pass
+// they now share a launch with, only a one-way hand-over:
+//   * the camera update (K7a) rides along the back substitution: the trial cameras are not needed before the NEXT kernel;
+//     the one thing the back substitution needs from it -- the step in the point passes' form, vt = (M dc_r, dc_t, ..) --
+//     is computed by every point workgroup for the rows of its own LDS window, right behind the table copy;
+//   * the step's scalar fold + LM verdict (k_scalars) rides along the speculated point half of the next linearisation as
+//     workgroup 0: the point workgroups need its result (the damping an accepted step continues with) only when they
+//     invert their first Hpp, a whole observation loop later, and pick it up through one device-scope word.
+// CamUpdateArgs / ScalarsArgs are the riders' arguments (n_blocks / on = 0: no rider in this launch).
+struct CamUpdateArgs {
+  const double *cams, *intr, *dc, *rpcg, *Hcc, *bc, *cs;
+  double *cams_trial, *intr_trial, *cs_trial, *vtil, *camA_trial, *partC;
+  int n_cams, fixed_cam, n_blocks;
+};
+struct ScalarsArgs {
+  const double* partR; int nR;
+  const double* partB; int nB;
+  const double* partC; int nC;
+  int kit;
+  const PcgState* st;
+  const double* partV; int nblkV;
+  double tol2; int min_iters;
+  double *scal, *scal_host;
+  long long* host_flag; long long seq;
+  int decide; double cost_cur, lambda;
+  long long* dev_flag;           // device word the point workgroups of the same launch wait on (rider mode)
+  int on;
+};
+template <class CM> __device__ void cam_update_body(const CamUpdateArgs& a, int blk, double* __restrict__ lds);
+template <class CM> __host__ __device__ constexpr int cam_update_lds_doubles() {
+  return 6 * VEC_CAMS + 3 * CM::NB * VEC_CAMS + CM::NH * VEC_CAMS + CS * VEC_CAMS + 6 * VEC_CAMS + CS * VEC_CAMS;
+}
+__device__ void scalars_body(const ScalarsArgs& a);
+
 // Work list of a point-pass launch.  Range mode (plist == nullptr): slot s is point s, points
 // with more than skip_thr observations are left to the long-track launch.  List mode: slot s is
 // point plist[s] (the long tracks, LANES = 16: one DPP row per point).
@@ -804,12 +850,15 @@ pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, co
                   const PtWork& wk, int bid, int nblk, double fx, double fy, double cx, double cy, double hub_c,
                   double lambda_arg, const double* __restrict__ lam_dev, double* __restrict__ Hpp, double* __restrict__ bp,
                   double2* __restrict__ p_w, int* __restrict__ p_camf, double* __restrict__ Hppinv, double* __restrict__ y0,
-                  double* __restrict__ partG) {
+                  double* __restrict__ partG, const long long* __restrict__ lam_flag = nullptr, long long lam_seq = 0) {
   extern __shared__ __align__(16) double tab[];   // 16-byte aligned: the table is read and written with b128 LDS operations
   __shared__ double smg[PT_THREADS / 64];
   double gm = 0.0;                                 // max |bp| over this thread's points (the reference's gtol test, scipy trf.py:451-453)
-  // lam_dev: the damping of a SPECULATED linearisation is decided on the device (k_scalars) just ahead of this launch
-  const double lambda = lam_dev ? lam_dev[0] : lambda_arg;
+  // lam_dev: the damping of a SPECULATED linearisation is decided on the device (k_scalars) -- by the kernel ahead of this
+  // launch (lam_flag == null), or by workgroup 0 of this very launch (the rider, lam_flag = the word it publishes
+  // lam_seq in when scal[] is written): then the damping is fetched as late as possible, before the first inverse
+  double lambda = (lam_dev && !lam_flag) ? lam_dev[0] : lambda_arg;
+  bool have_lambda = !(lam_dev && lam_flag);
   const int rb = pt_range_of_block(bid, nblk, wk.xcd_ranges);
   const int2 win = blk_win[wk.blk_base + rb];
   const bool use_lds = ALL_LDS || (size_t)win.y * CM::TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
@@ -862,6 +911,12 @@ pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, co
     }
 #pragma unroll
     for (int q = 0; q < 9; ++q) a[q] = lanes_sum<LANES>(a[q]);
+    if (!have_lambda) {
+      // workgroup 0 never waits for anybody and is dispatched first, so this wait ends; by now it has usually ended long ago
+      while (__hip_atomic_load(lam_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < lam_seq) __builtin_amdgcn_s_sleep(4);
+      lambda = __hip_atomic_load(lam_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      have_lambda = true;
+    }
     if (p >= 0 && sub == LANES - 1) {
 #pragma unroll
       for (int q = 0; q < 6; ++q) Hpp[6 * (size_t)p + q] = a[q];
@@ -894,13 +949,15 @@ pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, co
                       const int* __restrict__ p_cam, const double2* __restrict__ p_uv, const int2* __restrict__ blk_win
 #define BA_LIN_TAIL double fx, double fy, double cx, double cy, double hub_c, double lambda, const double* __restrict__ lam_dev, \
                     double* __restrict__ Hpp, double* __restrict__ bp, double2* __restrict__ p_w, int* __restrict__ p_camf,      \
-                    double* __restrict__ Hppinv, double* __restrict__ y0, double* __restrict__ partG
+                    double* __restrict__ Hppinv, double* __restrict__ y0, double* __restrict__ partG, ScalarsArgs sa
 // one kind of track per launch
 template <class CM, bool ROBUST, bool ALL_LDS, int LANES>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_linearize(BA_LIN_PARAMS, PtWork wk, BA_LIN_TAIL) {
-  pt_linearize_body<CM, ROBUST, ALL_LDS, LANES>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wk, blockIdx.x, gridDim.x, fx, fy, cx, cy,
-                                            hub_c, lambda, lam_dev, Hpp, bp, p_w, p_camf, Hppinv, y0, partG);
+  if (sa.on && blockIdx.x == 0) { scalars_body(sa); return; }        // the rider: workgroup 0
+  pt_linearize_body<CM, ROBUST, ALL_LDS, LANES>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wk, (int)blockIdx.x - sa.on, (int)gridDim.x - sa.on,
+                                            fx, fy, cx, cy, hub_c, lambda, lam_dev, Hpp, bp, p_w, p_camf, Hppinv, y0, partG,
+                                            sa.on ? sa.dev_flag : (const long long*)nullptr, sa.seq);
 }
 // short and long tracks in one launch: workgroups [0, nblk_short) take the range list with LPP lanes
 // per point, the rest the long-track list with a DPP row per point (saves a launch per pass on data
@@ -908,13 +965,16 @@ k_pt_linearize(BA_LIN_PARAMS, PtWork wk, BA_LIN_TAIL) {
 template <class CM, bool ROBUST, bool ALL_LDS>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_linearize_both(BA_LIN_PARAMS, PtWork wk, int nblk_short, PtWork wl, BA_LIN_TAIL) {
-  if ((int)blockIdx.x < nblk_short)
-    pt_linearize_body<CM, ROBUST, ALL_LDS, LPP>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wk, blockIdx.x, nblk_short, fx, fy, cx, cy,
-                                            hub_c, lambda, lam_dev, Hpp, bp, p_w, p_camf, Hppinv, y0, partG);
+  if (sa.on && blockIdx.x == 0) { scalars_body(sa); return; }        // the rider: workgroup 0
+  const int bid = (int)blockIdx.x - sa.on, nblk = (int)gridDim.x - sa.on;
+  const long long* lf = sa.on ? sa.dev_flag : (const long long*)nullptr;
+  if (bid < nblk_short)
+    pt_linearize_body<CM, ROBUST, ALL_LDS, LPP>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wk, bid, nblk_short, fx, fy, cx, cy,
+                                            hub_c, lambda, lam_dev, Hpp, bp, p_w, p_camf, Hppinv, y0, partG, lf, sa.seq);
   else
-    pt_linearize_body<CM, ROBUST, ALL_LDS, LPP_LONG>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wl, blockIdx.x - nblk_short,
-                                                 gridDim.x - nblk_short, fx, fy, cx, cy, hub_c, lambda, lam_dev, Hpp, bp, p_w,
-                                                 p_camf, Hppinv, y0, partG);
+    pt_linearize_body<CM, ROBUST, ALL_LDS, LPP_LONG>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wl, bid - nblk_short,
+                                                 nblk - nblk_short, fx, fy, cx, cy, hub_c, lambda, lam_dev, Hpp, bp, p_w,
+                                                 p_camf, Hppinv, y0, partG, lf, sa.seq);
 }
 #undef BA_LIN_PARAMS
 #undef BA_LIN_TAIL
@@ -995,7 +1055,8 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
               const double* __restrict__ y0, const double* __restrict__ Hpp, const double* __restrict__ bp,
               double* __restrict__ ptab_trial, double* __restrict__ partB,
               long long* __restrict__ host_flag, long long flag_base, double* __restrict__ verdict,
-              const double* __restrict__ partG, int nG, const double* __restrict__ partGc, int nGc, double* __restrict__ gmax_out) {
+              const double* __restrict__ partG, int nG, const double* __restrict__ partGc, int nGc, double* __restrict__ gmax_out,
+              const CamUpdateArgs& cu) {
   extern __shared__ __align__(16) double tab[];   // 16-byte aligned: the table is read and written with b128 LDS operations
   __shared__ double sm[4 * (PT_THREADS / 64)];
   if (MODE == 0) { BA_STAMP(0, 0); BA_STAMP(0, 1); }
@@ -1062,7 +1123,34 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
       }
     }
     if (!table_ready) {
-      fill_cam_table_wait();
+      if (MODE == 1 && cu.n_blocks > 0) {
+        // the camera update rides along this launch (extra workgroups): the step's vt = (M dc_r, dc_t, ..) of the window's
+        // rows is computed here, into the LDS table -- operands fetched while the table copy is in flight
+        constexpr int NBm = CM::NB;
+        int i = threadIdx.x;
+        double Mr[9], d[NBm];
+        const bool mine = i < win.y;
+        if (mine) {
+          const int c = win.x + i;
+#pragma unroll
+          for (int q = 0; q < 9; ++q) Mr[q] = cu.cs[CS * (size_t)c + 12 + q];
+#pragma unroll
+          for (int q = 0; q < NBm; ++q) d[q] = (c == fixed_cam) ? 0.0 : cu.dc[NBm * (size_t)c + q];
+        }
+        fill_cam_table_wait();
+        if (mine) write_vtil<NBm>(Mr, d, tab + CM::TA * i + CM::VOFF);
+        for (i += PT_THREADS; i < win.y; i += PT_THREADS) {       // (windows wider than the workgroup)
+          const int c = win.x + i;
+#pragma unroll
+          for (int q = 0; q < 9; ++q) Mr[q] = cu.cs[CS * (size_t)c + 12 + q];
+#pragma unroll
+          for (int q = 0; q < NBm; ++q) d[q] = (c == fixed_cam) ? 0.0 : cu.dc[NBm * (size_t)c + q];
+          write_vtil<NBm>(Mr, d, tab + CM::TA * i + CM::VOFF);
+        }
+        __syncthreads();
+      } else {
+        fill_cam_table_wait();
+      }
       table_ready = true;
       if (MODE == 0 && s_fin) return;
     }
@@ -1144,25 +1232,37 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
                     const double* __restrict__ Hpp, const double* __restrict__ bp, double* __restrict__ ptab_trial,            \
                     double* __restrict__ partB, long long* __restrict__ host_flag, long long flag_base,                     \
                     double* __restrict__ verdict, const double* __restrict__ partG, int nG, const double* __restrict__ partGc, \
-                    int nGc, double* __restrict__ gmax_out
+                    int nGc, double* __restrict__ gmax_out, CamUpdateArgs cu
 #define BA_SCH_TAIL_ARGS fx, fy, fixed_cam, partA, kit, st, partV, nblkV, tol2, min_iters, y0, Hpp, bp, ptab_trial, partB,       \
-                         host_flag, flag_base, verdict, partG, nG, partGc, nGc, gmax_out
+                         host_flag, flag_base, verdict, partG, nG, partGc, nGc, gmax_out, cu
 template <class CM, bool ROBUST, int MODE, bool ALL_LDS, int LANES, typename JT>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_schur(BA_SCH_PARAMS, PtWork wk, BA_SCH_TAIL) {
-  pt_schur_body<CM, ROBUST, MODE, ALL_LDS, LANES, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk, blockIdx.x, gridDim.x,
+  const int n_rider = (MODE == 1) ? cu.n_blocks : 0;           // the camera update's workgroups: the LAST ones of the launch
+  if (MODE == 1 && (int)blockIdx.x >= (int)gridDim.x - n_rider) {
+    extern __shared__ __align__(16) double tab[];
+    cam_update_body<CM>(cu, (int)blockIdx.x - ((int)gridDim.x - n_rider), tab);
+    return;
+  }
+  pt_schur_body<CM, ROBUST, MODE, ALL_LDS, LANES, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk, blockIdx.x, (int)gridDim.x - n_rider,
                                                   BA_SCH_TAIL_ARGS);
 }
 // short and long tracks in one launch (see k_pt_linearize_both)
 template <class CM, bool ROBUST, int MODE, bool ALL_LDS, typename JT>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_schur_both(BA_SCH_PARAMS, PtWork wk, int nblk_short, PtWork wl, BA_SCH_TAIL) {
+  const int n_rider = (MODE == 1) ? cu.n_blocks : 0;
+  if (MODE == 1 && (int)blockIdx.x >= (int)gridDim.x - n_rider) {
+    extern __shared__ __align__(16) double tab[];
+    cam_update_body<CM>(cu, (int)blockIdx.x - ((int)gridDim.x - n_rider), tab);
+    return;
+  }
   if ((int)blockIdx.x < nblk_short)
     pt_schur_body<CM, ROBUST, MODE, ALL_LDS, LPP, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk, blockIdx.x, nblk_short,
                                                   BA_SCH_TAIL_ARGS);
   else
     pt_schur_body<CM, ROBUST, MODE, ALL_LDS, LPP_LONG, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wl,
-                                                       blockIdx.x - nblk_short, gridDim.x - nblk_short, BA_SCH_TAIL_ARGS);
+                                                       blockIdx.x - nblk_short, (int)gridDim.x - n_rider - nblk_short, BA_SCH_TAIL_ARGS);
 }
 #undef BA_SCH_PARAMS
 #undef BA_SCH_TAIL
@@ -1171,15 +1271,6 @@ k_pt_schur_both(BA_SCH_PARAMS, PtWork wk, int nblk_short, PtWork wl, BA_SCH_TAIL
 // -------------------------------------------------------------------------------------
 // reduced-camera-system vector kernels (one thread per camera)
 // -------------------------------------------------------------------------------------
-template <int NB>
-__device__ inline void write_vtil(const double* __restrict__ M, const double (&v)[NB], double* __restrict__ dst) {
-  dst[0] = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
-  dst[1] = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
-  dst[2] = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
-#pragma unroll
-  for (int q = 3; q < NB; ++q) dst[q] = v[q];
-}
-
 // ---- cooperative staging for the camera-vector kernels ---------------------------------------------
 // A camera-vector workgroup (one wave) owns VEC_CAMS consecutive cameras, whose rows are CONTIGUOUS in every
 // per-camera array.  A thread per camera reading its own row issues one 8-byte load per word with 16 live
@@ -1548,64 +1639,78 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
 // K7a: camera update.  cams_trial = cams + dc (BAL: also intr_trial = intr + the last three entries of dc), camera
 // state and table row of the trial cameras, vtil = (M dc_r, dc_t, ..) into camA for the back substitution,
 // camera-side scalars -> partC[block][5]: bc.dc, sum Dc dc^2, dc.r_pcg, |dc|^2, |cams|^2
+// Body for workgroup `blk` of VC cameras; wave 0 does the work, every thread of the workgroup passes the barriers (the
+// body also runs as extra 1024-thread workgroups of the back-substitution launch, see "riders").  lds: at least
+// cam_update_lds_doubles<CM>() doubles of LDS, 16-byte aligned.
 template <class CM>
-__global__ void __launch_bounds__(VEC_BLOCK)
-k_cam_update(const double* __restrict__ cams, const double* __restrict__ intr, const double* __restrict__ dc,
-             const double* __restrict__ rpcg, const double* __restrict__ Hcc, const double* __restrict__ bc,
-             const double* __restrict__ cs, int n_cams, int fixed_cam, double* __restrict__ cams_trial,
-             double* __restrict__ intr_trial, double* __restrict__ cs_trial, double* __restrict__ vtil,
-             double* __restrict__ camA_trial, double* __restrict__ partC) {
+__device__ void cam_update_body(const CamUpdateArgs& a, int blk, double* __restrict__ lds) {
   constexpr int NB = CM::NB, NH = CM::NH;
   // LDS image of the workgroup's VC cameras (coalesced staging, see slice_load): cams | dc rpcg bc | Hcc | cs,
   // outputs cams_trial | cs_trial staged for a coalesced write-back
-  __shared__ double l_cam[6 * VC], l_in[3][NB * VC], l_hcc[NH * VC], l_cs[CS * VC], l_ct[6 * VC], l_cst[CS * VC];
-  const int c0 = blockIdx.x * VC;
+  double* l_cam = lds;
+  double* l_in = l_cam + 6 * VC;              // [3][NB * VC]
+  double* l_hcc = l_in + 3 * NB * VC;
+  double* l_cs = l_hcc + NH * VC;
+  double* l_ct = l_cs + CS * VC;
+  double* l_cst = l_ct + 6 * VC;
+  const int n_cams = a.n_cams, fixed_cam = a.fixed_cam;
+  const bool w0 = threadIdx.x < 64;
+  const int c0 = blk * VC;
   const int nc = min(VC, n_cams - c0);
-  const int c = vec_camera(n_cams);
-  {
+  const int c = (threadIdx.x < VEC_CAMS) ? c0 + (int)threadIdx.x : n_cams;
+  if (w0) {
     double2 v0[slice_chunks(6 * VC)], vi[3][slice_chunks(NB * VC)], vh[slice_chunks(NH * VC)], vc[slice_chunks(CS * VC)];
-    const double* ins[3] = {dc, rpcg, bc};
-    slice_load(VecSlice{cams + 6 * (size_t)c0, 6 * nc}, v0);
+    const double* ins[3] = {a.dc, a.rpcg, a.bc};
+    slice_load(VecSlice{a.cams + 6 * (size_t)c0, 6 * nc}, v0);
 #pragma unroll
     for (int q = 0; q < 3; ++q) slice_load(VecSlice{ins[q] + NB * (size_t)c0, NB * nc}, vi[q]);
-    slice_load(VecSlice{Hcc + NH * (size_t)c0, NH * nc}, vh);
-    slice_load(VecSlice{cs + CS * (size_t)c0, CS * nc}, vc);
+    slice_load(VecSlice{a.Hcc + NH * (size_t)c0, NH * nc}, vh);
+    slice_load(VecSlice{a.cs + CS * (size_t)c0, CS * nc}, vc);
     slice_store_lds(l_cam, 6 * VC, v0);
 #pragma unroll
-    for (int q = 0; q < 3; ++q) slice_store_lds(l_in[q], NB * VC, vi[q]);
+    for (int q = 0; q < 3; ++q) slice_store_lds(l_in + q * NB * VC, NB * VC, vi[q]);
     slice_store_lds(l_hcc, NH * VC, vh);
     slice_store_lds(l_cs, CS * VC, vc);
   }
   __syncthreads();
   double acc[5] = {0, 0, 0, 0, 0};
   const int t = threadIdx.x;
-  if (c < n_cams) {
+  if (w0 && c < n_cams) {
     double d[NB];
-    for (int q = 0; q < NB; ++q) d[q] = (c == fixed_cam) ? 0.0 : l_in[0][NB * t + q];
+    for (int q = 0; q < NB; ++q) d[q] = (c == fixed_cam) ? 0.0 : l_in[NB * t + q];
     double it3[3] = {0.0, 0.0, 0.0};                   // trial intrinsics (models with per-camera intrinsics)
     for (int q = 0; q < NB; ++q) {
-      const double xq = q < 6 ? l_cam[6 * t + q] : intr[3 * (size_t)c + (q - 6)];
+      const double xq = q < 6 ? l_cam[6 * t + q] : a.intr[3 * (size_t)c + (q - 6)];
       if (q < 6) l_ct[6 * t + q] = xq + d[q];
       else it3[q - 6] = xq + d[q];
-      acc[0] += l_in[2][NB * t + q] * d[q];
+      acc[0] += l_in[2 * NB * VC + NB * t + q] * d[q];
       acc[1] += fmax(l_hcc[NH * t + UT(NB, q, q)], DIAG_FLOOR) * d[q] * d[q];
-      acc[2] += d[q] * ((c == fixed_cam) ? 0.0 : l_in[1][NB * t + q]);
+      acc[2] += d[q] * ((c == fixed_cam) ? 0.0 : l_in[NB * VC + NB * t + q]);
       acc[3] += d[q] * d[q];
       acc[4] += xq * xq;
     }
     if (NB > 6) {
-      for (int q = 0; q < NB - 6; ++q) intr_trial[3 * (size_t)c + q] = it3[q];
+      for (int q = 0; q < NB - 6; ++q) a.intr_trial[3 * (size_t)c + q] = it3[q];
     }
-    write_vtil<NB>(l_cs + CS * t + 12, d, vtil + CM::TA * (size_t)c + CM::VOFF);
+    write_vtil<NB>(l_cs + CS * t + 12, d, a.vtil + CM::TA * (size_t)c + CM::VOFF);
     camera_state(l_ct + 6 * t, l_cst + CS * t);
-    CM::table_row(l_cst + CS * t, it3, camA_trial + CM::TA * (size_t)c);
+    CM::table_row(l_cst + CS * t, it3, a.camA_trial + CM::TA * (size_t)c);
   }
   __syncthreads();
-  slice_write_back(cams_trial + 6 * (size_t)c0, l_ct, 6 * nc);
-  slice_write_back(cs_trial + CS * (size_t)c0, l_cst, CS * nc);
+  if (w0) {
+    slice_write_back(a.cams_trial + 6 * (size_t)c0, l_ct, 6 * nc);
+    slice_write_back(a.cs_trial + CS * (size_t)c0, l_cst, CS * nc);
 #pragma unroll
-  for (int q = 0; q < 5; ++q) acc[q] = wave_total_dpp(acc[q]);
-  if (threadIdx.x == 0) for (int q = 0; q < 5; ++q) partC[5 * blockIdx.x + q] = acc[q];
+    for (int q = 0; q < 5; ++q) acc[q] = wave_total_dpp(acc[q]);
+    if (threadIdx.x == 0) for (int q = 0; q < 5; ++q) a.partC[5 * blk + q] = acc[q];
+  }
+}
+// stand-alone launch (camera windows that do not all fit in LDS, a rank without landmarks)
+template <class CM>
+__global__ void __launch_bounds__(VEC_BLOCK)
+k_cam_update(CamUpdateArgs a) {
+  __shared__ __align__(16) double lds[cam_update_lds_doubles<CM>()];
+  cam_update_body<CM>(a, blockIdx.x, lds);
 }
 
 // One workgroup folds every partial-sum array of an LM step into the scalar block `scal`
@@ -1652,12 +1757,11 @@ __global__ void k_word_to_host(const double* __restrict__ src, double* __restric
   if (threadIdx.x == 0 && blockIdx.x == 0) dst_host[0] = src[0];
 }
 
-__global__ void __launch_bounds__(1024)
-k_scalars(const double* __restrict__ partR, int nR, const double* __restrict__ partB, int nB,
-          const double* __restrict__ partC, int nC, int kit, const PcgState* __restrict__ st,
-          const double* __restrict__ partV, int nblkV, double tol2, int min_iters,
-          double* __restrict__ scal, double* __restrict__ scal_host, long long* __restrict__ host_flag, long long seq,
-          int decide, double cost_cur, double lambda) {
+__device__ void scalars_body(const ScalarsArgs& a) {
+  const double* __restrict__ partR = a.partR; const int nR = a.nR;
+  const double* __restrict__ partB = a.partB; const int nB = a.nB;
+  const double* __restrict__ partC = a.partC; const int nC = a.nC;
+  const PcgState* __restrict__ st = a.st;
   __shared__ double sm[11 * 16];
   // PCG verdict first (wave 1, whole wave: pcg_finished sums across its lanes): its loads are in
   // flight while the partial sums below are read
@@ -1665,26 +1769,26 @@ k_scalars(const double* __restrict__ partR, int nR, const double* __restrict__ p
   double pcg_iters = 0.0;
   if ((threadIdx.x >> 6) == 1 && st) {
     double g, z;
-    pcg_fin = pcg_finished(kit, st, partV, nblkV, tol2, min_iters, g, z);
-    const PcgState& s = st[kit & 1];
-    pcg_iters = s.done ? (double)s.iters : (double)kit;
+    pcg_fin = pcg_finished(a.kit, st, a.partV, a.nblkV, a.tol2, a.min_iters, g, z);
+    const PcgState& s = st[a.kit & 1];
+    pcg_iters = s.done ? (double)s.iters : (double)a.kit;
   }
-  double a[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int i = threadIdx.x; i < nR; i += 1024) { const double2 t = ((const double2*)partR)[i]; a[0] += t.x; a[1] += t.y; }
+  double v[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = threadIdx.x; i < nR; i += 1024) { const double2 t = ((const double2*)partR)[i]; v[0] += t.x; v[1] += t.y; }
   for (int i = threadIdx.x; i < nB; i += 1024) {
     const double2 t0 = ((const double2*)partB)[2 * i], t1 = ((const double2*)partB)[2 * i + 1];
-    a[2] += t0.x; a[3] += t0.y; a[4] += t1.x; a[5] += t1.y;
+    v[2] += t0.x; v[3] += t0.y; v[4] += t1.x; v[5] += t1.y;
   }
   for (int i = threadIdx.x; i < nC; i += 1024) {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) a[6 + q] += partC[5 * i + q];
+    for (int q = 0; q < 5; ++q) v[6 + q] += partC[5 * i + q];
   }
 #pragma unroll
-  for (int q = 0; q < 11; ++q) a[q] = wave_total_dpp(a[q]);
+  for (int q = 0; q < 11; ++q) v[q] = wave_total_dpp(v[q]);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (lane == 0) {
 #pragma unroll
-    for (int q = 0; q < 11; ++q) sm[wv * 11 + q] = a[q];
+    for (int q = 0; q < 11; ++q) sm[wv * 11 + q] = v[q];
   }
   __syncthreads();
   __shared__ double res[S_COUNT];
@@ -1701,21 +1805,29 @@ k_scalars(const double* __restrict__ partR, int nR, const double* __restrict__ p
     res[S_PCG_ITERS] = pcg_iters;
   }
   __syncthreads();
-  if (decide) {
-    if (threadIdx.x == 0) lm_decide(res, cost_cur, lambda);
+  if (a.decide) {
+    if (threadIdx.x == 0) lm_decide(res, a.cost_cur, a.lambda);
     __syncthreads();
   }
   if (threadIdx.x < S_COUNT) {
-    scal[threadIdx.x] = res[threadIdx.x];
-    if (scal_host) scal_host[threadIdx.x] = res[threadIdx.x];   // one wave: 24 consecutive host-mapped words
+    a.scal[threadIdx.x] = res[threadIdx.x];
+    if (a.scal_host) a.scal_host[threadIdx.x] = res[threadIdx.x];   // one wave: 24 consecutive host-mapped words
   }
-  // one wave wrote every host word: a system-scope fence in that wave, then its lane 0 publishes
-  // the sequence number behind them
-  if (host_flag && threadIdx.x < 64) {
-    __threadfence_system();
-    if (threadIdx.x == 0) publish_flag(host_flag, seq, 0);
+  // one wave wrote every device and host word: the same wave fences and its lane 0 publishes the sequence numbers
+  // behind them -- the device word first (rider mode: the point workgroups of this launch wait on it), then the host's
+  if (threadIdx.x < 64) {
+    if (a.dev_flag) {
+      __threadfence();
+      if (threadIdx.x == 0) __hip_atomic_store(a.dev_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (a.host_flag) {
+      __threadfence_system();
+      if (threadIdx.x == 0) publish_flag(a.host_flag, a.seq, 0);
+    }
   }
 }
+__global__ void __launch_bounds__(1024)
+k_scalars(ScalarsArgs a) { scalars_body(a); }
 
 // out[0] = max over two arrays of per-workgroup maxima (multi-rank gtol path; single wave)
 __global__ void __launch_bounds__(64)

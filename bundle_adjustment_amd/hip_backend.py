@@ -273,6 +273,32 @@ class Solver:
                                           _dp(out["Hcc"]), _dp(out["bc"]), _dp(out["Hpp"]), _dp(out["bp"])))
         return out
 
+    def set_problem_bal(self, bal, fixed_cam=-1):
+        """Upload a bal.BALProblem once (observation lists, poses, points); returns its (Nc,3) intrinsics.  Solves on the
+        resident problem: ``solve_bal_resident``; parameters are restored with ``set_params(bal.cams[:, :6], bal.pts)``."""
+        return self._set_bal(bal, fixed_cam)
+
+    def solve_bal_resident(self, intr, **kw):
+        """ba_solve_bal on the problem the handle already holds: intr (Nc,3) = (f, k1, k2) per camera at the start, adjusted
+        in place.  Returns the summary dict."""
+        intr = np.ascontiguousarray(intr, dtype=np.float64).reshape(self.n_cams, 3)
+        o = self._options(kw)
+        s = BASummary()
+        _check(self._lib.ba_solve_bal(self._h, _dp(intr), C.byref(o), C.byref(s)))
+        return s.as_dict()
+
+    def _options(self, kw):
+        o = self.default_options()
+        for k, v in kw.items():
+            if k == "loss":
+                v = LOSS[v] if isinstance(v, str) else v
+            if k == "preconditioner":
+                v = PRECOND[v] if isinstance(v, str) else v
+            if not hasattr(o, k):
+                raise TypeError(f"unknown option {k}")
+            setattr(o, k, v)
+        return o
+
     def solve_bal(self, bal, fixed_cam=-1, **kw):
         """ba_solve_bal on a bal.BALProblem (9-parameter cameras, f / k1 / k2 adjusted with the pose): returns
         (summary dict, cams (Nc,9), pts (Np,3)).  kw as for solve()."""

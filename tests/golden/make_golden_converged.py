@@ -10,6 +10,8 @@ Run in the build container only (needs /root/reference):
     python tests/golden/make_golden_converged.py --config C2 --loss huber --warm-start --max-nfev 3000
     python tests/golden/make_golden_converged.py --config C3 --loss linear
     python tests/golden/make_golden_converged.py --config C3 --loss huber --warm-start --skip-fd-check
+    python tests/golden/make_golden_converged.py --config C2 --loss huber --certify gpurun_out/xstar_c2_huber.npy
+    python tests/golden/make_golden_converged.py --config C3 --loss huber --certify gpurun_out/xstar_c3_huber.npy --fun oracle
 
 What runs (match: ``/root/reference/src/bundle_adjuster.py:170-176``):
 
@@ -25,6 +27,13 @@ What runs (match: ``/root/reference/src/bundle_adjuster.py:170-176``):
 * ``scipy.optimize.least_squares(fun, x0, jac, method='trf', tr_solver='lsmr', x_scale='jac',
   loss=<linear|huber>, f_scale=1)`` with tolerances far below the reference's 1e-5, so that it stops
   at the minimum instead of after 4-5 iterations.
+
+``--certify <x*.npy>`` (the Huber pins as CERTIFICATES instead of stalled scipy crawls): x* is the minimiser the device
+solver exported (``tools/export_converged.py``, run on the GPU box) in the reference's parameter packing.  In the build
+container the imported reference's ``_cost_function`` is evaluated AT x*, the Huber gradient ``J^T (rho' f)`` is formed with
+the oracle's analytic CSR Jacobian and its max-norm recorded, and scipy's ``least_squares`` is restarted FROM x* with the
+reference's kind of tolerances: it must stop on gtol / ftol / xtol within a few evaluations without lowering the cost by more
+than 1e-9 relative.  Written to ``cert_<config>_huber.npz`` (C2: with x* itself; C3: its SHA-256 and the scalars).
 
 The synthetic problem is regenerated from ``(config, seed)`` by ``bundle_adjustment_amd.synthetic``;
 the fixture stores only scalars plus a checksum of the inputs, so the tests notice if the generator
@@ -62,6 +71,8 @@ def main():
     ap.add_argument("--skip-fd-check", action="store_true")
     ap.add_argument("--chunk", type=int, default=200, help="evaluations per scipy call; the fixture is rewritten after each")
     ap.add_argument("--stall", type=float, default=2e-8, help="stop when the RMSE moved less than this over each of the last two chunks")
+    ap.add_argument("--certify", default=None, metavar="XSTAR.npy",
+                    help="certify a minimiser exported by tools/export_converged.py instead of running scipy from the start")
     ap.add_argument("--warm-start", action="store_true",
                     help="first run the same scipy call with loss='linear' to convergence and start the requested loss there "
                          "(scipy's Huber TRF crawls for hundreds of iterations from a 9 px start; the minimum pinned is the same)")
@@ -89,6 +100,9 @@ def main():
 
     oracle_fun = o.flat_residual_fun(p.cams, p.n_pts, p.cam_idx, p.pt_idx, p.uv, p.K4, p.fixed_cam)
     jac = o.flat_jacobian_fun(p.cams, p.n_pts, p.cam_idx, p.pt_idx, p.K4, p.fixed_cam)
+
+    if args.certify:
+        return certify(args, p, x0, ref_fun, oracle_fun, jac, o)
 
     t = time.time()
     f0_ref = ref_fun(x0)
@@ -165,6 +179,51 @@ def main():
         if len(history) >= 3 and abs(history[-1][1] - history[-2][1]) < args.stall and abs(history[-2][1] - history[-3][1]) < args.stall:
             print(f"RMSE moved less than {args.stall:g} px over each of the last two chunks: stopping", flush=True)
             break
+    print("wrote", name)
+
+
+def certify(args, p, x0, ref_fun, oracle_fun, jac, o):
+    """Stationarity certificate of a device-exported minimiser (see the module docstring)."""
+    from scipy.optimize import least_squares
+    assert args.loss == "huber", "the linear-loss pins already are converged scipy runs (status 2)"
+    xs = np.load(args.certify)
+    assert xs.shape == x0.shape, (xs.shape, x0.shape)
+    t = time.time()
+    f_ref = ref_fun(xs)                                          # the reference's own arithmetic at x*
+    t_sweep = time.time() - t
+    f_or = oracle_fun(xs)
+    sse = float(f_ref @ f_ref)
+    rho, drho, _ = o.huber_rho(f_ref ** 2)
+    cost = 0.5 * float(rho.sum())
+    J = jac(xs)
+    g = J.T @ (drho * f_ref)                                     # gradient of 0.5 sum rho(f^2)
+    g_inf = float(np.abs(g).max())
+    g0 = J.T @ f_ref
+    print(f"{args.config} huber certificate: reference sweep at x* {t_sweep:.1f} s, oracle vs reference residual {np.abs(f_ref - f_or).max():.2e} px; "
+          f"cost {cost:.12f} sse {sse:.9f} rmse {np.sqrt(sse / p.n_obs):.9f}; |grad|_inf {g_inf:.3e} (|J^T f|_inf {np.abs(g0).max():.3e})", flush=True)
+    fun = ref_fun if args.fun == "reference" else oracle_fun
+    # restart scipy FROM x*: the reference's solver (TRF, LSMR; x_scale='jac' so that it can move at all) with scipy's default gtol and
+    # tolerances a thousand times tighter than the reference's 1e-5 -- it has to declare convergence at once
+    res = least_squares(fun, xs, jac=jac, method="trf", tr_solver="lsmr", x_scale="jac", loss="huber", f_scale=1.0,
+                        xtol=1e-10, ftol=1e-10, gtol=1e-8, max_nfev=args.max_nfev if args.max_nfev < 50 else 25,
+                        tr_options=dict(atol=args.lsmr_tol, btol=args.lsmr_tol))
+    f_end = ref_fun(res.x)
+    cost_end = 0.5 * float(o.huber_rho(f_end ** 2)[0].sum())
+    rel_drop = (cost - cost_end) / cost
+    print(f"scipy from x*: status {res.status} after {res.nfev} evaluations, optimality {res.optimality:.3e}, cost {cost_end:.12f} "
+          f"(relative decrease {rel_drop:.3e}), moved |dx|_inf {np.abs(res.x - xs).max():.3e}", flush=True)
+    assert res.status in (1, 2, 3, 4), "scipy did not declare convergence when started at x*"
+    assert rel_drop <= 1e-9, "scipy lowered the cost from x* by more than 1e-9 relative: x* is not the minimiser"
+    out = dict(config=np.array(args.config), seed=args.seed, loss=np.array("huber"), fun=np.array(args.fun),
+               n_cams=p.n_cams, n_pts=p.n_pts, n_obs=p.n_obs, problem_sha256=np.array(problem_checksum(p)),
+               xstar_sha256=np.array(hashlib.sha256(np.ascontiguousarray(xs).tobytes()).hexdigest()),
+               res_cost=cost, res_sse=sse, res_rmse=float(np.sqrt(sse / p.n_obs)), grad_inf=g_inf,
+               scipy_status=int(res.status), scipy_nfev=int(res.nfev), scipy_optimality=float(res.optimality),
+               scipy_cost_end=cost_end, scipy_relative_decrease=rel_drop, scipy_dx_inf=float(np.abs(res.x - xs).max()))
+    if xs.size <= 50_000:
+        out["xstar"] = xs
+    name = f"cert_{args.config.lower()}_huber.npz"
+    np.savez_compressed(os.path.join(HERE, name), **out)
     print("wrote", name)
 
 

@@ -119,5 +119,8 @@ def test_device_triangulation_matches_the_reference_function(name):
         pts, idx = triangulate_points(g["K"], g[name + "_R"], g[name + "_t"], g[name + "_pts1"], g[name + "_pts2"])
     want = g[name + "_out"]
     assert np.array_equal(idx, g[name + "_idx"])
-    assert pts.shape == want.shape and np.abs(pts - want).max() <= 1e-9 * np.abs(want).max()
+    # "degenerate": parallel rays leave the homogeneous w (~1e-8 of a unit vector) determined to ~1e-14 only, and the
+    # result is x / (w + 1e-6): two correct SVDs (LAPACK's in the generator, the device's one-sided Jacobi) agree to 1e-7
+    tol = 1e-9 if name != "degenerate" else 1e-7
+    assert pts.shape == want.shape and np.abs(pts - want).max() <= tol * np.abs(want).max()
     assert buf.getvalue() == str(g[name + "_log"])

@@ -16,10 +16,12 @@ import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# the PCG instantiations: k_pt_schur<ROBUST, MODE 0, ALL_LDS, LPP lanes, JT>, k_cam_schur<ROBUST, PCG true, JT>
-SLOT = {"k_pt_schur<true, 0, true, 2,": "schur_pt", "k_pt_schur<false, 0, true, 2,": "schur_pt",
-        "k_pt_schur<true, 0, false, 2,": "schur_pt", "k_pt_schur<false, 0, false, 2,": "schur_pt",
-        "k_cam_schur<true, true,": "schur_cam", "k_cam_schur<false, true,": "schur_cam"}
+# the PCG instantiations: k_pt_schur[_both]<CM, ROBUST, MODE 0, ...>, k_cam_schur<CM, ROBUST, PCG true, ...>
+import re
+SLOT = [(re.compile(r"k_pt_schur(_both)?<ba::\w+, (true|false), 0,"), "schur_pt"),
+        (re.compile(r"k_cam_schur<ba::\w+, (true|false), true,"), "schur_cam"),
+        (re.compile(r"k_pt_linearize(_both)?<"), "linearize_pt"), (re.compile(r"k_camrow_linearize<"), "linearize_cam"),
+        (re.compile(r"k_camrow_schur_diag<"), "precond"), (re.compile(r"k_pt_schur(_both)?<ba::\w+, (true|false), 1,"), "backsub_pt")]
 
 
 def agg(path, cname):
@@ -42,13 +44,14 @@ def main():
         fk, wk = med(f[k]), med(w.get(k, [0.0]))
         hbm = (2 * fk + wk) * 1024
         rows.append((k, len(f[k]), fk, wk, hbm))
-        for pat, slot in SLOT.items():
-            if pat in k:
-                traffic[slot] = round(hbm)
+        for pat, slot in SLOT:
+            if pat.search(k):
+                traffic[slot] = max(traffic.get(slot, 0), round(hbm))       # (several instantiations of a slot: the working one moves the most)
     with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_per_kernel.csv"), "w") as out:
         out.write("kernel,launches,FETCH_SIZE_KB_median,WRITE_SIZE_KB_median,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
         for k, n, fk, wk, hbm in rows:
             out.write(f"\"{k}\",{n},{fk:.1f},{wk:.1f},{hbm:.0f}\n")
+    traffic["_source"] = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the bench command, profile tag {tag} (tools/profile_round.sh)"
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     print(traffic)
 
