@@ -189,6 +189,9 @@ def main():
     ap.add_argument("--jacobian", default="f64", choices=["f64", "f32"], help="f32: config 5's fp32 Jacobian blocks in the PCG passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=11, help="timed repeats of the K-step solve; value = the median repeat")
+    ap.add_argument("--weak", action="store_true",
+                    help="also time the problem that GROWS with the ranks (every rank a C3-sized landmark shard) and report it "
+                         "under 'weak_scaling'; on by default for --gpus > 1 with the headline config")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -362,6 +365,45 @@ def main():
     roofline["lm_iteration"] = dict(algorithmic_bytes=round(b_iter), achieved=round(iter_gbs, 1),
                                     frac=round(iter_gbs / HBM_PEAK_GBS, 4))
 
+    # ---- weak scaling beside the strong headline (one exchange per PCG iteration makes the FIXED 1k / 100k
+    # problem latency-bound across GPUs; the same exchange amortises over N times the landmarks): every rank generates its
+    # own C3-sized landmark shard of an N x 100k-point problem (cameras identical on all ranks) and the same K steps are timed
+    weak = None
+    if (args.weak or world > 1) and args.camera == "pinhole" and args.config in ("C2", "C3"):
+        from bundle_adjustment_amd.synthetic import CONFIGS, make_weak_shard
+        cfgw = CONFIGS[args.config]
+        wshard = make_weak_shard(cfgw["n_cams"], cfgw["n_pts"], cfgw["obs_per_pt"], args.seed, rank)
+        solver.set_problem(wshard)
+        if args.warmup > 0:
+            solver.solve(max_iters=args.warmup, **kw)
+        wdts = []
+        for _ in range(max(1, min(args.repeats, 5))):
+            solver.set_params(wshard.cams, wshard.pts)
+            barrier()
+            t0 = time.perf_counter()
+            wout = solver.solve(max_iters=args.steps, **kw)
+            solver.synchronize()
+            dtw = time.perf_counter() - t0
+            barrier()
+            if dist is not None:
+                import torch
+                t = torch.tensor([dtw], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dtw = float(t.item())
+            wdts.append(dtw)
+        n_obs_w = wshard.n_obs
+        if dist is not None:
+            import torch
+            t = torch.tensor([float(n_obs_w)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            n_obs_w = int(t.item())
+        dtw = float(np.median(wdts))
+        weak = dict(value=round(wout["iterations"] / dtw, 3), unit="LM iterations/s", ms_per_step=round(1e3 * dtw / max(wout["iterations"], 1), 4),
+                    workload=f"{args.config} x {world}: {cfgw['n_cams']} cams / {cfgw['n_pts'] * world} pts / {n_obs_w} obs "
+                             f"({cfgw['n_pts']} landmarks per rank, generated per rank)",
+                    pcg_iterations_per_lm=round(wout["pcg_iterations"] / max(wout["iterations"], 1), 2),
+                    final_rmse_px=round(float(np.sqrt(wout["final_sse"] / n_obs_w)), 6), repeats=len(wdts))
+
     line = None
     if rank == 0:
         cpu = None
@@ -387,6 +429,7 @@ def main():
                        "accepted_steps": out["accepted"],
                        "seconds": {k: round(out[k], 6) for k in ("seconds_total", "seconds_linearize", "seconds_pcg", "seconds_update")}},
             "roofline": roofline,
+            **({"weak_scaling": weak} if weak is not None else {}),
             "kernel_profile_us": {k: round(v["working_mean_us"], 3) for k, v in prof.items()},
         }
         if cpu is not None:

@@ -169,7 +169,7 @@ struct ba_handle {
   DBuf<double> partG[2], partGc;   // per-workgroup max |bp| (point half, double-buffered like it) and max |bc| (k_pcg_setup): the gtol test
   int lb = 0;                  // which c_w / partL buffer holds the current linearisation
   // PCG vectors, comm buffers (multi-rank), scalars
-  DBuf<double> gvec, x, r, p, s, z, vin, scal, rbuf, gather;
+  DBuf<double> gvec, x, r, p, s, z, vin, vx, scal, rbuf, gather;
   DBuf<PcgState> st;
   DBuf<double> tri;            // staging of ba_triangulate
   char* h_small = nullptr;     // k_small_lm's results, host-mapped: ba_summary | int cur | trace records
@@ -202,6 +202,7 @@ struct ba_handle {
   long long flag_base = 1, step_seq = 1;
   // comm
   int rank = 0, world = 1;
+  bool one_part = false;       // multi-rank, thin shards: every camera's local observations in partition 0 (no fold kernels; ba_set_problem)
   bool multi = false;          // the multi-rank control flow is on: world > 1, or a communicator of ONE rank was forced
                                // (BA_COMM_FORCE=1: lets a single GPU execute every fold / all-reduce / decide step of the
                                // multi-rank loop through the real RCCL library)
@@ -341,7 +342,7 @@ extern "C" int ba_destroy(ba_handle* h) {
                         &h->Hppinv[0], &h->Hppinv[1], &h->y0[0], &h->y0[1], &h->Hccd, &h->Minv,
                         &h->partR, &h->partL[0], &h->partL[1], &h->part6, &h->partE, &h->partA, &h->partB, &h->partC, &h->partV,
                         &h->partG[0], &h->partG[1], &h->partGc,
-                        &h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin, &h->scal, &h->rbuf, &h->gather};
+                        &h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin, &h->vx, &h->scal, &h->rbuf, &h->gather};
   for (auto b : db) b->release();
   h->st.release();
   h->tri.release();
@@ -634,6 +635,10 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   if (table_fits) h->nblkP = std::min(h->nblkP, h->n_cu * per_cu);
   if (const char* e = getenv("BA_PT_BLOCKS")) h->nblkP = std::max(1, std::min(want, atoi(e)));
   if (const char* e = getenv("BA_XCD_RANGES")) h->xcd_ranges = atoi(e) != 0;
+  // lanes per (camera, partition) segment in the PCG camera pass: a wave, or a 16-lane row when segments are short
+  // (config 5: ~48 observations per segment -- a wave would walk it in one step with a quarter of its lanes idle and
+  // pay the 64-lane reduction of every sum for it; measured 13.4 -> 12.1 us, C3's ~125-observation segments keep the wave)
+  h->cam_segl = (Nc > 0 && (long long)No / Nc / NPART < 64) ? 16 : 64;
   if (const char* e = getenv("BA_CAM_SEGL")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) h->cam_segl = v; }
   h->ppb = std::max(1, (Np + h->nblkP - 1) / h->nblkP);
   // ---- bank-aware visiting order inside a point (2-lane point passes with the camera table in LDS).
@@ -715,10 +720,17 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   // uniformly spread observations chunk k covers about the k-th eighth of the point table (what
   // keeps it resident in XCD k's L2); for band-structured data the chunks stay balanced and are
   // narrow in point index anyway.
+  // A rank of a multi-GPU job holds 1/world of every camera's observations: when that leaves fewer than 32 per
+  // (camera, partition) segment, the whole local list of a camera goes into partition 0 (the others stay empty and
+  // their partial sums zero).  The camera passes then work on segments of a useful length, and -- the point -- the
+  // partial sums come out already "folded": the fold kernels in front of every all-reduce (fold_and_reduce) disappear.
+  h->one_part = h->world > 1 && Nc > 0 && (long long)No / Nc / NPART < 32;
+  if (const char* e = getenv("BA_ONE_PART")) h->one_part = atoi(e) != 0 && h->multi;
   std::vector<int> offk((size_t)Nc * (NPART + 1));
   for (int c = 0; c < Nc; ++c) {
     const long long n = cam_off[c + 1] - cam_off[c];
-    for (int k = 0; k <= NPART; ++k) offk[(size_t)c * (NPART + 1) + k] = cam_off[c] + (int)((n * k) / NPART);
+    for (int k = 0; k <= NPART; ++k)
+      offk[(size_t)c * (NPART + 1) + k] = h->one_part ? (k == 0 ? cam_off[c] : cam_off[c + 1]) : cam_off[c] + (int)((n * k) / NPART);
   }
   // which workgroup -> XCD assignment of the camera passes keeps an XCD on one slice of the point table
   // (group_of_block): count the observations whose point lies in the slice of their partition, and in
@@ -814,6 +826,17 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   h->n_long = (int)long_pts.size();
   const int long_per_blk = PT_THREADS / LPP_LONG;
   h->nblkL = (h->n_long + long_per_blk - 1) / long_per_blk;
+  // Windowed point passes hold ONE 1024-thread workgroup per compute unit (128 VGPRs x 16 waves).  When one-round ranges
+  // need somewhat more workgroups than the chip has units (config 5: 306 + 24 on 256), the second wave of workgroups
+  // runs on a quarter of the chip while the rest idles: instead every unit gets one workgroup and a slightly longer range
+  // (a full round plus a partial one).  Much larger problems keep one-round ranges (narrow windows matter more there).
+  if (!table_fits && !getenv("BA_PT_BLOCKS")) {
+    const int avail = h->n_cu - h->nblkL;
+    if (avail > 0 && want > avail && want <= 2 * avail) {
+      h->nblkP = avail;
+      h->ppb = (Np + avail - 1) / avail;
+    }
+  }
   std::vector<int2> win(h->nblkP + h->nblkL);
   // a window is staged in LDS when its rows fit; the row stride depends on the camera model (18 doubles for the
   // reference's pinhole, 26 for the BAL camera), so the LDS size and the "every window fits" flag are kept per model
@@ -881,7 +904,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(h->partA.alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partB.alloc(4 * (size_t)(h->nblkP + h->nblkL)));
   HIPCHECK(h->partC.alloc(5 * (size_t)h->nblkV)); HIPCHECK(h->partV.alloc(4 * (size_t)h->nblkV));
   HIPCHECK(h->partG[0].alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partG[1].alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partGc.alloc(h->nblkV));
-  DBuf<double>* v6[] = {&h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin};
+  DBuf<double>* v6[] = {&h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin, &h->vx};
   for (auto b : v6) HIPCHECK(b->alloc(NBX * (size_t)Nc));
   HIPCHECK(h->scal.alloc(64));
   if (h->two_level_ok) {
@@ -918,6 +941,12 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     const dim3 gg((No + 255) / 256), gb(256);
     BA_LAUNCH(k_gather_uv, gg, gb, 0, h->stream, (const double2*)h->rbuf.p, (const int*)h->c_ptf[0].p, No, h->p_uv.p);
     BA_LAUNCH(k_gather_uv, gg, gb, 0, h->stream, (const double2*)h->rbuf.p, (const int*)h->c_orig.p, No, h->c_uv.p);
+    // the flagged copies of the index streams start as the plain streams: a robust linearisation reads them and stores
+    // an entry only where its "weights are not (1, 1)" flag changes
+    for (int k = 0; k < 2; ++k) {
+      HIPCHECK(hipMemcpyAsync(h->c_ptf[k].p, h->c_pt.p, No * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+      HIPCHECK(hipMemcpyAsync(h->p_camf[k].p, h->p_cam.p, No * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    }
   }
   BA_SYNC(h);   // host vectors go out of scope
   stage("upload");
@@ -1105,7 +1134,7 @@ static PtWork pt_work_long(ba_handle* h) { return PtWork{h->long_pts.p, h->n_lon
 template <class CM>
 static void launch_lin_pt_t(ba_handle* h, int w, int pbuf, bool robust, double fscale, double lambda, const double* lam_dev,
                             const ScalarsArgs& sa) {
-  const int ride = sa.on;                              // the step's scalar fold + verdict as workgroup 0 of this launch
+  const int ride = sa.on * NPART;                      // the step's scalar fold + verdict as workgroup 0 of this launch (+ NPART - 1 idle ones)
 #define LP_HEAD h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_uv.p, h->blk_win.p
 #define LP_TAIL h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, lambda, lam_dev, h->Hpp[pbuf].p, h->bp[pbuf].p, h->p_w[pbuf].p,      \
                 h->p_camf[pbuf].p, h->Hppinv[pbuf].p, h->y0[pbuf].p, h->partG[pbuf].p, sa
@@ -1207,7 +1236,7 @@ static void launch_pt_schur_t(ba_handle* h, bool robust, int mode, int k, double
 #define PS_TAIL h->K4[0], h->K4[1], h->fixed, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0[h->pb].p,     \
                 h->Hpp[h->pb].p, h->bp[h->pb].p, h->ptab[1 - w].p, h->partB.p, flag, flag_base, h->verdict.p,                      \
                 (const double*)h->partG[h->pb].p, h->nblkP + h->nblkL, (const double*)h->partGc.p, h->nblkV, gmax_out, cu
-  const size_t lds = std::max(lds_of(h), ride ? cam_update_lds_doubles<CM>() * sizeof(double) : (size_t)0) + (size_t)h->debug_lds_extra;
+  const size_t lds = std::max(lds_of(h), ride ? CU_GROUPS * cam_update_lds_doubles<CM>() * sizeof(double) : (size_t)0) + (size_t)h->debug_lds_extra;
   long long* flag = (mode == 0 && flag_base > 0) ? h->d_flags : (long long*)nullptr;
   // data with long tracks: short and long tracks in one launch (workgroup 0 publishes the verdict)
 #define PS_ONE(R, M, L, LN, JT) \
@@ -1267,7 +1296,7 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
 // An eighth of the bytes on the wire for two launch-floor kernels.  Single rank: nothing.
 static int fold_and_reduce(ba_handle* h, double* parts, size_t n_per_part, double* msg, size_t msg_count) {
   if (!h->multi) return BA_OK;
-  {
+  if (!h->one_part) {        // (one_part: partitions 1 .. NPART-1 are empty, partition 0 already is the sum)
     Scope sc(h, BA_K_MISC);
     BA_LAUNCH(k_fold_parts, dim3((unsigned)((n_per_part + 255) / 256)), dim3(256), 0, h->stream, parts, n_per_part, NPART);
   }
@@ -1288,7 +1317,7 @@ static void launch_pcg_setup(ba_handle* h, double lambda, bool schur_diag, bool 
   Scope sc(h, BA_K_PCG_UPDATE);
 #define SU_ARGS h->partL[h->lb].p, h->HccBc.p, bc_ptr(h), p6_ptr(h), h->partE.p, NPART, h->cs[h->cur].p, lambda,           \
                 schur_diag ? 1 : 0, h->Nc, h->fixed, h->Hccd.p, h->Minv.p, h->gvec.p, h->x.p, h->r.p, h->p.p, h->s.p,     \
-                h->z.p, h->camA[h->cur].p, h->partV.p, h->st.p, h->partGc.p, (h->two_level ? h->coarse_rc.p : (double*)nullptr)
+                h->z.p, h->camA[h->cur].p, h->partV.p, h->st.p, h->partGc.p, (h->two_level ? h->coarse_rc.p : (double*)nullptr), h->vx.p
 #define CALL_T(CM)                                                                                               \
   do {                                                                                                           \
     if (finalize) BA_LAUNCH((k_pcg_setup<CM, true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);    \
@@ -1722,7 +1751,9 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     return BA_OK;
   }
   const bool debug_poison = getenv("BA_DEBUG_POISON_TRIAL") != nullptr;     // tests: every trial cost comes out NaN
-  const bool riders = getenv("BA_NO_RIDERS") == nullptr;                    // (tuning / tests: the O(Nc) kernels as launches of their own)
+  // BA_RIDERS: bit 0 = the camera update rides along the back substitution, bit 1 = the scalar fold + verdict rides along
+  // the speculated point half (ba_kernels.hpp, "riders"); BA_NO_RIDERS / BA_RIDERS=0: launches of their own (tuning, tests)
+  const int riders = getenv("BA_NO_RIDERS") ? 0 : (getenv("BA_RIDERS") ? atoi(getenv("BA_RIDERS")) : 3);
   double lambda = opts->initial_lambda, nu = 2.0;
   int it = 0, status = 0;
   bool need_linearize = true;      // a linearisation at the current parameters is needed before the next damped system
@@ -1790,14 +1821,14 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
                   opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA[h->cur].p, h->partV.p, h->nblkV, h->st.p, \
                   h->d_flags, base, (const double*)h->verdict.p
       if (h->two_level) {
-        BA_LAUNCH((k_pcg_step<Pinhole, true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, h->coarse_rc.p);
+        BA_LAUNCH((k_pcg_step<Pinhole, true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, h->coarse_rc.p, h->vx.p);
         BA_LAUNCH(k_pcg_coarse, dim3(h->n_agg), dim3(VEC_BLOCK), 0, h->stream, kk, (const double*)h->coarseEinv.p,
                   (const double*)h->coarse_rc.p, h->n_agg, (const double*)h->Hccd.p, (const double*)h->cs[h->cur].p, Nc, h->fixed,
                   (const double*)h->r.p, h->z.p, h->camA[h->cur].p, h->partV.p, h->nblkV, (const double*)h->verdict.p, 1);
       } else if (h->model) {
-        BA_LAUNCH((k_pcg_step<BalCam, false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, (double*)nullptr);
+        BA_LAUNCH((k_pcg_step<BalCam, false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, (double*)nullptr, h->vx.p);
       } else {
-        BA_LAUNCH((k_pcg_step<Pinhole, false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, (double*)nullptr);
+        BA_LAUNCH((k_pcg_step<Pinhole, false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, (double*)nullptr, h->vx.p);
       }
 #undef STEP_ARGS
       return BA_OK;
@@ -1833,8 +1864,10 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       cu.cams = h->cams[h->cur].p; cu.intr = h->intr[h->cur].p; cu.dc = h->x.p; cu.rpcg = h->r.p; cu.Hcc = h->HccBc.p; cu.bc = bc_ptr(h);
       cu.cs = h->cs[h->cur].p; cu.cams_trial = h->cams[1 - h->cur].p; cu.intr_trial = h->intr[1 - h->cur].p; cu.cs_trial = h->cs[1 - h->cur].p;
       cu.vtil = h->camA[h->cur].p; cu.camA_trial = h->camA[1 - h->cur].p; cu.partC = h->partC.p;
-      cu.n_cams = Nc; cu.fixed_cam = h->fixed; cu.n_blocks = h->nblkV;
-      const bool ride = riders && all_lds_of(h) && h->Np > 0;
+      cu.vx = h->vx.p;
+      // (riding workgroups: a multiple of NPART, so that the point workgroups behind them keep their XCD = index mod NPART)
+      cu.n_cams = Nc; cu.fixed_cam = h->fixed; cu.n_blocks = (((h->nblkV + CU_GROUPS - 1) / CU_GROUPS + NPART - 1) / NPART) * NPART;
+      const bool ride = (riders & 1) && all_lds_of(h) && h->Np > 0;
       if (!ride) {
         Scope sc(h, BA_K_MISC);
         if (h->model) BA_LAUNCH(k_cam_update<BalCam>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, cu);
@@ -1858,7 +1891,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     const long long seq = ++h->step_seq;
     // the step's scalar fold + verdict: single rank with a speculated point half behind it -> workgroup 0 of that launch
     // (the point workgroups pick the next damping up through a device word); else a launch of its own
-    const bool ride_scalars = riders && speculated && !h->multi && h->Np > 0;
+    const bool ride_scalars = (riders & 2) && speculated && !h->multi && h->Np > 0;
     if (!ride_scalars) launch_scalars(h, true, k, tol2, opts->pcg_min_iters, seq, cost, lambda);
     if (h->multi) {           // the six sums over ranks, then the verdict on the all-reduced block; same host-mapped mirror + word
       if (int rc = allreduce(h, h->scal.p, 6)) return rc;

@@ -531,13 +531,18 @@ k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ int
   if (s.live) {
     double cam[CM::CAM];
     CM::load_cam_vec(cs, intr, s.c, cam);
+    // ROBUST: the index stream is read from the flagged copy this pass maintains (c_ptf holds c_pt | flag from an earlier
+    // linearisation, or plain c_pt): an entry is stored only when its flag CHANGES -- near the solution almost none does,
+    // and the 4-byte-per-observation store stream disappears from the pass's traffic
+    const int* __restrict__ idx_in = ROBUST ? (const int*)c_ptf : c_pt;
     int i = s.beg + s.l16;
-    int p = (i < s.end) ? c_pt[i] : 0;
+    int pr = (i < s.end) ? idx_in[i] : 0;
     double2 uv = (i < s.end) ? c_uv[i] : make_double2(0, 0);
     while (i < s.end) {
       const int in = i + ROW_LANES;
-      const int pn = (in < s.end) ? c_pt[in] : 0;
+      const int pn = (in < s.end) ? idx_in[in] : 0;
       const double2 uvn = (in < s.end) ? c_uv[in] : make_double2(0, 0);
+      const int p = ROBUST ? (pr & IDX_MASK) : pr;
       const double4 X = *(const double4*)(ptab + PT * (size_t)p);
       typename CM::template Obs<double> g;
       CM::template geom<false, double, double>(cam, X.x, X.y, X.z, fx, fy, g);
@@ -551,7 +556,7 @@ k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ int
         huber(rv, hub_c, t1, w1);
         if (COST) acc[NL + 1] += t0 + t1;
         const int pfl = flagged_index(p, w0, w1);
-        c_ptf[i] = pfl;
+        if (pfl != pr) c_ptf[i] = pfl;
         if (pfl < 0) c_w[i] = make_double2(w0, w1);        // unflagged weights are never read
       }
       double J0[NB], J1[NB];
@@ -563,7 +568,7 @@ k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ int
         for (int b = a; b < NB; ++b) acc[UT(NB, a, b)] += wa0 * J0[b] + wa1 * J1[b];
         acc[NH + a] += wa0 * ru + wa1 * rv;
       }
-      i = in; p = pn; uv = uvn;
+      i = in; pr = pn; uv = uvn;
     }
   }
   if (COST && !ROBUST) acc[NL + 1] = acc[NL];
@@ -790,6 +795,7 @@ __device__ inline void write_vtil(const double* __restrict__ M, const double (&v
 // CamUpdateArgs / ScalarsArgs are the riders' arguments (n_blocks / on = 0: no rider in this launch).
 struct CamUpdateArgs {
   const double *cams, *intr, *dc, *rpcg, *Hcc, *bc, *cs;
+  const double* vx;              // (M x_r, x_t, ..) of the PCG iterate, NB per camera, kept current by k_pcg_setup / k_pcg_step
   double *cams_trial, *intr_trial, *cs_trial, *vtil, *camA_trial, *partC;
   int n_cams, fixed_cam, n_blocks;
 };
@@ -807,7 +813,9 @@ struct ScalarsArgs {
   long long* dev_flag;           // device word the point workgroups of the same launch wait on (rider mode)
   int on;
 };
-template <class CM> __device__ void cam_update_body(const CamUpdateArgs& a, int blk, double* __restrict__ lds);
+constexpr int CU_GROUPS = 4;          // camera groups (of VEC_CAMS cameras, one wave each) per riding 1024-thread workgroup
+template <class CM> __device__ void cam_update_body(const CamUpdateArgs& a, int blk, bool active, double* __restrict__ lds);
+template <class CM> __device__ __forceinline__ void cam_update_rider(const CamUpdateArgs& a, int rb, double* __restrict__ dyn_lds);
 template <class CM> __host__ __device__ constexpr int cam_update_lds_doubles() {
   return 6 * VEC_CAMS + 3 * CM::NB * VEC_CAMS + CM::NH * VEC_CAMS + CS * VEC_CAMS + 6 * VEC_CAMS + CS * VEC_CAMS;
 }
@@ -876,13 +884,16 @@ pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, co
     double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (p >= 0) {
       const double4 X = *(const double4*)(ptab + PT * (size_t)p);
+      // (ROBUST: index stream from the flagged copy, stored back only where the flag changes -- see k_camrow_linearize)
+      const int* __restrict__ idx_in = ROBUST ? (const int*)p_camf : p_cam;
       int j = beg + sub;
-      int c = (j < end) ? p_cam[j] : 0;
+      int cr = (j < end) ? idx_in[j] : 0;
       double2 uv = (j < end) ? p_uv[j] : make_double2(0, 0);
       while (j < end) {
         const int jn = j + LANES;
-        const int cn = (jn < end) ? p_cam[jn] : 0;
+        const int cn = (jn < end) ? idx_in[jn] : 0;
         const double2 uvn = (jn < end) ? p_uv[jn] : make_double2(0, 0);
+        const int c = ROBUST ? (cr & IDX_MASK) : cr;
         double row[CM::LIN_ROW];
         load_cam_row<CM::LIN_ROW, CM::TA>(use_lds, tab, camA, win.x, c, row);
         typename CM::template Obs<double> g;
@@ -896,7 +907,7 @@ pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, co
           huber(ru, hub_c, t, w0);
           huber(rv, hub_c, t, w1);
           const int cfl = flagged_index(c, w0, w1);
-          p_camf[j] = cfl;
+          if (cfl != cr) p_camf[j] = cfl;
           if (cfl < 0) p_w[j] = make_double2(w0, w1);      // unflagged weights are never read
         }
 #pragma unroll
@@ -906,14 +917,17 @@ pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, co
           for (int r = q; r < 3; ++r) a[U3(q, r)] += wa0 * Pm[r] + wa1 * Pm[3 + r];
           a[6 + q] -= wa0 * ru + wa1 * rv;       // Jp = -Pm
         }
-        j = jn; c = cn; uv = uvn;
+        j = jn; cr = cn; uv = uvn;
       }
     }
 #pragma unroll
     for (int q = 0; q < 9; ++q) a[q] = lanes_sum<LANES>(a[q]);
     if (!have_lambda) {
       // workgroup 0 never waits for anybody and is dispatched first, so this wait ends; by now it has usually ended long ago
-      while (__hip_atomic_load(lam_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < lam_seq) __builtin_amdgcn_s_sleep(4);
+      // RELAXED device-scope loads (served at the coherence point, nothing invalidated): an ACQUIRE here would make every
+      // wave of the launch invalidate its XCD's L2 (measured: the pass went from 21 to 99 us).  The value is read by a
+      // second such load issued after the flag has been seen; the writer released the flag behind the value.
+      while (__hip_atomic_load(lam_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lam_seq) __builtin_amdgcn_s_sleep(8);
       lambda = __hip_atomic_load(lam_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       have_lambda = true;
     }
@@ -954,8 +968,9 @@ pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, co
 template <class CM, bool ROBUST, bool ALL_LDS, int LANES>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_linearize(BA_LIN_PARAMS, PtWork wk, BA_LIN_TAIL) {
-  if (sa.on && blockIdx.x == 0) { scalars_body(sa); return; }        // the rider: workgroup 0
-  pt_linearize_body<CM, ROBUST, ALL_LDS, LANES>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wk, (int)blockIdx.x - sa.on, (int)gridDim.x - sa.on,
+  // the rider: workgroup 0; workgroups 1 .. NPART-1 leave at once, so that the point workgroups keep their XCD (= index mod NPART)
+  if (sa.on && blockIdx.x < NPART) { if (blockIdx.x == 0) scalars_body(sa); return; }
+  pt_linearize_body<CM, ROBUST, ALL_LDS, LANES>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wk, (int)blockIdx.x - sa.on * NPART, (int)gridDim.x - sa.on * NPART,
                                             fx, fy, cx, cy, hub_c, lambda, lam_dev, Hpp, bp, p_w, p_camf, Hppinv, y0, partG,
                                             sa.on ? sa.dev_flag : (const long long*)nullptr, sa.seq);
 }
@@ -965,8 +980,8 @@ k_pt_linearize(BA_LIN_PARAMS, PtWork wk, BA_LIN_TAIL) {
 template <class CM, bool ROBUST, bool ALL_LDS>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_linearize_both(BA_LIN_PARAMS, PtWork wk, int nblk_short, PtWork wl, BA_LIN_TAIL) {
-  if (sa.on && blockIdx.x == 0) { scalars_body(sa); return; }        // the rider: workgroup 0
-  const int bid = (int)blockIdx.x - sa.on, nblk = (int)gridDim.x - sa.on;
+  if (sa.on && blockIdx.x < NPART) { if (blockIdx.x == 0) scalars_body(sa); return; }      // the rider: workgroup 0 (1 .. NPART-1 idle, see k_pt_linearize)
+  const int bid = (int)blockIdx.x - sa.on * NPART, nblk = (int)gridDim.x - sa.on * NPART;
   const long long* lf = sa.on ? sa.dev_flag : (const long long*)nullptr;
   if (bid < nblk_short)
     pt_linearize_body<CM, ROBUST, ALL_LDS, LPP>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wk, bid, nblk_short, fx, fy, cx, cy,
@@ -1124,29 +1139,21 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
     }
     if (!table_ready) {
       if (MODE == 1 && cu.n_blocks > 0) {
-        // the camera update rides along this launch (extra workgroups): the step's vt = (M dc_r, dc_t, ..) of the window's
-        // rows is computed here, into the LDS table -- operands fetched while the table copy is in flight
+        // the camera update rides along this launch (extra workgroups), so nobody has put the step's vt = (M dc_r, dc_t, ..)
+        // into the table rows: the PCG vector kernels keep that form of their iterate in vx (NB doubles per camera, dense),
+        // and the window's slice of it is dropped into the LDS rows here -- fetched while the table copy is in flight
         constexpr int NBm = CM::NB;
-        int i = threadIdx.x;
-        double Mr[9], d[NBm];
-        const bool mine = i < win.y;
-        if (mine) {
-          const int c = win.x + i;
-#pragma unroll
-          for (int q = 0; q < 9; ++q) Mr[q] = cu.cs[CS * (size_t)c + 12 + q];
-#pragma unroll
-          for (int q = 0; q < NBm; ++q) d[q] = (c == fixed_cam) ? 0.0 : cu.dc[NBm * (size_t)c + q];
-        }
+        const int nw = win.y * NBm;                      // doubles of vx this window needs, contiguous from NBm * win.x
+        const double* __restrict__ src = cu.vx + NBm * (size_t)win.x;
+        int e = threadIdx.x;
+        double v0 = 0.0, v1 = 0.0;
+        const int e1 = e + PT_THREADS;
+        if (e < nw) v0 = src[e];
+        if (e1 < nw) v1 = src[e1];
         fill_cam_table_wait();
-        if (mine) write_vtil<NBm>(Mr, d, tab + CM::TA * i + CM::VOFF);
-        for (i += PT_THREADS; i < win.y; i += PT_THREADS) {       // (windows wider than the workgroup)
-          const int c = win.x + i;
-#pragma unroll
-          for (int q = 0; q < 9; ++q) Mr[q] = cu.cs[CS * (size_t)c + 12 + q];
-#pragma unroll
-          for (int q = 0; q < NBm; ++q) d[q] = (c == fixed_cam) ? 0.0 : cu.dc[NBm * (size_t)c + q];
-          write_vtil<NBm>(Mr, d, tab + CM::TA * i + CM::VOFF);
-        }
+        if (e < nw) tab[CM::TA * (e / NBm) + CM::VOFF + e % NBm] = v0;
+        if (e1 < nw) tab[CM::TA * (e1 / NBm) + CM::VOFF + e1 % NBm] = v1;
+        for (e += 2 * PT_THREADS; e < nw; e += PT_THREADS) tab[CM::TA * (e / NBm) + CM::VOFF + e % NBm] = src[e];
         __syncthreads();
       } else {
         fill_cam_table_wait();
@@ -1238,31 +1245,32 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
 template <class CM, bool ROBUST, int MODE, bool ALL_LDS, int LANES, typename JT>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_schur(BA_SCH_PARAMS, PtWork wk, BA_SCH_TAIL) {
-  const int n_rider = (MODE == 1) ? cu.n_blocks : 0;           // the camera update's workgroups: the LAST ones of the launch
-  if (MODE == 1 && (int)blockIdx.x >= (int)gridDim.x - n_rider) {
+  const int n_rider = (MODE == 1) ? cu.n_blocks : 0;           // the camera update's workgroups: the FIRST ones of the launch
+  if (MODE == 1 && (int)blockIdx.x < n_rider) {
     extern __shared__ __align__(16) double tab[];
-    cam_update_body<CM>(cu, (int)blockIdx.x - ((int)gridDim.x - n_rider), tab);
+    cam_update_rider<CM>(cu, blockIdx.x, tab);
     return;
   }
-  pt_schur_body<CM, ROBUST, MODE, ALL_LDS, LANES, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk, blockIdx.x, (int)gridDim.x - n_rider,
-                                                  BA_SCH_TAIL_ARGS);
+  pt_schur_body<CM, ROBUST, MODE, ALL_LDS, LANES, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk, (int)blockIdx.x - n_rider,
+                                                  (int)gridDim.x - n_rider, BA_SCH_TAIL_ARGS);
 }
 // short and long tracks in one launch (see k_pt_linearize_both)
 template <class CM, bool ROBUST, int MODE, bool ALL_LDS, typename JT>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_schur_both(BA_SCH_PARAMS, PtWork wk, int nblk_short, PtWork wl, BA_SCH_TAIL) {
   const int n_rider = (MODE == 1) ? cu.n_blocks : 0;
-  if (MODE == 1 && (int)blockIdx.x >= (int)gridDim.x - n_rider) {
+  if (MODE == 1 && (int)blockIdx.x < n_rider) {
     extern __shared__ __align__(16) double tab[];
-    cam_update_body<CM>(cu, (int)blockIdx.x - ((int)gridDim.x - n_rider), tab);
+    cam_update_rider<CM>(cu, blockIdx.x, tab);
     return;
   }
-  if ((int)blockIdx.x < nblk_short)
-    pt_schur_body<CM, ROBUST, MODE, ALL_LDS, LPP, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk, blockIdx.x, nblk_short,
+  const int bid = (int)blockIdx.x - n_rider;
+  if (bid < nblk_short)
+    pt_schur_body<CM, ROBUST, MODE, ALL_LDS, LPP, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk, bid, nblk_short,
                                                   BA_SCH_TAIL_ARGS);
   else
     pt_schur_body<CM, ROBUST, MODE, ALL_LDS, LPP_LONG, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wl,
-                                                       blockIdx.x - nblk_short, (int)gridDim.x - n_rider - nblk_short, BA_SCH_TAIL_ARGS);
+                                                       bid - nblk_short, (int)gridDim.x - n_rider - nblk_short, BA_SCH_TAIL_ARGS);
 }
 #undef BA_SCH_PARAMS
 #undef BA_SCH_TAIL
@@ -1307,7 +1315,7 @@ __device__ inline void slice_write_back(double* __restrict__ dst, const double* 
   }
 }
 constexpr int VC = VEC_CAMS;
-static_assert(VEC_CAMS == 16, "the staging below is laid out for 16 cameras per camera-vector workgroup");
+static_assert(VEC_CAMS == 16 || VEC_CAMS == 8 || VEC_CAMS == 4, "camera-vector workgroups: 4, 8 or 16 cameras per wave (the coarse level of ba_coarse.hpp and its oracle mirror assume 16)");
 constexpr int slice_chunks(int doubles) { return (doubles + 127) / 128; }      // double2 per lane that cover a slice
 
 // PCG setup at damping lambda: Hccd = Hcc + lam Dc (fixed camera: identity), Schur-Jacobi
@@ -1323,7 +1331,8 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
             int use_schur_diag, int n_cams, int fixed_cam, double* __restrict__ Hccd, double* __restrict__ Minv,
             double* __restrict__ gvec, double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
             double* __restrict__ s, double* __restrict__ z, double* __restrict__ vtil,
-            double* __restrict__ partV, PcgState* __restrict__ st, double* __restrict__ partGc, double* __restrict__ rc) {
+            double* __restrict__ partV, PcgState* __restrict__ st, double* __restrict__ partGc, double* __restrict__ rc,
+            double* __restrict__ vx) {
   constexpr int NB = CM::NB, NH = CM::NH, NL = CM::NL;
   // (rc != null: two-level preconditioner -- also the aggregate's restricted right-hand side; z, partV and vtil written
   // here are then the single-level ones and are redone by k_pcg_coarse once E^-1 exists)
@@ -1453,7 +1462,10 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
   slice_write_back(gvec + NB * (size_t)c0, l_g, NB * nc);
   slice_write_back(r + NB * (size_t)c0, l_g, NB * nc);
   slice_write_back(z + NB * (size_t)c0, l_z, NB * nc);
-  for (int i = lane; i < NB * nc; i += 64) { x[NB * (size_t)c0 + i] = 0.0; p[NB * (size_t)c0 + i] = 0.0; s[NB * (size_t)c0 + i] = 0.0; }
+  for (int i = lane; i < NB * nc; i += 64) {
+    x[NB * (size_t)c0 + i] = 0.0; p[NB * (size_t)c0 + i] = 0.0; s[NB * (size_t)c0 + i] = 0.0;
+    vx[NB * (size_t)c0 + i] = 0.0;                       // the iterate in the point passes' form (see k_pcg_step)
+  }
 #pragma unroll
   for (int q = 0; q < 2; ++q) acc[q] = wave_total_dpp(acc[q]);
   gmc = wave_nanmax(gmc);
@@ -1487,7 +1499,7 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
            double* __restrict__ x, double* __restrict__ r, double* __restrict__ p, double* __restrict__ s,
            double* __restrict__ z, double* __restrict__ vtil, double* __restrict__ partV, int nblkV,
            PcgState* __restrict__ st, long long* __restrict__ host_flag, long long flag_base,
-           const double* __restrict__ verdict, double* __restrict__ rc) {
+           const double* __restrict__ verdict, double* __restrict__ rc, double* __restrict__ vx) {
   constexpr int NB = CM::NB, NH = CM::NH;
   // LDS image of the workgroup's cameras: Hccd | Minv | z p s r x | part6[NPART] | cs
   __shared__ double l_h[NH * VC], l_mi[NH * VC], l_v[5][NB * VC], l_p6[NPART][NB * VC], l_cs[CS * VC];
@@ -1601,6 +1613,9 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
       }
     }
     if (!COARSE) write_vtil<NB>(M, zz, vtil + CM::TA * (size_t)c + CM::VOFF);
+    // the iterate itself in the point passes' form, (M x_r, x_t, ..): what the back substitution multiplies with once PCG
+    // has stopped -- kept current here so that no kernel has to run between the last PCG iteration and the step
+    write_vtil<NB>(M, xx, vx + NB * (size_t)c);
   }
   if (COARSE) {                                         // restricted residual of this aggregate (= this workgroup)
 #pragma unroll
@@ -1639,11 +1654,12 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
 // K7a: camera update.  cams_trial = cams + dc (BAL: also intr_trial = intr + the last three entries of dc), camera
 // state and table row of the trial cameras, vtil = (M dc_r, dc_t, ..) into camA for the back substitution,
 // camera-side scalars -> partC[block][5]: bc.dc, sum Dc dc^2, dc.r_pcg, |dc|^2, |cams|^2
-// Body for workgroup `blk` of VC cameras; wave 0 does the work, every thread of the workgroup passes the barriers (the
-// body also runs as extra 1024-thread workgroups of the back-substitution launch, see "riders").  lds: at least
-// cam_update_lds_doubles<CM>() doubles of LDS, 16-byte aligned.
+// Body for camera group `blk` (VC cameras), run by ONE wave (`active`: this wave has a group); every thread of the
+// workgroup passes the barriers (the body also runs inside 1024-thread workgroups of the back-substitution launch, one
+// group per wave for the first CU_GROUPS waves, see "riders").  lds: this wave's cam_update_lds_doubles<CM>() doubles
+// of LDS, 16-byte aligned.
 template <class CM>
-__device__ void cam_update_body(const CamUpdateArgs& a, int blk, double* __restrict__ lds) {
+__device__ void cam_update_body(const CamUpdateArgs& a, int blk, bool active, double* __restrict__ lds) {
   constexpr int NB = CM::NB, NH = CM::NH;
   // LDS image of the workgroup's VC cameras (coalesced staging, see slice_load): cams | dc rpcg bc | Hcc | cs,
   // outputs cams_trial | cs_trial staged for a coalesced write-back
@@ -1654,10 +1670,11 @@ __device__ void cam_update_body(const CamUpdateArgs& a, int blk, double* __restr
   double* l_ct = l_cs + CS * VC;
   double* l_cst = l_ct + 6 * VC;
   const int n_cams = a.n_cams, fixed_cam = a.fixed_cam;
-  const bool w0 = threadIdx.x < 64;
+  const bool w0 = active;
+  const int lane = threadIdx.x & 63;
   const int c0 = blk * VC;
   const int nc = min(VC, n_cams - c0);
-  const int c = (threadIdx.x < VEC_CAMS) ? c0 + (int)threadIdx.x : n_cams;
+  const int c = (lane < VEC_CAMS) ? c0 + lane : n_cams;
   if (w0) {
     double2 v0[slice_chunks(6 * VC)], vi[3][slice_chunks(NB * VC)], vh[slice_chunks(NH * VC)], vc[slice_chunks(CS * VC)];
     const double* ins[3] = {a.dc, a.rpcg, a.bc};
@@ -1674,7 +1691,7 @@ __device__ void cam_update_body(const CamUpdateArgs& a, int blk, double* __restr
   }
   __syncthreads();
   double acc[5] = {0, 0, 0, 0, 0};
-  const int t = threadIdx.x;
+  const int t = lane;
   if (w0 && c < n_cams) {
     double d[NB];
     for (int q = 0; q < NB; ++q) d[q] = (c == fixed_cam) ? 0.0 : l_in[NB * t + q];
@@ -1702,7 +1719,7 @@ __device__ void cam_update_body(const CamUpdateArgs& a, int blk, double* __restr
     slice_write_back(a.cs_trial + CS * (size_t)c0, l_cst, CS * nc);
 #pragma unroll
     for (int q = 0; q < 5; ++q) acc[q] = wave_total_dpp(acc[q]);
-    if (threadIdx.x == 0) for (int q = 0; q < 5; ++q) a.partC[5 * blk + q] = acc[q];
+    if (lane == 0) for (int q = 0; q < 5; ++q) a.partC[5 * blk + q] = acc[q];
   }
 }
 // stand-alone launch (camera windows that do not all fit in LDS, a rank without landmarks)
@@ -1710,7 +1727,15 @@ template <class CM>
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_cam_update(CamUpdateArgs a) {
   __shared__ __align__(16) double lds[cam_update_lds_doubles<CM>()];
-  cam_update_body<CM>(a, blockIdx.x, lds);
+  cam_update_body<CM>(a, blockIdx.x, true, lds);
+}
+// the same as riding workgroup `rb` of a 1024-thread launch: waves 0 .. CU_GROUPS-1 take one camera group each
+template <class CM>
+__device__ __forceinline__ void cam_update_rider(const CamUpdateArgs& a, int rb, double* __restrict__ dyn_lds) {
+  const int wv = threadIdx.x >> 6;
+  const int grp = rb * CU_GROUPS + wv;
+  const int n_groups = (a.n_cams + VEC_CAMS - 1) / VEC_CAMS;
+  cam_update_body<CM>(a, grp, wv < CU_GROUPS && grp < n_groups, dyn_lds + (wv < CU_GROUPS ? wv : 0) * cam_update_lds_doubles<CM>());
 }
 
 // One workgroup folds every partial-sum array of an LM step into the scalar block `scal`

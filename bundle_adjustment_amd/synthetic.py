@@ -45,39 +45,16 @@ def _perturb_cameras(rng, rvec, centre, rot_sigma, trans_sigma):
     return np.concatenate([r0, t0], axis=1)
 
 
-def make_problem(n_cams, n_pts, obs_per_pt, seed=0, K4=REF_K4, image_wh=IMAGE_WH,
-                 pixel_sigma=0.5, rot_sigma=0.005, trans_sigma=0.02, point_sigma=0.05,
-                 outlier_frac=0.0, return_truth=False):
-    """Cameras on a gentle arc looking down +z at a box of points 8-16 m away; every
-    point is seen by ``obs_per_pt`` distinct cameras chosen uniformly among those that
-    image it inside the frame; pixels get N(0, pixel_sigma) noise and are rounded to
-    float32 (keypoint precision, SURVEY.md 8a a3); the initial guess is the truth
-    perturbed by (rot_sigma, trans_sigma, point_sigma).  Camera 0 is the identity and is
-    the fixed camera.  Observation order = camera ascending, then point ascending
-    (the reference's gather order for a map whose keyframes list points by id)."""
-    rng = np.random.default_rng(seed)
-    K4 = np.asarray(K4, dtype=np.float64)
+def _observe(rng, cams_true, pts_true, obs_per_pt, K4, image_wh, pixel_sigma, outlier_frac=0.0):
+    """Every point is seen by ``obs_per_pt`` distinct cameras chosen uniformly among those that image it inside the frame;
+    pixels = projection + N(0, pixel_sigma), rounded to float32.  Returns (cam_idx, pt_idx, uv), camera-major order."""
+    n_cams, n_pts = cams_true.shape[0], pts_true.shape[0]
     w, h = image_wh
-    # ---- ground truth cameras (world->camera), camera 0 = identity
-    s = np.linspace(-1.0, 1.0, n_cams) if n_cams > 1 else np.zeros(1)
-    s = s - s[0]
-    centre = np.stack([1.5 * s, 0.15 * np.sin(2.0 * s), 0.2 * (1 - np.cos(1.5 * s))], axis=1)
-    rvec = rng.normal(0.0, 0.05, size=(n_cams, 3))
-    rvec[:, 1] += -0.08 * s                      # pan back towards the scene centre
-    rvec[0] = 0.0
-    R = rvecs_to_matrices(rvec)
-    tvec = -np.einsum('nij,nj->ni', R, centre)
-    cams_true = np.concatenate([rvec, tvec], axis=1)
-    # ---- ground truth points: box in front of the arc
-    span = 1.5 * (s.max() - s.min())
-    pts_true = np.stack([rng.uniform(-2.0, 2.0 + span, n_pts) - 0.0,
-                         rng.uniform(-1.5, 1.5, n_pts),
-                         rng.uniform(8.0, 16.0, n_pts)], axis=1)
     # ---- visibility + choice of obs_per_pt distinct cameras per point
     k = min(obs_per_pt, n_cams)
     cam_sel = np.empty((n_pts, k), dtype=np.int32)
     chunk = max(1, min(n_pts, 4_000_000 // max(n_cams, 1)))
-    Rm, tm = R, tvec
+    Rm, tm = rvecs_to_matrices(cams_true[:, :3]), cams_true[:, 3:]
     for a in range(0, n_pts, chunk):
         b = min(n_pts, a + chunk)
         X = pts_true[a:b]
@@ -109,6 +86,38 @@ def make_problem(n_cams, n_pts, obs_per_pt, seed=0, K4=REF_K4, image_wh=IMAGE_WH
         idx = rng.choice(uv.shape[0], size=nout, replace=False)
         uv[idx] += rng.normal(0.0, 30.0, size=(nout, 2))
     uv = uv.astype(np.float32).astype(np.float64)
+    return cam_idx, pt_idx, uv
+
+
+def make_problem(n_cams, n_pts, obs_per_pt, seed=0, K4=REF_K4, image_wh=IMAGE_WH,
+                 pixel_sigma=0.5, rot_sigma=0.005, trans_sigma=0.02, point_sigma=0.05,
+                 outlier_frac=0.0, return_truth=False):
+    """Cameras on a gentle arc looking down +z at a box of points 8-16 m away; every
+    point is seen by ``obs_per_pt`` distinct cameras chosen uniformly among those that
+    image it inside the frame; pixels get N(0, pixel_sigma) noise and are rounded to
+    float32 (keypoint precision, SURVEY.md 8a a3); the initial guess is the truth
+    perturbed by (rot_sigma, trans_sigma, point_sigma).  Camera 0 is the identity and is
+    the fixed camera.  Observation order = camera ascending, then point ascending
+    (the reference's gather order for a map whose keyframes list points by id)."""
+    rng = np.random.default_rng(seed)
+    K4 = np.asarray(K4, dtype=np.float64)
+    w, h = image_wh
+    # ---- ground truth cameras (world->camera), camera 0 = identity
+    s = np.linspace(-1.0, 1.0, n_cams) if n_cams > 1 else np.zeros(1)
+    s = s - s[0]
+    centre = np.stack([1.5 * s, 0.15 * np.sin(2.0 * s), 0.2 * (1 - np.cos(1.5 * s))], axis=1)
+    rvec = rng.normal(0.0, 0.05, size=(n_cams, 3))
+    rvec[:, 1] += -0.08 * s                      # pan back towards the scene centre
+    rvec[0] = 0.0
+    R = rvecs_to_matrices(rvec)
+    tvec = -np.einsum('nij,nj->ni', R, centre)
+    cams_true = np.concatenate([rvec, tvec], axis=1)
+    # ---- ground truth points: box in front of the arc
+    span = 1.5 * (s.max() - s.min())
+    pts_true = np.stack([rng.uniform(-2.0, 2.0 + span, n_pts) - 0.0,
+                         rng.uniform(-1.5, 1.5, n_pts),
+                         rng.uniform(8.0, 16.0, n_pts)], axis=1)
+    cam_idx, pt_idx, uv = _observe(rng, cams_true, pts_true, obs_per_pt, K4, image_wh, pixel_sigma, outlier_frac)
     # ---- initial guess
     cams0 = _perturb_cameras(rng, rvec, centre, rot_sigma, trans_sigma)
     pts0 = pts_true + rng.normal(0.0, point_sigma, size=pts_true.shape)
@@ -116,6 +125,39 @@ def make_problem(n_cams, n_pts, obs_per_pt, seed=0, K4=REF_K4, image_wh=IMAGE_WH
     if return_truth:
         return prob, cams_true, pts_true
     return prob
+
+
+def _arc_cameras(rng, n_cams):
+    """Ground-truth cameras of make_problem: a gentle arc looking down +z, camera 0 = identity (same draws, same order)."""
+    s = np.linspace(-1.0, 1.0, n_cams) if n_cams > 1 else np.zeros(1)
+    s = s - s[0]
+    centre = np.stack([1.5 * s, 0.15 * np.sin(2.0 * s), 0.2 * (1 - np.cos(1.5 * s))], axis=1)
+    rvec = rng.normal(0.0, 0.05, size=(n_cams, 3))
+    rvec[:, 1] += -0.08 * s
+    rvec[0] = 0.0
+    R = rvecs_to_matrices(rvec)
+    tvec = -np.einsum('nij,nj->ni', R, centre)
+    return rvec, centre, np.concatenate([rvec, tvec], axis=1), s
+
+
+def make_weak_shard(n_cams, pts_per_rank, obs_per_pt, seed, rank, K4=REF_K4, image_wh=IMAGE_WH, pixel_sigma=0.5,
+                    rot_sigma=0.005, trans_sigma=0.02, point_sigma=0.05):
+    """Landmark shard `rank` of a problem that GROWS with the number of ranks (weak scaling: `pts_per_rank` points per
+    rank, the same `n_cams` cameras on every rank): cameras -- truth and initial guess -- come from a stream that depends on
+    `seed` only, so every rank builds identical ones; the shard's points, visibility choices and pixel noise come from a
+    stream of (seed, rank).  The union over ranks is one bundle-adjustment problem of n_ranks * pts_per_rank points in the
+    scene of ``make_problem``; no rank ever materialises more than its own shard.  Returns a BAProblem (camera 0 fixed)."""
+    K4 = np.asarray(K4, dtype=np.float64)
+    rng_c = np.random.default_rng([int(seed), 0])
+    rvec, centre, cams_true, s = _arc_cameras(rng_c, n_cams)
+    cams0 = _perturb_cameras(rng_c, rvec, centre, rot_sigma, trans_sigma)
+    rng_p = np.random.default_rng([int(seed), 1, int(rank)])
+    span = 1.5 * (s.max() - s.min())
+    pts_true = np.stack([rng_p.uniform(-2.0, 2.0 + span, pts_per_rank), rng_p.uniform(-1.5, 1.5, pts_per_rank),
+                         rng_p.uniform(8.0, 16.0, pts_per_rank)], axis=1)
+    cam_idx, pt_idx, uv = _observe(rng_p, cams_true, pts_true, obs_per_pt, K4, image_wh, pixel_sigma)
+    pts0 = pts_true + rng_p.normal(0.0, point_sigma, size=pts_true.shape)
+    return BAProblem(cams0, pts0, cam_idx.astype(np.int32), pt_idx.astype(np.int32), uv, K4.copy(), 0).validate()
 
 
 def make_config(name, seed=0, **overrides):

@@ -318,7 +318,11 @@ def test_bal_fp32_jacobian_mode_reaches_the_fp64_solution():
         a, ca, pa = s.solve_bal(p, **kw)
         b, cb, pb = s.solve_bal(p, jacobian_precision=1, **kw)
     assert abs(a["final_cost"] - b["final_cost"]) <= 1e-7 * a["final_cost"]
-    assert np.abs(ca - cb).max() <= 1e-4 * np.abs(ca).max() and np.abs(pa - pb).max() <= 1e-4 * np.abs(pa).max()
+    # (only camera 0 is held: the scale of the scene is free, the minimiser is a one-parameter family and the two runs
+    # stop at different members of it -- rotations, focal lengths and distortion are scale-free and agree)
+    assert np.abs(ca[:, :3] - cb[:, :3]).max() <= 1e-5 and np.abs(ca[:, 6:] / cb[:, 6:] - 1).max() <= 1e-4
+    sc = np.linalg.norm(ca[1:, 3:6]) / np.linalg.norm(cb[1:, 3:6])
+    assert abs(sc - 1) < 1e-2 and np.abs(sc * pb - pa).max() <= 1e-3 * np.abs(pa).max()
 
 
 @pytest.mark.gpu

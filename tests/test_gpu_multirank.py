@@ -51,13 +51,16 @@ dist.destroy_process_group()
 """
 
 
-def test_two_ranks_on_one_gpu_match_single_rank(tmp_path):
+@pytest.mark.parametrize("one_part", ["0", "1"])
+def test_two_ranks_on_one_gpu_match_single_rank(tmp_path, one_part):
+    """one_part = 1: every camera's shard-local observations in partition 0 (what thin shards of a many-rank job get
+    by themselves, ba_set_problem): partial sums come out folded, no fold kernel runs ahead of the all-reduces."""
     from bundle_adjustment_amd import hip_backend
     from bundle_adjustment_amd.problem import shard_by_landmark
     from bundle_adjustment_amd.synthetic import make_problem
     script = tmp_path / "worker.py"
     script.write_text(WORKER % dict(root=ROOT, out=str(tmp_path)))
-    env = dict(os.environ, BA_COMM="shm")
+    env = dict(os.environ, BA_COMM="shm", BA_ONE_PART=one_part)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", _free_port(), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
@@ -254,6 +257,9 @@ def test_bench_two_ranks_over_the_shm_transport_reports_its_transport(tmp_path):
     cfg = line["config"]
     assert line["n_gpus"] == 2 and cfg["world"] == 2 and cfg["transport"] == "shm" and cfg["ranks_in_communicator"] == 2
     assert line["steps"] == 4 and line["value"] > 0 and line["repeats"] == 2
+    # next to the strong line: the problem that grows with the ranks (every rank its own C2-sized landmark shard)
+    weak = line["weak_scaling"]
+    assert weak["value"] > 0 and "x 2" in weak["workload"] and f"{2 * 5000} pts" in weak["workload"] and weak["final_rmse_px"] < 3.0
 
 
 def test_real_rccl_communicator_of_one_rank_runs_the_whole_multi_rank_loop(monkeypatch):
