@@ -185,6 +185,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--pcg-tol", type=float, default=0.1)
     ap.add_argument("--pcg-max-iters", type=int, default=200)
+    ap.add_argument("--pcg-model-tol", type=float, default=0.0, help="Nash & Sofer model test of the PCG loop (ba_options.pcg_model_tol; 0 = off)")
     ap.add_argument("--precond", default="schur_jacobi", choices=["schur_jacobi", "jacobi", "two_level"])
     ap.add_argument("--jacobian", default="f64", choices=["f64", "f32"], help="f32: config 5's fp32 Jacobian blocks in the PCG passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -284,6 +285,7 @@ def main():
     # per-iteration gradient-norm work of a production run() (per-workgroup maxima folded by the first PCG probe) is inside
     # the timed region
     kw = dict(loss=args.loss, ftol=0.0, xtol=0.0, gtol=1e-300, pcg_tol=args.pcg_tol, pcg_max_iters=args.pcg_max_iters,
+              pcg_model_tol=args.pcg_model_tol,
               preconditioner=args.precond, jacobian_precision=1 if args.jacobian == "f32" else 0)
 
     def run_solve(**k):
@@ -418,7 +420,7 @@ def main():
             "dtype": "f64" if args.jacobian == "f64" else "f64 accumulation and solve, f32 Jacobian blocks in the PCG passes",
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {prob.n_cams} cams / {prob.n_pts} pts / {n_obs_total} obs, "
-                                   f"loss={args.loss}, LM+Schur+PCG(tol {args.pcg_tol})"
+                                   f"loss={args.loss}, LM+Schur+PCG(tol {args.pcg_tol}, model test {args.pcg_model_tol})"
                                    + (", BAL 9-parameter camera (f, k1, k2 per camera, adjusted)" if intr0 is not None else ""),
                        "camera": args.camera,
                        "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU", "comm": comm_note,

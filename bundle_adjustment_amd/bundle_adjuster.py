@@ -40,14 +40,14 @@ from .rotations import matrices_to_rvecs
 
 class BundleAdjuster:
     def __init__(self, camera_matrix, window_size=5, *, device_id=0, loss='huber', f_scale=1.0, ftol=1e-5,
-                 xtol=1e-5, gtol=1e-8, max_iters=50, pcg_tol=0.1, pcg_max_iters=200, preconditioner='schur_jacobi',
+                 xtol=1e-5, gtol=1e-8, max_iters=50, pcg_tol=0.1, pcg_max_iters=200, pcg_model_tol=0.0, preconditioner='schur_jacobi',
                  jacobian='f64', comm=None, sparsity_plot_hook=None, verbose=0, reuse_window=True, metrics_path=None,
                  inplace_writeback=False):
         self.camera_matrix = camera_matrix
         self.window_size = window_size
         self.device_id = device_id
         self.solver_options = dict(loss=loss, f_scale=f_scale, ftol=ftol, xtol=xtol, gtol=gtol, max_iters=max_iters,
-                                   pcg_tol=pcg_tol, pcg_max_iters=pcg_max_iters, preconditioner=preconditioner,
+                                   pcg_tol=pcg_tol, pcg_max_iters=pcg_max_iters, pcg_model_tol=pcg_model_tol, preconditioner=preconditioner,
                                    jacobian_precision={'f64': 0, 'f32': 1}[jacobian], verbose=verbose)
         self.comm = comm                       # None, or (rank, world, unique_id bytes)
         self.sparsity_plot_hook = sparsity_plot_hook

@@ -121,12 +121,15 @@ template <typename T>
 struct DBuf {
   T* p = nullptr;
   size_t n = 0;
+  // a NEW allocation comes back zero-filled (once: callers do not clear buffers on every use)
   hipError_t alloc(size_t count) {
     if (p && n >= count && count > 0) return hipSuccess;
     release();
     n = count;
     if (count == 0) return hipSuccess;
-    return hipMalloc((void**)&p, count * sizeof(T));
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e != hipSuccess) { p = nullptr; n = 0; return e; }
+    return hipMemset(p, 0, count * sizeof(T));
   }
   void release() {
     if (p) (void)hipFree(p);
@@ -172,6 +175,8 @@ struct ba_handle {
   DBuf<double> gvec, x, r, p, s, z, vin, vx, scal, rbuf, gather;
   DBuf<PcgState> st;
   DBuf<double> tri;            // staging of ba_triangulate
+  char* h_up = nullptr;        // pinned staging of ba_set_problem's index uploads (small problems: one memcpy + async copies
+  size_t h_up_cap = 0;         //  instead of a blocking staged copy per array; grow-only)
   char* h_small = nullptr;     // k_small_lm's results, host-mapped: ba_summary | int cur | trace records
   char* d_small_host = nullptr;
   size_t h_small_bytes = 0;
@@ -358,6 +363,7 @@ extern "C" int ba_destroy(ba_handle* h) {
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->h_flags) (void)hipHostFree(h->h_flags);
   if (h->h_small) (void)hipHostFree(h->h_small);
+  if (h->h_up) (void)hipHostFree(h->h_up);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return BA_OK;
@@ -867,29 +873,47 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   h->lds_bytes_m[0] = max_win[0]; h->lds_bytes_m[1] = max_win[1];
   stage("long tracks + windows");
   const size_t nobs1 = std::max(No, 1), np1 = std::max(Np, 1);
+  // Index uploads.  A window-sized problem (the reference's own use: a few thousand observations) sends a dozen small
+  // arrays; copied from pageable memory each is a blocking staged transfer (~10 us), so they go through ONE pinned
+  // staging block and truly asynchronous copies.  Large problems (C3: 36 MB) keep the direct path.
+  size_t up_used = 0;
+  const size_t up_need = ((size_t)No * (4 * 4 + 16) + (size_t)Np * 12 + (size_t)Nc * 40 + win.size() * 8 + 4096) * 1;
+  const bool staged = up_need <= ((size_t)4 << 20);
+  if (staged && h->h_up_cap < up_need) {
+    if (h->h_up) { (void)hipHostFree(h->h_up); h->h_up = nullptr; h->h_up_cap = 0; }
+    HIPCHECK(hipHostMalloc((void**)&h->h_up, up_need, hipHostMallocDefault));
+    h->h_up_cap = up_need;
+  }
+  auto upload = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+    if (bytes == 0) return hipSuccess;
+    if (staged && up_used + bytes <= h->h_up_cap) {
+      memcpy(h->h_up + up_used, src, bytes);
+      const hipError_t e = hipMemcpyAsync(dst, h->h_up + up_used, bytes, hipMemcpyHostToDevice, h->stream);
+      up_used += (bytes + 63) & ~(size_t)63;
+      return e;
+    }
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream);
+  };
   HIPCHECK(h->offk.alloc((size_t)Nc * (NPART + 1))); HIPCHECK(h->pt_off.alloc(Np + 1));
   HIPCHECK(h->slot.alloc(np1));
-  if (Np > 0) HIPCHECK(hipMemcpyAsync(h->slot.p, slot.data(), Np * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (Np > 0) HIPCHECK(upload(h->slot.p, slot.data(), Np * sizeof(int)));
   HIPCHECK(h->blk_win.alloc(win.size()));
-  HIPCHECK(hipMemcpyAsync(h->blk_win.p, win.data(), win.size() * sizeof(int2), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(upload(h->blk_win.p, win.data(), win.size() * sizeof(int2)));
   HIPCHECK(h->long_pts.alloc(std::max(h->n_long, 1)));
-  if (h->n_long) HIPCHECK(hipMemcpyAsync(h->long_pts.p, long_pts.data(), h->n_long * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  if (h->n_long) HIPCHECK(upload(h->long_pts.p, long_pts.data(), h->n_long * sizeof(int)));
   HIPCHECK(h->c_pt.alloc(nobs1)); HIPCHECK(h->c_orig.alloc(nobs1)); HIPCHECK(h->p_cam.alloc(nobs1));
   HIPCHECK(h->c_uv.alloc(nobs1)); HIPCHECK(h->p_uv.alloc(nobs1));
   HIPCHECK(h->c_w[0].alloc(nobs1)); HIPCHECK(h->c_w[1].alloc(nobs1)); HIPCHECK(h->p_w[0].alloc(nobs1)); HIPCHECK(h->p_w[1].alloc(nobs1));
   HIPCHECK(h->c_ptf[0].alloc(nobs1)); HIPCHECK(h->c_ptf[1].alloc(nobs1)); HIPCHECK(h->p_camf[0].alloc(nobs1)); HIPCHECK(h->p_camf[1].alloc(nobs1));
   for (int k = 0; k < 2; ++k) {
     HIPCHECK(h->cams[k].alloc(6 * (size_t)Nc)); HIPCHECK(h->cs[k].alloc(CS * (size_t)Nc));
-    HIPCHECK(h->ptab[k].alloc(PT * np1));
-    HIPCHECK(hipMemsetAsync(h->ptab[k].p, 0, PT * np1 * sizeof(double), h->stream));
-  }
+    HIPCHECK(h->ptab[k].alloc(PT * np1));     // (k_pack_points writes whole records of set 0; set 1 gets X from the back
+  }                                           //  substitution and y from the point half before either is read)
   HIPCHECK(h->stage.alloc(3 * np1));
   // per-camera buffers are sized for the larger camera model (BAL: 9 parameters, 45 + 9 sums, 26-double table rows)
   constexpr size_t NBX = BalCam::NB, NHX = BalCam::NH, NLX = BalCam::NL;
   HIPCHECK(h->camA[0].alloc(TA_MAX * (size_t)Nc)); HIPCHECK(h->camA[1].alloc(TA_MAX * (size_t)Nc));
   HIPCHECK(h->intr[0].alloc(3 * (size_t)Nc)); HIPCHECK(h->intr[1].alloc(3 * (size_t)Nc));
-  HIPCHECK(hipMemsetAsync(h->intr[0].p, 0, 3 * (size_t)Nc * sizeof(double), h->stream));
-  HIPCHECK(hipMemsetAsync(h->intr[1].p, 0, 3 * (size_t)Nc * sizeof(double), h->stream));
   HIPCHECK(h->HccBc.alloc(NLX * (size_t)Nc + 8));   // Hcc (NH Nc) | bc (NB Nc): one all-reduce
   for (int k = 0; k < 2; ++k) {
     HIPCHECK(h->Hpp[k].alloc(6 * np1)); HIPCHECK(h->bp[k].alloc(3 * np1)); HIPCHECK(h->Hppinv[k].alloc(6 * np1));
@@ -922,31 +946,28 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(h->verdict.alloc(8));
   HIPCHECK(hipMemsetAsync(h->verdict.p, 0, 8 * sizeof(double), h->stream));
   HIPCHECK(h->dev_seq.alloc(2));
-  HIPCHECK(hipMemsetAsync(h->dev_seq.p, 0, 2 * sizeof(long long), h->stream));
-  HIPCHECK(hipMemsetAsync(h->camA[0].p, 0, TA_MAX * (size_t)Nc * sizeof(double), h->stream));
-  HIPCHECK(hipMemsetAsync(h->camA[1].p, 0, TA_MAX * (size_t)Nc * sizeof(double), h->stream));
+  // (dev_seq only ever grows with the handle's step sequence; camA rows: geometry by k_cam_prepare / k_cam_update, vt by the
+  //  PCG setup before any pass reads it)
   h->lb = 0;
   stage("allocations");
-  HIPCHECK(hipMemcpyAsync(h->offk.p, offk.data(), offk.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  HIPCHECK(hipMemcpyAsync(h->pt_off.p, pt_off.data(), (Np + 1) * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(upload(h->offk.p, offk.data(), offk.size() * sizeof(int)));
+  HIPCHECK(upload(h->pt_off.p, pt_off.data(), (Np + 1) * sizeof(int)));
   if (No > 0) {
-    HIPCHECK(hipMemcpyAsync(h->c_pt.p, c_pt.data(), No * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(hipMemcpyAsync(h->c_orig.p, c_orig.data(), No * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(hipMemcpyAsync(h->p_cam.p, p_cam.data(), No * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(upload(h->c_pt.p, c_pt.data(), No * sizeof(int)));
+    HIPCHECK(upload(h->c_orig.p, c_orig.data(), No * sizeof(int)));
+    HIPCHECK(upload(h->p_cam.p, p_cam.data(), No * sizeof(int)));
     // pixels: uploaded once in the caller's order, permuted into both orderings on the device
     // (staging: the residual buffer for the pixels, a flagged-index buffer for the point-order permutation)
     HIPCHECK(h->rbuf.alloc(2 * (size_t)No));
-    HIPCHECK(hipMemcpyAsync(h->rbuf.p, uv, 2 * (size_t)No * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(hipMemcpyAsync(h->c_ptf[0].p, p_src.data(), No * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(upload(h->rbuf.p, uv, 2 * (size_t)No * sizeof(double)));
+    HIPCHECK(upload(h->c_ptf[0].p, p_src.data(), No * sizeof(int)));
     const dim3 gg((No + 255) / 256), gb(256);
     BA_LAUNCH(k_gather_uv, gg, gb, 0, h->stream, (const double2*)h->rbuf.p, (const int*)h->c_ptf[0].p, No, h->p_uv.p);
     BA_LAUNCH(k_gather_uv, gg, gb, 0, h->stream, (const double2*)h->rbuf.p, (const int*)h->c_orig.p, No, h->c_uv.p);
     // the flagged copies of the index streams start as the plain streams: a robust linearisation reads them and stores
     // an entry only where its "weights are not (1, 1)" flag changes
-    for (int k = 0; k < 2; ++k) {
-      HIPCHECK(hipMemcpyAsync(h->c_ptf[k].p, h->c_pt.p, No * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
-      HIPCHECK(hipMemcpyAsync(h->p_camf[k].p, h->p_cam.p, No * sizeof(int), hipMemcpyDeviceToDevice, h->stream));
-    }
+    BA_LAUNCH(k_init_flagged, gg, gb, 0, h->stream, (const int*)h->c_pt.p, (const int*)h->p_cam.p, No, h->c_ptf[0].p, h->c_ptf[1].p,
+              h->p_camf[0].p, h->p_camf[1].p);
   }
   BA_SYNC(h);   // host vectors go out of scope
   stage("upload");
@@ -1511,6 +1532,8 @@ extern "C" int ba_default_options(ba_options* o) {
   o->reserved0 = 0;
   o->profile = 0;
   o->verbose = 0;
+  o->pcg_model_tol = 0.0;           // Nash & Sofer's truncated-Newton test on the quadratic model: off (ba_hip.h; 0.5 is their value)
+  o->pcg_model_min_iters = 5;
   return BA_OK;
 }
 
@@ -1712,6 +1735,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   if (opts->jacobian_precision != 0 && opts->jacobian_precision != 1)
     return fail(BA_ERR_INVALID, "jacobian_precision must be 0 (f64) or 1 (f32 blocks, f64 accumulation)");
   if (opts->preconditioner < BA_PRECOND_JACOBI || opts->preconditioner > BA_PRECOND_TWO_LEVEL) return fail(BA_ERR_INVALID, "unknown preconditioner");
+  if (!(opts->pcg_model_tol >= 0.0) || opts->pcg_model_min_iters < 0) return fail(BA_ERR_INVALID, "bad pcg_model_tol / pcg_model_min_iters");
   if (set_device(h)) return BA_ERR_HIP;
   memset(sum, 0, sizeof *sum);
   h->trace.clear();
@@ -1820,17 +1844,19 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
 #define STEP_ARGS kk, p6_ptr(h), NPART, (const double*)uy_ptr(h), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc, h->fixed, tol2,       \
                   opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA[h->cur].p, h->partV.p, h->nblkV, h->st.p, \
                   h->d_flags, base, (const double*)h->verdict.p
+#define STEP_TAIL h->vx.p, opts->pcg_model_tol, opts->pcg_model_min_iters
       if (h->two_level) {
-        BA_LAUNCH((k_pcg_step<Pinhole, true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, h->coarse_rc.p, h->vx.p);
+        BA_LAUNCH((k_pcg_step<Pinhole, true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, h->coarse_rc.p, STEP_TAIL);
         BA_LAUNCH(k_pcg_coarse, dim3(h->n_agg), dim3(VEC_BLOCK), 0, h->stream, kk, (const double*)h->coarseEinv.p,
                   (const double*)h->coarse_rc.p, h->n_agg, (const double*)h->Hccd.p, (const double*)h->cs[h->cur].p, Nc, h->fixed,
                   (const double*)h->r.p, h->z.p, h->camA[h->cur].p, h->partV.p, h->nblkV, (const double*)h->verdict.p, 1);
       } else if (h->model) {
-        BA_LAUNCH((k_pcg_step<BalCam, false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, (double*)nullptr, h->vx.p);
+        BA_LAUNCH((k_pcg_step<BalCam, false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, (double*)nullptr, STEP_TAIL);
       } else {
-        BA_LAUNCH((k_pcg_step<Pinhole, false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, (double*)nullptr, h->vx.p);
+        BA_LAUNCH((k_pcg_step<Pinhole, false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, (double*)nullptr, STEP_TAIL);
       }
 #undef STEP_ARGS
+#undef STEP_TAIL
       return BA_OK;
     };
     Range* r_pcg = new Range("pcg");

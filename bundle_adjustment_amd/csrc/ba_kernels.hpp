@@ -88,8 +88,10 @@ __device__ inline double wave_nanmax(double m) {
 
 // PCG device state, two copies indexed by iteration parity (see k_pcg_step)
 struct PcgState {
-  double gamma_prev, alpha_prev, gamma0, pad0;
-  int done, iters, flag, pad1;     // done: 1 converged, 2 breakdown
+  double gamma_prev, alpha_prev, gamma0;
+  double q_tot;                    // -q(x_k): decrease of the quadratic model 1/2 x^T S x - g^T x since x = 0 (sum of 1/2 alpha gamma)
+  int done, iters, flag;           // done: 1 converged, 2 breakdown
+  int stop_model;                  // the model test (ba_options.pcg_model_tol) fired after the last iteration: the next one does not run
 };
 
 // scalar slots written by k_scalars (device `scal`)
@@ -123,6 +125,16 @@ __global__ void k_fold_parts(double* __restrict__ parts, size_t n, int nparts) {
 __global__ void k_gather_uv(const double2* __restrict__ uv, const int* __restrict__ idx, int n, double2* __restrict__ out) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) out[j] = uv[idx[j]];
+}
+
+// the flagged copies of the two index streams start as the plain streams (a robust linearisation stores an entry only
+// where its flag changes)
+__global__ void k_init_flagged(const int* __restrict__ c_pt, const int* __restrict__ p_cam, int n, int* __restrict__ c_ptf0,
+                               int* __restrict__ c_ptf1, int* __restrict__ p_camf0, int* __restrict__ p_camf1) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int a = c_pt[j], b = p_cam[j];
+  c_ptf0[j] = a; c_ptf1[j] = a; p_camf0[j] = b; p_camf1[j] = b;
 }
 
 // pts (Np,3) -> X slots of the point table; table (Np,8) -> pts
@@ -360,7 +372,7 @@ __device__ inline bool pcg_finished(int k, const PcgState* __restrict__ st, cons
   g = wave_total_dpp(g);
   z = wave_total_dpp(z);
   gamma = g; zeta = z;
-  if (s.done) return true;
+  if (s.done || s.stop_model) return true;
   const double g0 = (k == 0) ? g : s.gamma0;
   if (!(g > 0.0)) return true;
   return (k >= min_iters && g <= tol2 * g0);
@@ -1499,7 +1511,8 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
            double* __restrict__ x, double* __restrict__ r, double* __restrict__ p, double* __restrict__ s,
            double* __restrict__ z, double* __restrict__ vtil, double* __restrict__ partV, int nblkV,
            PcgState* __restrict__ st, long long* __restrict__ host_flag, long long flag_base,
-           const double* __restrict__ verdict, double* __restrict__ rc, double* __restrict__ vx) {
+           const double* __restrict__ verdict, double* __restrict__ rc, double* __restrict__ vx,
+           double model_tol, int model_min_iters) {
   constexpr int NB = CM::NB, NH = CM::NH;
   // LDS image of the workgroup's cameras: Hccd | Minv | z p s r x | part6[NPART] | cs
   __shared__ double l_h[NH * VC], l_mi[NH * VC], l_v[5][NB * VC], l_p6[NPART][NB * VC], l_cs[CS * VC];
@@ -1645,6 +1658,11 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
       o.gamma_prev = gamma; o.alpha_prev = alpha;
       o.gamma0 = (k == 0) ? gamma : sin.gamma0;
       o.iters = k + 1;
+      // model test (Nash & Sofer): this iteration lowered q by 1/2 alpha gamma; stop when (k + 1) times that is no more
+      // than model_tol of the whole decrease so far
+      const double dq = 0.5 * alpha * gamma;
+      o.q_tot = ((k == 0) ? 0.0 : sin.q_tot) + dq;
+      o.stop_model = (model_tol > 0.0 && k + 1 >= model_min_iters && (double)(k + 1) * dq <= model_tol * o.q_tot) ? 1 : 0;
       *sout = o;
     }
   }

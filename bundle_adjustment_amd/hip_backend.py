@@ -32,7 +32,8 @@ class BAOptions(C.Structure):
                 ("xtol", C.c_double), ("gtol", C.c_double), ("initial_lambda", C.c_double), ("pcg_tol", C.c_double),
                 ("pcg_max_iters", C.c_int32), ("pcg_min_iters", C.c_int32), ("preconditioner", C.c_int32),
                 ("jacobian_precision", C.c_int32), ("reserved0", C.c_int32), ("profile", C.c_int32),
-                ("verbose", C.c_int32), ("small_solver", C.c_int32)]
+                ("verbose", C.c_int32), ("small_solver", C.c_int32), ("pcg_model_tol", C.c_double),
+                ("pcg_model_min_iters", C.c_int32), ("reserved1", C.c_int32)]
 
 
 class BASummary(C.Structure):

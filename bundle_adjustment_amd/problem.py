@@ -212,58 +212,30 @@ def extract_shard(problem: BAProblem, p_begin: int, p_end: int):
 
 
 class WindowCache:
-    """What ``BundleAdjuster.run`` keeps between consecutive calls so that it does not re-walk (and the solver does not
-    re-sort and re-upload) what did not change.  The reference calls ``run`` after every new keyframe
-    (``src/pipeline.py:99``) and once more for the final global BA (``src/main.py:83-86``); between two calls only the
-    newest keyframes' observation lists grow (``src/pipeline.py:294-308`` appends), landmarks are only ever added, and
-    poses / positions change.
+    """What ``BundleAdjuster.run`` keeps between consecutive calls so that an UNCHANGED window is not walked, re-sorted and
+    re-uploaded again.  The reference calls ``run`` after every new keyframe (``src/pipeline.py:99``) and once more for the
+    final global BA (``src/main.py:83-86``).
 
-    Two levels, both validated on every use (never trusted blindly):
-    * the whole window: same keyframe objects, the same observation-list objects with the same lengths, and every
-      landmark the cached window lists still in ``gmap.map_points`` -> the observation structure (camera index,
-      landmark index, pixels, sorted landmark ids) is reused as it stands; only poses and positions are read again.
-      The caller may then keep the solver's uploaded problem and send parameters only.
-    * one keyframe (windows of up to ``PER_KF_LIMIT`` keyframes): its rows ``(landmark id, pixel)`` with the
-      last-pixel-wins rule applied, reused while its list object and length are unchanged; a sliding window then walks
-      only the keyframe that entered.
+    One level, validated on every use (never trusted blindly): the whole window -- same keyframe objects, the same
+    observation-list objects with the same lengths, and every landmark the cached window lists still in
+    ``gmap.map_points`` -> the observation structure (camera index, landmark index, pixels, sorted landmark ids) is reused
+    as it stands; only poses and positions are read again, and the caller may keep the solver's uploaded problem and send
+    parameters only (a repeated run on the same window, e.g. the global BA after the last sliding-window one: 188 ms -> 10 ms
+    at 1000 keyframes / 1 M observations).  A window that moved is walked afresh by the native walk (``csrc/mapwalk.c``,
+    ~0.1 us per observation).  (Round 2 also cached the rows of single keyframes, so that a sliding window walked only the
+    keyframe that entered; measured on the reference's own 5-keyframe use that bought nothing -- the per-keyframe
+    validation and the numpy merge cost what the walk of four small keyframes costs -- and it is gone.)
 
     Assumption, stated: observation lists are append-only (what the reference does); an element replaced in place
     without changing the length is not noticed.  The cache holds references to the list objects it has seen, so an
     ``id()`` can never be recycled behind its back.  ``BundleAdjuster(..., reuse_window=False)`` turns it off.
     """
-    PER_KF_LIMIT = 64
 
     def __init__(self):
-        self.window = None          # dict: kfs, lists, lens, n_have, all_present, cam_idx, pt_idx, uv, mp_ids, token
-        self.per_kf = {}            # kf_id -> (kf object, obs list object, len, mp ids per kept row, uv per kept row, all_present)
+        self.window = None          # dict: ids, kfs, lists, lens, n_have, all_present, cam_idx, pt_idx, uv, mp_ids, token
         self.tokens = 0
-        self.hits = dict(window=0, keyframe=0, walked=0)
+        self.hits = dict(window=0, walked=0)
 
-    # -- one keyframe ---------------------------------------------------------------------
-    def _rows_of(self, gmap, kf_id):
-        from . import _mapwalk
-        kf = gmap.keyframes[kf_id]
-        obs = kf.observations
-        ent = self.per_kf.get(kf_id)
-        if ent is not None and ent[0] is kf and ent[1] is obs and ent[2] == len(obs):
-            mp, uv, all_present = ent[3], ent[4], ent[5]
-            uniq = ent[6]
-            if _mapwalk.count_present(gmap.map_points, uniq) == uniq.shape[0] and (all_present or ent[7] == len(gmap.map_points)):
-                self.hits["keyframe"] += 1
-                return mp, uv
-        n = len(obs)
-        cam_idx = np.empty(max(n, 1), dtype=np.int32)
-        first = np.empty(max(n, 1), dtype=np.int64)
-        uv = np.empty((max(n, 1), 2), dtype=np.float64)
-        distinct = np.empty(max(n, 1), dtype=np.int64)
-        nobs, npts = _mapwalk.walk_window(gmap.keyframes, gmap.map_points, [kf_id], cam_idx, first, uv, distinct) if n else (0, 0)
-        mp = distinct[:npts][first[:nobs]].copy()
-        uv = uv[:nobs].copy()
-        self.per_kf[kf_id] = (kf, obs, n, mp, uv, nobs == n, distinct[:npts].copy(), len(gmap.map_points))
-        self.hits["walked"] += 1
-        return mp, uv
-
-    # -- the window -----------------------------------------------------------------------
     def flatten(self, gmap, local_kf_ids, camera_matrix):
         """-> (BAProblem or None, sorted landmark ids as int64 array, structure token).  The token changes whenever the
         observation structure (indices, pixels) differs from the previous call's; equal tokens = same structure."""
@@ -277,51 +249,20 @@ class WindowCache:
                  and all(a is b for a, b in zip(w["kfs"], kfs)) and all(a is b for a, b in zip(w["lists"], lists))
                  and w["lens"] == lens and (w["all_present"] or w["n_have"] == len(have))
                  and _mapwalk.count_present(have, w["mp_ids"]) == w["mp_ids"].shape[0])
-        if reuse:
-            self.hits["window"] += 1
-        else:
-            cap = sum(lens)
-            if cap == 0:
+        if not reuse:
+            prob, ids_list = flatten_map_window(gmap, local_kf_ids, camera_matrix)
+            self.hits["walked"] += len(kfs)
+            if prob is None:
                 self.window = None
                 return None, np.empty(0, dtype=np.int64), -1
-            if len(kfs) <= self.PER_KF_LIMIT:
-                rows = [self._rows_of(gmap, k) for k in local_kf_ids]
-                for k in [k for k in self.per_kf if k not in local_kf_ids]:       # the keyframe that left the window
-                    del self.per_kf[k]
-                mp_all = np.concatenate([r[0] for r in rows])
-                if mp_all.shape[0] == 0:
-                    self.window = None
-                    return None, np.empty(0, dtype=np.int64), -1
-                cam_idx = np.repeat(np.arange(len(rows), dtype=np.int32), [r[0].shape[0] for r in rows])
-                uv = np.concatenate([r[1] for r in rows])
-                mp_ids, pt_idx = np.unique(mp_all, return_inverse=True)          # landmark ids ascending (:210 sorted(...))
-                pt_idx = pt_idx.astype(np.int32)
-                nobs = mp_all.shape[0]
-            else:
-                cam_idx = np.empty(cap, dtype=np.int32)
-                first_seen = np.empty(cap, dtype=np.int64)
-                uv = np.empty((cap, 2), dtype=np.float64)
-                distinct = np.empty(cap, dtype=np.int64)
-                nobs, npts = _mapwalk.walk_window(keyframes, have, list(local_kf_ids), cam_idx, first_seen, uv, distinct)
-                self.hits["walked"] += len(kfs)
-                if nobs == 0:
-                    self.window = None
-                    return None, np.empty(0, dtype=np.int64), -1
-                distinct = distinct[:npts]
-                order = np.argsort(distinct, kind="stable")
-                rank = np.empty(npts, dtype=np.int32)
-                rank[order] = np.arange(npts, dtype=np.int32)
-                mp_ids = distinct[order]
-                cam_idx, pt_idx, uv = cam_idx[:nobs].copy(), rank[first_seen[:nobs]], uv[:nobs].copy()
             self.tokens += 1
-            w = self.window = dict(ids=list(local_kf_ids), kfs=kfs, lists=lists, lens=lens, n_have=len(have),
-                                   all_present=(nobs == sum(lens)), cam_idx=cam_idx, pt_idx=pt_idx, uv=uv, mp_ids=mp_ids,
-                                   token=self.tokens)
+            self.window = dict(ids=list(local_kf_ids), kfs=kfs, lists=lists, lens=lens, n_have=len(have),
+                               all_present=(prob.n_obs == sum(lens)), cam_idx=prob.cam_idx, pt_idx=prob.pt_idx, uv=prob.uv,
+                               mp_ids=np.asarray(ids_list, dtype=np.int64), token=self.tokens)
+            return prob, self.window["mp_ids"], self.tokens
+        self.hits["window"] += 1
         mp_ids = w["mp_ids"]
         pts = np.empty((mp_ids.shape[0], 3), dtype=np.float64)
         _mapwalk.gather_positions(have, mp_ids, pts)
         cams, K4 = _window_cameras(gmap, local_kf_ids, camera_matrix)
-        prob = BAProblem(cams, pts, w["cam_idx"], w["pt_idx"], w["uv"], K4, fixed_cam=0)
-        if not reuse:
-            prob.validate()
-        return prob, mp_ids, w["token"]
+        return BAProblem(cams, pts, w["cam_idx"], w["pt_idx"], w["uv"], K4, fixed_cam=0), mp_ids, w["token"]

@@ -464,10 +464,12 @@ def two_level_apply(Minv, Einv, fixed_cam=-1):
     return apply
 
 
-def pcg(op, rhs, Minv, tol, max_iters, min_iters=0):
+def pcg(op, rhs, Minv, tol, max_iters, min_iters=0, model_tol=0.0, model_min_iters=5):
     """Preconditioned CG on S x = rhs with block-Jacobi Minv (Nc,6,6), or any callable r -> M^-1 r.
-    Stops when sqrt(rz / rz0) <= tol (after min_iters) or at max_iters.
-    Returns x (Nc,6), iterations, final residual vector."""
+    Stops when sqrt(rz / rz0) <= tol (after min_iters), at max_iters, or -- model_tol > 0 -- by Nash & Sofer's
+    truncated-Newton test on the quadratic model q(x) = 1/2 x^T S x - rhs^T x that CG minimises: iteration i lowers q by
+    1/2 alpha_i (r.z)_{i-1}; stop after iteration i >= model_min_iters when i times that is <= model_tol of the whole decrease
+    (the device: ba_options.pcg_model_tol, k_pcg_step).  Returns x (Nc,6), iterations, final residual vector."""
     if not callable(Minv):
         blocks = Minv
         Minv = lambda r_: np.einsum('cij,cj->ci', blocks, r_)          # noqa: E731
@@ -478,6 +480,7 @@ def pcg(op, rhs, Minv, tol, max_iters, min_iters=0):
     rz = float((r * z).sum())
     rz0 = rz
     it = 0
+    q_tot = 0.0
     if rz0 <= 0:
         return x, 0, r
     while it < max_iters:
@@ -491,7 +494,12 @@ def pcg(op, rhs, Minv, tol, max_iters, min_iters=0):
         z = Minv(r)
         rz_new = float((r * z).sum())
         it += 1
+        dq = 0.5 * alpha * rz
+        q_tot += dq
         if it >= min_iters and rz_new <= tol * tol * rz0:
+            rz = rz_new
+            break
+        if model_tol > 0 and it >= model_min_iters and it * dq <= model_tol * q_tot:
             rz = rz_new
             break
         beta = rz_new / rz
@@ -502,7 +510,8 @@ def pcg(op, rhs, Minv, tol, max_iters, min_iters=0):
 
 def lm_solve(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam=-1, loss='linear',
              max_iters=50, ftol=1e-10, xtol=1e-10, gtol=1e-10, lam0=1e-4,
-             pcg_tol=1e-1, pcg_max_iters=200, precond='schur_jacobi', verbose=False, linear_solver='pcg', model='pinhole'):
+             pcg_tol=1e-1, pcg_max_iters=200, precond='schur_jacobi', verbose=False, linear_solver='pcg', model='pinhole',
+             pcg_model_tol=0.0, pcg_model_min_iters=5):
     """CPU mirror of the device LM / Schur / PCG loop (same formulas, same update
     rules, same stopping tests) -- see ba_solve in bundle_adjustment_amd/csrc/ba_hip.hip.
     linear_solver='dense' solves the explicit reduced system (schur_dense) exactly instead, as the
@@ -548,7 +557,7 @@ def lm_solve(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam=-1, loss='linear',
             S_, g_, _, _ = schur_dense(ne, cam_idx, pt_idx, lam, fixed_cam)
             dc, k, rfin = np.linalg.solve(S_, g_).reshape(-1, nb), 0, np.zeros_like(rhs)
         else:
-            dc, k, rfin = pcg(op, rhs, Minv, pcg_tol, pcg_max_iters)
+            dc, k, rfin = pcg(op, rhs, Minv, pcg_tol, pcg_max_iters, model_tol=pcg_model_tol, model_min_iters=pcg_model_min_iters)
         pcg_total += k
         dp = op.back_substitute(dc)
         # model decrease of the damped, inexactly solved system (LM section)

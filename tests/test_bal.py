@@ -153,7 +153,7 @@ def test_oracle_bal_lm_dense_and_pcg_agree():
     p = _perturbed(read_bal(TINY), 3)
     kw = dict(fixed_cam=-1, loss="huber", max_iters=6, ftol=0.0, xtol=0.0, gtol=0.0, model="bal", precond="jacobi")
     a = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, None, linear_solver="dense", **kw)
-    b = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, None, pcg_tol=1e-13, pcg_max_iters=5000, **kw)
+    b = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, None, pcg_tol=1e-13, pcg_max_iters=5000, pcg_model_tol=0.0, **kw)
     assert a["cost"] < 0.1 * a["cost0"]
     for ha, hb in zip(a["history"], b["history"]):
         assert abs(ha["cost_new"] - hb["cost_new"]) <= 1e-8 * hb["cost_new"]

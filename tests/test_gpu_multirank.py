@@ -166,7 +166,7 @@ if mode == "empty":
 else:
     p = make_config("C3", seed=0)
     b, e = shard_by_landmark(p, world)[rank]
-    kw = dict(loss="huber", max_iters=4, ftol=0.0, xtol=0.0, gtol=1e-300, pcg_tol=1e-10, pcg_max_iters=300)
+    kw = dict(loss="huber", max_iters=4, ftol=0.0, xtol=0.0, gtol=1e-300, pcg_tol=1e-10, pcg_max_iters=300, pcg_model_tol=0.0)
 sub, _ = extract_shard(p, b, e)
 s = hip_backend.Solver(0)
 uid = [hip_backend.comm_unique_id() if rank == 0 else None]
@@ -228,7 +228,7 @@ def test_c3_sized_shard_pair_reproduces_the_single_rank_iterates(tmp_path):
     p = make_config("C3", seed=0)
     with hip_backend.Solver(0) as s:
         s.set_problem(p)
-        ref = s.solve(loss="huber", max_iters=4, ftol=0.0, xtol=0.0, gtol=1e-300, pcg_tol=1e-10, pcg_max_iters=300)
+        ref = s.solve(loss="huber", max_iters=4, ftol=0.0, xtol=0.0, gtol=1e-300, pcg_tol=1e-10, pcg_max_iters=300, pcg_model_tol=0.0)
         cams_ref, pts_ref = s.get_params()
     for key in ("iterations", "accepted", "initial_sse", "final_sse", "final_cost"):
         assert outs[0][key] == outs[1][key], key

@@ -369,3 +369,22 @@ def test_lanes_per_point_variants(solver, monkeypatch, lanes):
     ref = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, 0, "huber", max_iters=12, ftol=1e-12, xtol=1e-12,
                      gtol=0.0, pcg_tol=1e-2)
     assert abs(out["final_cost"] - ref["cost"]) <= 1e-8 * ref["cost"]
+
+
+def test_pcg_model_test_follows_the_oracle(solver):
+    """ba_options.pcg_model_tol (Nash & Sofer's truncated-Newton test on the quadratic model, opt-in): on a chain problem at
+    small damping the PCG loop is ended by the model test well before the residual test or the iteration cap; the device
+    and the oracle's mirror stop at the same iteration counts and walk the same LM trajectory."""
+    p = make_bal_like(n_cams=120, n_pts=9000, n_obs_target=40000, seed=3)
+    kw = dict(max_iters=7, ftol=0.0, xtol=0.0, gtol=0.0, pcg_tol=1e-3, pcg_max_iters=400)
+    ref = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, fixed_cam=0, loss="huber", lam0=1e-7, pcg_model_tol=0.5, **kw)
+    full = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, fixed_cam=0, loss="huber", lam0=1e-7, pcg_model_tol=0.0, **kw)
+    assert ref["pcg_iters"] < 0.6 * full["pcg_iters"]                   # the test does cut the inner solves short
+    solver.set_problem(p)
+    out = solver.solve(loss="huber", initial_lambda=1e-7, pcg_model_tol=0.5, pcg_min_iters=0, **kw)
+    tr = solver.trace()
+    assert out["iterations"] == len(ref["history"])
+    for t, h in zip(tr, ref["history"]):
+        assert abs(t["pcg_iterations"] - h["pcg"]) <= max(1, 0.1 * h["pcg"]), (t, h)
+        assert abs(t["cost_trial"] - h["cost_new"]) <= 1e-6 * h["cost_new"], (t, h)
+    assert abs(out["final_cost"] - ref["cost"]) <= 1e-6 * ref["cost"]

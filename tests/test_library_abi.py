@@ -29,7 +29,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_struct_layouts_match_header():
     import ctypes as C
     from bundle_adjustment_amd import hip_backend as hb
-    assert C.sizeof(hb.BAOptions) == 2 * 4 + 6 * 8 + 8 * 4
+    assert C.sizeof(hb.BAOptions) == 2 * 4 + 6 * 8 + 8 * 4 + 8 + 2 * 4
     assert C.sizeof(hb.BASummary) == 4 * 4 + 9 * 8
     assert C.sizeof(hb.BAProfile) == 2 * (16 * 4 + 16 * 8)
     hdr = open(os.path.join(ROOT, "include", "ba_hip.h")).read()

@@ -76,7 +76,7 @@ def test_dense_and_matrix_free_reduced_systems_give_the_same_lm_trajectory():
     p = make_problem(4, 60, 3, seed=1, outlier_frac=0.05)
     kw = dict(fixed_cam=0, loss="huber", max_iters=5, ftol=0.0, xtol=0.0, gtol=0.0)
     a = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, linear_solver="dense", **kw)
-    b = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, pcg_tol=1e-13, pcg_max_iters=2000, **kw)
+    b = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, pcg_tol=1e-13, pcg_max_iters=2000, pcg_model_tol=0.0, **kw)
     assert a["pcg_iters"] == 0 and b["pcg_iters"] > 0
     for ha, hb in zip(a["history"], b["history"]):
         assert abs(ha["cost_new"] - hb["cost_new"]) <= 1e-10 * hb["cost_new"]

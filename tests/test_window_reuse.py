@@ -82,11 +82,11 @@ def test_cached_window_equals_a_fresh_walk_on_a_growing_map():
             kf.observations.append((mp0, len(kf.keypoints) - 1))
         _grow(gmap, rng)
     assert len(set(tokens)) == len(tokens)                      # every growth step changed the structure
-    assert cache.hits["keyframe"] > 0 and cache.hits["walked"] < 7 * w      # the sliding window re-walked only what changed
+    assert cache.hits["window"] >= 2 and cache.hits["walked"] >= 7 * w - w    # a window that moved is walked afresh, an unchanged one is not
 
 
-def test_large_windows_take_the_one_shot_walk_and_reuse_the_whole_window():
-    p = make_problem(WindowCache.PER_KF_LIMIT + 6, 400, 3, seed=4)
+def test_large_windows_reuse_the_whole_window():
+    p = make_problem(70, 400, 3, seed=4)
     gmap = problem_to_map(p)
     K = np.array([[p.K4[0], 0, p.K4[2]], [0, p.K4[1], p.K4[3]], [0, 0, 1.0]])
     local = sorted(gmap.keyframes)[:-1]
@@ -94,7 +94,7 @@ def test_large_windows_take_the_one_shot_walk_and_reuse_the_whole_window():
     a, ids_a, ta = cache.flatten(gmap, local, K)
     b, ids_b, tb = cache.flatten(gmap, local, K)
     ref, ref_ids = flatten_map_window(gmap, local, K)
-    assert ta == tb and cache.hits["window"] == 1 and not cache.per_kf
+    assert ta == tb and cache.hits["window"] == 1
     assert ids_a.tolist() == ref_ids
     _same(a, ref)
     _same(b, ref)

@@ -25,7 +25,7 @@ for cfg in (sys.argv[1:] or ["C2", "C3"]):
         s.set_problem(p)
         # two stages: the descent of the GPU test (PCG tolerance 1e-2), then a polish with a tight inner solve
         out = s.solve(loss="huber", max_iters=150, ftol=1e-14, xtol=1e-14, gtol=0.0, pcg_tol=1e-2, pcg_max_iters=500)
-        pol = s.solve(loss="huber", max_iters=60, ftol=1e-16, xtol=1e-16, gtol=0.0, pcg_tol=1e-6, pcg_max_iters=2000)
+        pol = s.solve(loss="huber", max_iters=60, ftol=1e-16, xtol=1e-16, gtol=0.0, pcg_tol=1e-6, pcg_max_iters=2000, pcg_model_tol=0.0)
         cams, pts = s.get_params()
     adj = [i for i in range(p.n_cams) if i != p.fixed_cam]
     x = np.concatenate([cams[adj, :3].ravel(), cams[adj, 3:].ravel(), pts.ravel()])

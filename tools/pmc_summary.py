@@ -39,14 +39,14 @@ def med(vals):
 
 def main():
     f, w, tag = agg(sys.argv[1], "FETCH_SIZE"), agg(sys.argv[2], "WRITE_SIZE"), sys.argv[3]
-    rows, traffic = [], {}
+    rows, traffic, launches = [], {}, {}
     for k in sorted(f):
         fk, wk = med(f[k]), med(w.get(k, [0.0]))
         hbm = (2 * fk + wk) * 1024
         rows.append((k, len(f[k]), fk, wk, hbm))
         for pat, slot in SLOT:
-            if pat.search(k):
-                traffic[slot] = max(traffic.get(slot, 0), round(hbm))       # (several instantiations of a slot: the working one moves the most)
+            if pat.search(k) and len(f[k]) > launches.get(slot, 0):        # several instantiations of a slot: the one the loop launches most
+                traffic[slot], launches[slot] = round(hbm), len(f[k])
     with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_hbm_per_kernel.csv"), "w") as out:
         out.write("kernel,launches,FETCH_SIZE_KB_median,WRITE_SIZE_KB_median,hbm_bytes_per_launch(2*FETCH+WRITE)\n")
         for k, n, fk, wk, hbm in rows:

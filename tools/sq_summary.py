@@ -21,7 +21,7 @@ print("C3 (1000 cams / 100k pts / 1M obs); mean over working launches (>= half t
 for path in sys.argv[1:]:
     d = table(path)
     names = sorted({c for k in d for c in d[k]})
-    print(f"{'kernel':44s} " + " ".join(f"{n:>20s}" for n in names) + "  launches")
+    print(f"{'kernel':58s} " + " ".join(f"{n:>20s}" for n in names) + "  launches")
     for k in sorted(d):
         if not k.startswith("k_"):
             continue
@@ -33,5 +33,5 @@ for path in sys.argv[1:]:
             w = [x for x in v if x >= 0.5 * mx] if mx > 0 else v
             row.append(sum(w) / max(len(w), 1))
             n_l = max(n_l, len(v))
-        print(f"{k[:44]:44s} " + " ".join(f"{x:20.4g}" for x in row) + f"  {n_l}")
+        print(f"{k[:58]:58s} " + " ".join(f"{x:20.4g}" for x in row) + f"  {n_l}")
     print()

@@ -34,7 +34,12 @@ for k_, v in times.items():
 # ---- the reference's actual use: run() after every new keyframe (src/pipeline.py:99), window sliding by one ----
 from bundle_adjustment_amd.map_structures import Map
 extra = 25
-pl = make_problem(n_cams + extra, n_pts * 3, k, seed=1)
+# a map like the reference's pipeline grows: landmarks are triangulated from two consecutive keyframes and tracked over the
+# next few (src/pipeline.py:248-308), so a 5-keyframe window sees most of its landmarks from several cameras
+# (make_problem's uniformly random visibility would leave most of a window's landmarks with ONE observation inside it:
+# free depths, dozens of LM iterations -- not what a sliding window is)
+from bundle_adjustment_amd.synthetic import make_bal_like
+pl = make_bal_like(n_cams=n_cams + extra, n_pts=n_pts * 6, n_obs_target=n_pts * 6 * k, seed=1)
 for reuse in (True, False):
     full = problem_to_map(pl, extra_newest=False)       # a fresh (unoptimised) map for each mode
     gv = Map()
@@ -44,6 +49,18 @@ for reuse in (True, False):
         gv.add_keyframe(full.keyframes[i])
     bs = BundleAdjuster(K, window_size=n_cams, reuse_window=reuse)
     lat = []
+    # stage timers around the solver calls of run() (the rest of a call is host glue: window walk / cache, write-back, prints)
+    sv = bs._get_solver()
+    stage = {"set_problem": [], "set_params": [], "solve": [], "get_params": [], "get_rotations": []}
+    iters = []
+    def timed(name):
+        fn = getattr(sv, name)
+        def w(*a, **k):
+            t0 = time.perf_counter(); r = fn(*a, **k); stage[name].append(time.perf_counter() - t0)
+            if name == "solve": iters.append(r["iterations"])
+            return r
+        setattr(sv, name, w)
+    for nm in stage: timed(nm)
     for i in ids[n_cams + 1:]:
         buf = io.StringIO()
         t = time.perf_counter()
@@ -54,4 +71,6 @@ for reuse in (True, False):
     lat = np.array(lat[3:]) * 1e3
     extra_note = f", cache hits {bs._window.hits}" if reuse else ""
     print(f"  sliding window, reuse_window={reuse}: run() median {np.median(lat):7.3f} ms   min {lat.min():7.3f}{extra_note}")
+    print("     inside run(): " + ", ".join(f"{nm} {1e3 * np.median(v):.3f} ms x{len(v)}" for nm, v in stage.items() if v)
+          + f"; LM iterations per solve: median {np.median(iters):.0f}, max {max(iters)}")
     bs.close()
