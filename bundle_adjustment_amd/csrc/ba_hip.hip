@@ -125,11 +125,18 @@ struct DBuf {
   hipError_t alloc(size_t count) {
     if (p && n >= count && count > 0) return hipSuccess;
     release();
-    n = count;
     if (count == 0) return hipSuccess;
+    // small buffers get headroom: consecutive sliding windows differ a little in size, and a hipFree + hipMalloc per
+    // buffer on every growth costs more than the solve of such a window
+    if (count < ((size_t)1 << 20)) count += count / 2 + 64;
+    n = count;
     hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
     if (e != hipSuccess) { p = nullptr; n = 0; return e; }
-    return hipMemset(p, 0, count * sizeof(T));
+    // hipMemset of device memory may return before the fill has run (it is queued on the null stream, which the handle's
+    // non-blocking stream does not wait for): drain it, or the zeros can land on top of the first upload.  Allocations are rare.
+    e = hipMemset(p, 0, count * sizeof(T));
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(nullptr);
   }
   void release() {
     if (p) (void)hipFree(p);
@@ -879,10 +886,11 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   size_t up_used = 0;
   const size_t up_need = ((size_t)No * (4 * 4 + 16) + (size_t)Np * 12 + (size_t)Nc * 40 + win.size() * 8 + 4096) * 1;
   const bool staged = up_need <= ((size_t)4 << 20);
-  if (staged && h->h_up_cap < up_need) {
+  if (staged && h->h_up_cap < up_need) {       // grow-only, with headroom: consecutive windows differ a little in size
     if (h->h_up) { (void)hipHostFree(h->h_up); h->h_up = nullptr; h->h_up_cap = 0; }
-    HIPCHECK(hipHostMalloc((void**)&h->h_up, up_need, hipHostMallocDefault));
-    h->h_up_cap = up_need;
+    const size_t cap = std::min<size_t>((size_t)4 << 20, std::max<size_t>(2 * up_need, (size_t)256 << 10));
+    HIPCHECK(hipHostMalloc((void**)&h->h_up, cap, hipHostMallocDefault));
+    h->h_up_cap = cap;
   }
   auto upload = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
     if (bytes == 0) return hipSuccess;

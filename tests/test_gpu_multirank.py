@@ -294,3 +294,64 @@ def test_real_rccl_communicator_of_one_rank_runs_the_whole_multi_rank_loop(monke
         assert out[key] == ref[key], key
     assert np.array_equal(cams, cams_ref) and np.array_equal(pts, pts_ref) and np.array_equal(allpts, pts_ref)
     assert prof["allreduce"]["launches"] > 0 and prof_out["iterations"] == 2          # the collectives really ran
+
+
+BAL_WORKER = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+from bundle_adjustment_amd import hip_backend
+from bundle_adjustment_amd.problem import BAProblem, extract_shard, shard_by_landmark
+from bundle_adjustment_amd.synthetic import make_bal_problem
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group(backend="gloo")
+bal = make_bal_problem(60, 5000, 22000, seed=5)
+p = BAProblem(np.ascontiguousarray(bal.cams[:, :6]), bal.pts, bal.cam_idx, bal.pt_idx, bal.uv, np.array([1.0, 1.0, 0.0, 0.0]), 0)
+b, e = shard_by_landmark(p, world)[rank]
+sub, _ = extract_shard(p, b, e)
+s = hip_backend.Solver(0)
+uid = [hip_backend.comm_unique_id() if rank == 0 else None]
+dist.broadcast_object_list(uid, src=0)
+s.comm_init(rank, world, uid[0])
+s.set_problem(sub)
+intr = np.ascontiguousarray(bal.cams[:, 6:9]).copy()
+out = s.solve_bal_resident(intr, loss="huber", max_iters=12, ftol=0.0, xtol=0.0, gtol=0.0, pcg_tol=1e-3, pcg_max_iters=400)
+cams, pts = s.get_params()
+np.save(os.path.join(%(out)r, f"cams_{rank}.npy"), np.concatenate([cams, intr], axis=1))
+np.save(os.path.join(%(out)r, f"pts_{rank}.npy"), pts)
+json.dump(out, open(os.path.join(%(out)r, f"out_{rank}.json"), "w"))
+s.close()
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_bal_camera_match_single_rank(tmp_path):
+    """The BAL 9-parameter camera shards by landmark like the pinhole (fold / all-reduce sizes follow the camera model: 9 and
+    45 + 9 sums per camera): two ranks on one GPU (shm transport) against the single-rank ba_solve_bal -- same global costs on
+    both ranks, cameras (f, k1, k2 included) bitwise identical across ranks, and the single-rank iterates to round-off."""
+    from bundle_adjustment_amd import hip_backend
+    from bundle_adjustment_amd.synthetic import make_bal_problem
+    script = tmp_path / "worker_bal.py"
+    script.write_text(BAL_WORKER % dict(root=ROOT, out=str(tmp_path)))
+    env = dict(os.environ, BA_COMM="shm")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", _free_port(), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    bal = make_bal_problem(60, 5000, 22000, seed=5)
+    with hip_backend.Solver(0) as s:
+        ref, cams_ref, pts_ref = s.solve_bal(bal, fixed_cam=0, loss="huber", max_iters=12, ftol=0.0, xtol=0.0, gtol=0.0, pcg_tol=1e-3,
+                                             pcg_max_iters=400)
+    outs = [json.load(open(tmp_path / f"out_{k}.json")) for k in range(2)]
+    for key in ("iterations", "accepted", "pcg_iterations", "initial_sse", "final_sse", "final_cost"):
+        assert outs[0][key] == outs[1][key], key
+    assert abs(outs[0]["initial_cost"] - ref["initial_cost"]) <= 1e-10 * ref["initial_cost"]
+    assert abs(outs[0]["final_cost"] - ref["final_cost"]) <= 1e-8 * ref["final_cost"]
+    assert outs[0]["final_cost"] < 0.05 * outs[0]["initial_cost"]
+    c0, c1 = np.load(tmp_path / "cams_0.npy"), np.load(tmp_path / "cams_1.npy")
+    assert np.array_equal(c0, c1) and c0.shape == (60, 9)
+    assert np.abs(c0 - cams_ref).max() <= 1e-6 * np.abs(cams_ref).max()
+    pts = np.concatenate([np.load(tmp_path / f"pts_{k}.npy") for k in range(2)])
+    assert pts.shape == pts_ref.shape and np.abs(pts - pts_ref).max() <= 1e-5 * np.abs(pts_ref).max()
