@@ -388,3 +388,24 @@ def test_pcg_model_test_follows_the_oracle(solver):
         assert abs(t["pcg_iterations"] - h["pcg"]) <= max(1, 0.1 * h["pcg"]), (t, h)
         assert abs(t["cost_trial"] - h["cost_new"]) <= 1e-6 * h["cost_new"], (t, h)
     assert abs(out["final_cost"] - ref["cost"]) <= 1e-6 * ref["cost"]
+
+
+def test_camera_windows_that_do_not_fit_in_lds_follow_the_oracle(solver):
+    """1200 cameras with uniformly random visibility: the camera table (1200 x 144 bytes) exceeds the LDS budget and no
+    workgroup's camera window is narrow, so the point passes gather camera rows from L2 (ALL_LDS = false instantiations)
+    and the camera update runs as a launch of its own instead of riding along the back substitution.  Same LM trajectory
+    as the oracle, residuals <= 1e-9 px."""
+    p = make_problem(1200, 6000, 6, seed=31, outlier_frac=0.01)
+    solver.set_problem(p)
+    r, sse, _ = solver.residuals("huber")
+    assert np.abs(r - o.residuals(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4)).max() <= 1e-9
+    kw = dict(max_iters=5, ftol=0.0, xtol=0.0, gtol=0.0, pcg_tol=1e-2, pcg_max_iters=300)
+    ref = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, fixed_cam=0, loss="huber", **kw)
+    out = solver.solve(loss="huber", pcg_min_iters=0, **kw)
+    tr = solver.trace()
+    assert out["iterations"] == len(ref["history"]) == 5
+    for t, h in zip(tr, ref["history"]):
+        assert abs(t["pcg_iterations"] - h["pcg"]) <= max(1, 0.1 * h["pcg"]), (t, h)
+        assert abs(t["cost_trial"] - h["cost_new"]) <= 1e-7 * h["cost_new"], (t, h)
+        assert bool(t["accepted"]) == bool(h["rho"] > 0)
+    assert abs(out["final_cost"] - ref["cost"]) <= 1e-7 * ref["cost"]
