@@ -15,9 +15,9 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o r
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- python3 $ARGS > /dev/null 2> $OUT/write.err
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/sq1 -o run -- python3 $ARGS > /dev/null 2> $OUT/sq1.err
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq2 -o run -- python3 $ARGS > /dev/null 2> $OUT/sq2.err
-python3 bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err
 cp $OUT/trace/run_kernel_stats.csv profiles/${TAG}_kernel_stats.csv
 python3 tools/pmc_summary.py $OUT/fetch/run_counter_collection.csv $OUT/write/run_counter_collection.csv $TAG
+python3 bench.py --steps 20 --warmup 3 > $OUT/bench.json 2> $OUT/bench.err       # (reads the traffic.json just written)
 python3 tools/sq_summary.py $OUT/sq1/run_counter_collection.csv $OUT/sq2/run_counter_collection.csv > profiles/${TAG}_c3_sq_counters.txt
 cp $OUT/bench.json profiles/${TAG}_bench.json
 python3 tools/trace_summary.py profiles/${TAG}_kernel_stats.csv 16
