@@ -202,7 +202,8 @@ struct ba_handle {
   DBuf<long long> dev_seq;     // device word a riding k_scalars publishes the step's sequence number in (ba_kernels.hpp, "riders")
   DBuf<double> verdict;        // PCG verdict words {gamma, zeta, finished, -} x 2 iteration parities (point pass -> camera pass, vector kernel)
   int cam_segl = 64;           // lanes per (camera, partition) segment in the PCG camera pass (BA_CAM_SEGL, tuning)
-  int nblkP = 1, ppb = 1, nblkV = 1;
+  int nblkP = 1, ppb = 1, nblkV = 1;   // nblkV: camera-vector workgroups of the pinhole (VEC_CAMS cameras each)
+  int nblkVm[2] = {1, 1};              // ... per camera model (CM::VC cameras each)
   size_t lds_bytes_m[2] = {0, 0};   // dynamic LDS of the point passes (largest window that fits), per camera model (row strides differ)
   bool jac_f32 = false;        // PCG passes recompute the Jacobian blocks in fp32 (ba_options.jacobian_precision = 1)
   bool all_lds_m[2] = {true, true};  // every point-pass workgroup's camera window fits in LDS, per camera model
@@ -824,6 +825,8 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   h->Nc = Nc; h->Np = Np; h->Nobs = No; h->fixed = fixed_cam;
   memcpy(h->K4, K4, sizeof h->K4);
   h->nblkV = (Nc + VEC_CAMS - 1) / VEC_CAMS;
+  h->nblkVm[0] = (Nc + Pinhole::VC - 1) / Pinhole::VC; h->nblkVm[1] = (Nc + BalCam::VC - 1) / BalCam::VC;
+  const size_t nbv_max = (size_t)std::max(h->nblkVm[0], h->nblkVm[1]);
   // long tracks: one DPP row (16 lanes) per point in a launch of their own
   std::vector<int> long_pts;
   {   // long = more than max(8, 2 x median track length) observations (BA_LONG_TRACK overrides)
@@ -934,8 +937,8 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(h->part6.alloc(NBX * (size_t)NPART * Nc + 8));   // + the u.y word: one all-reduce carries both
   HIPCHECK(h->partE.alloc(NHX * (size_t)NPART * Nc));
   HIPCHECK(h->partA.alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partB.alloc(4 * (size_t)(h->nblkP + h->nblkL)));
-  HIPCHECK(h->partC.alloc(5 * (size_t)h->nblkV)); HIPCHECK(h->partV.alloc(4 * (size_t)h->nblkV));
-  HIPCHECK(h->partG[0].alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partG[1].alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partGc.alloc(h->nblkV));
+  HIPCHECK(h->partC.alloc(5 * nbv_max)); HIPCHECK(h->partV.alloc(4 * nbv_max));
+  HIPCHECK(h->partG[0].alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partG[1].alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partGc.alloc(nbv_max));
   DBuf<double>* v6[] = {&h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin, &h->vx};
   for (auto b : v6) HIPCHECK(b->alloc(NBX * (size_t)Nc));
   HIPCHECK(h->scal.alloc(64));
@@ -987,6 +990,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
 
 // block sizes of the running camera model
 static int nb_of(const ba_handle* h) { return h->model ? BalCam::NB : Pinhole::NB; }
+static int nbv(const ba_handle* h) { return h->nblkVm[h->model]; }      // camera-vector workgroups of the active model
 static int nh_of(const ba_handle* h) { return h->model ? BalCam::NH : Pinhole::NH; }
 static int nl_of(const ba_handle* h) { return h->model ? BalCam::NL : Pinhole::NL; }
 static size_t lds_of(const ba_handle* h) { return h->lds_bytes_m[h->model]; }
@@ -1089,10 +1093,10 @@ static ScalarsArgs scalars_args(ba_handle* h, bool with_step, int k, double tol2
   ScalarsArgs a;
   a.partR = h->partR.p; a.nR = NPART * h->Nc;
   a.partB = h->partB.p; a.nB = (with_step && h->Np > 0) ? h->nblkP + h->nblkL : 0;
-  a.partC = h->partC.p; a.nC = with_step ? h->nblkV : 0;
+  a.partC = h->partC.p; a.nC = with_step ? nbv(h) : 0;
   a.kit = k;
   a.st = with_step ? (const PcgState*)h->st.p : (const PcgState*)nullptr;
-  a.partV = h->partV.p; a.nblkV = h->nblkV;
+  a.partV = h->partV.p; a.nblkV = nbv(h);
   a.tol2 = tol2; a.min_iters = min_iters;
   a.scal = h->scal.p; a.scal_host = direct ? h->d_scal_host : (double*)nullptr;
   a.host_flag = direct ? h->d_flags + 2 : (long long*)nullptr; a.seq = seq;
@@ -1262,9 +1266,9 @@ static void launch_pt_schur_t(ba_handle* h, bool robust, int mode, int k, double
   const int ride = (mode == 1) ? cu.n_blocks : 0;      // the camera update as extra workgroups of the back substitution
 #define PS_HEAD h->camA[w].p, h->ptab[w].p, h->pt_off.p, (robust ? h->p_camf[h->pb].p : h->p_cam.p), h->p_w[h->pb].p,                 \
                 h->Hppinv[h->pb].p, h->blk_win.p
-#define PS_TAIL h->K4[0], h->K4[1], h->fixed, h->partA.p, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->y0[h->pb].p,     \
+#define PS_TAIL h->K4[0], h->K4[1], h->fixed, h->partA.p, k, h->st.p, h->partV.p, nbv(h), tol2, min_iters, h->y0[h->pb].p,     \
                 h->Hpp[h->pb].p, h->bp[h->pb].p, h->ptab[1 - w].p, h->partB.p, flag, flag_base, h->verdict.p,                      \
-                (const double*)h->partG[h->pb].p, h->nblkP + h->nblkL, (const double*)h->partGc.p, h->nblkV, gmax_out, cu
+                (const double*)h->partG[h->pb].p, h->nblkP + h->nblkL, (const double*)h->partGc.p, nbv(h), gmax_out, cu
   const size_t lds = std::max(lds_of(h), ride ? CU_GROUPS * cam_update_lds_doubles<CM>() * sizeof(double) : (size_t)0) + (size_t)h->debug_lds_extra;
   long long* flag = (mode == 0 && flag_base > 0) ? h->d_flags : (long long*)nullptr;
   // data with long tracks: short and long tracks in one launch (workgroup 0 publishes the verdict)
@@ -1305,8 +1309,8 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
     // an empty landmark shard (multi-rank): no point pass, but the PCG probe's verdict is still owed
     if (mode == 0 && flag_base > 0) {
       Scope sc(h, BA_K_SCHUR_PT);
-      BA_LAUNCH(k_pcg_probe, dim3(1), dim3(64), 0, h->stream, k, h->st.p, h->partV.p, h->nblkV, tol2, min_iters, h->d_flags,
-                flag_base, h->verdict.p, (const double*)h->partGc.p, h->nblkV, gmax_out);
+      BA_LAUNCH(k_pcg_probe, dim3(1), dim3(64), 0, h->stream, k, h->st.p, h->partV.p, nbv(h), tol2, min_iters, h->d_flags,
+                flag_base, h->verdict.p, (const double*)h->partGc.p, nbv(h), gmax_out);
     }
     return;
   }
@@ -1349,8 +1353,8 @@ static void launch_pcg_setup(ba_handle* h, double lambda, bool schur_diag, bool 
                 h->z.p, h->camA[h->cur].p, h->partV.p, h->st.p, h->partGc.p, (h->two_level ? h->coarse_rc.p : (double*)nullptr), h->vx.p
 #define CALL_T(CM)                                                                                               \
   do {                                                                                                           \
-    if (finalize) BA_LAUNCH((k_pcg_setup<CM, true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);    \
-    else          BA_LAUNCH((k_pcg_setup<CM, false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);   \
+    if (finalize) BA_LAUNCH((k_pcg_setup<CM, true>), dim3(nbv(h)), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);    \
+    else          BA_LAUNCH((k_pcg_setup<CM, false>), dim3(nbv(h)), dim3(VEC_BLOCK), 0, h->stream, SU_ARGS);   \
   } while (0)
   BA_BY_MODEL(CALL_T);
 #undef CALL_T
@@ -1470,7 +1474,7 @@ static void coarse_build(ba_handle* h) {
             h->coarseEinv.p);
   BA_LAUNCH(k_pcg_coarse, dim3(h->n_agg), dim3(VEC_BLOCK), 0, h->stream, -1, (const double*)h->coarseEinv.p,
             (const double*)h->coarse_rc.p, h->n_agg, (const double*)h->Hccd.p, (const double*)h->cs[h->cur].p, h->Nc, h->fixed,
-            (const double*)h->r.p, h->z.p, h->camA[h->cur].p, h->partV.p, h->nblkV, (const double*)h->verdict.p, 0);
+            (const double*)h->r.p, h->z.p, h->camA[h->cur].p, h->partV.p, nbv(h), (const double*)h->verdict.p, 0);
 }
 
 // --------------------------------------------------------------------- K4 test hooks
@@ -1506,7 +1510,7 @@ extern "C" int ba_schur_apply(ba_handle* h, double lambda, const double* v, doub
     Scope sc(h, BA_K_MISC);
     BA_LAUNCH(k_vtil, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->vin.p, h->cs[h->cur].p, h->Nc,
                        h->fixed, h->camA[h->cur].p);
-    BA_LAUNCH(k_pcg_reset, dim3(1), dim3(64), 0, h->stream, h->st.p, h->partV.p, h->nblkV);
+    BA_LAUNCH(k_pcg_reset, dim3(1), dim3(64), 0, h->stream, h->st.p, h->partV.p, nbv(h));
   }
   launch_pt_schur(h, h->lin_robust, 0, 0, -1.0, 1 << 30);        // y = Hppinv W^T v into the point table
   launch_cam_schur(h, h->lin_robust, false, false, 0, 0.0, 0);
@@ -1823,7 +1827,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
         {
           Scope sc(h, BA_K_MISC);
           BA_LAUNCH(k_max_partials, dim3(1), dim3(64), 0, h->stream, (const double*)h->partG[h->pb].p,
-                    h->Np > 0 ? h->nblkP + h->nblkL : 0, (const double*)h->partGc.p, h->nblkV, h->scal.p + 18);
+                    h->Np > 0 ? h->nblkP + h->nblkL : 0, (const double*)h->partGc.p, nbv(h), h->scal.p + 18);
         }
         if (int rc = allreduce(h, h->scal.p + 18, 1, true)) return rc;
         Scope sc(h, BA_K_MISC);
@@ -1850,16 +1854,16 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       if (int rc = exchange_schur(h, false)) return rc;
       Scope sc(h, BA_K_PCG_UPDATE);
 #define STEP_ARGS kk, p6_ptr(h), NPART, (const double*)uy_ptr(h), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc, h->fixed, tol2,       \
-                  opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA[h->cur].p, h->partV.p, h->nblkV, h->st.p, \
+                  opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA[h->cur].p, h->partV.p, nbv(h), h->st.p, \
                   h->d_flags, base, (const double*)h->verdict.p
 #define STEP_TAIL h->vx.p, opts->pcg_model_tol, opts->pcg_model_min_iters
       if (h->two_level) {
         BA_LAUNCH((k_pcg_step<Pinhole, true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, h->coarse_rc.p, STEP_TAIL);
         BA_LAUNCH(k_pcg_coarse, dim3(h->n_agg), dim3(VEC_BLOCK), 0, h->stream, kk, (const double*)h->coarseEinv.p,
                   (const double*)h->coarse_rc.p, h->n_agg, (const double*)h->Hccd.p, (const double*)h->cs[h->cur].p, Nc, h->fixed,
-                  (const double*)h->r.p, h->z.p, h->camA[h->cur].p, h->partV.p, h->nblkV, (const double*)h->verdict.p, 1);
+                  (const double*)h->r.p, h->z.p, h->camA[h->cur].p, h->partV.p, nbv(h), (const double*)h->verdict.p, 1);
       } else if (h->model) {
-        BA_LAUNCH((k_pcg_step<BalCam, false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, (double*)nullptr, STEP_TAIL);
+        BA_LAUNCH((k_pcg_step<BalCam, false>), dim3(nbv(h)), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, (double*)nullptr, STEP_TAIL);
       } else {
         BA_LAUNCH((k_pcg_step<Pinhole, false>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, (double*)nullptr, STEP_TAIL);
       }
@@ -1900,11 +1904,11 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       cu.vtil = h->camA[h->cur].p; cu.camA_trial = h->camA[1 - h->cur].p; cu.partC = h->partC.p;
       cu.vx = h->vx.p;
       // (riding workgroups: a multiple of NPART, so that the point workgroups behind them keep their XCD = index mod NPART)
-      cu.n_cams = Nc; cu.fixed_cam = h->fixed; cu.n_blocks = (((h->nblkV + CU_GROUPS - 1) / CU_GROUPS + NPART - 1) / NPART) * NPART;
+      cu.n_cams = Nc; cu.fixed_cam = h->fixed; cu.n_blocks = (((nbv(h) + CU_GROUPS - 1) / CU_GROUPS + NPART - 1) / NPART) * NPART;
       const bool ride = (riders & 1) && all_lds_of(h) && h->Np > 0;
       if (!ride) {
         Scope sc(h, BA_K_MISC);
-        if (h->model) BA_LAUNCH(k_cam_update<BalCam>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, cu);
+        if (h->model) BA_LAUNCH(k_cam_update<BalCam>, dim3(nbv(h)), dim3(VEC_BLOCK), 0, h->stream, cu);
         else          BA_LAUNCH(k_cam_update<Pinhole>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, cu);
       }
       launch_pt_schur(h, robust, 1, 0, 0.0, 0, 0, nullptr, ride ? &cu : nullptr);
@@ -2047,7 +2051,7 @@ extern "C" int ba_time_kernel(ba_handle* h, int slot, int reps, double* mean_us)
   launch_lin_pt(h, h->cur, h->pb, robust, h->lin_fscale, 1e-4);
   h->linearized = true;
   if (int rc = damped_system(h, 1e-4, true)) return rc;
-  BA_LAUNCH(k_pcg_reset, dim3(1), dim3(64), 0, h->stream, h->st.p, h->partV.p, h->nblkV);
+  BA_LAUNCH(k_pcg_reset, dim3(1), dim3(64), 0, h->stream, h->st.p, h->partV.p, nbv(h));
   hipEvent_t e0, e1;
   HIPCHECK(hipEventCreate(&e0));
   HIPCHECK(hipEventCreate(&e1));

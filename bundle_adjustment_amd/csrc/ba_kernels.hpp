@@ -60,11 +60,9 @@ constexpr int PT_THREADS = 1024; // threads per workgroup in point passes
 constexpr int LPP = 2;           // lanes per point in point passes (short tracks)
 constexpr int LPP_LONG = 16;     // one DPP row per point for long tracks (threshold chosen per problem)
 constexpr int VEC_BLOCK = 64;    // threads per workgroup in camera-vector kernels (one wave)
-#ifndef BA_VEC_CAMS
-#define BA_VEC_CAMS 16
-#endif
-constexpr int VEC_CAMS = BA_VEC_CAMS;   // cameras per workgroup: a thread per camera reads hundreds of strided words, i.e. one
-                                        // cache line per lane per load; 16 live lanes per wave spread that over 4x the CUs
+constexpr int VEC_CAMS = Pinhole::VC;   // cameras per workgroup (CM::VC per camera model): a thread per camera reads hundreds of
+                                        // strided words, i.e. one cache line per lane per load; 16 live lanes per wave spread
+                                        // that over 4x the CUs
 
 // Flagged index streams.  With a robust loss the linearisation writes, next to the IRLS weights,
 // a copy of each index stream whose top bit says "this observation's weights are not (1, 1)".
@@ -75,8 +73,9 @@ constexpr int IDX_FLAG = (int)0x80000000;
 constexpr int IDX_MASK = 0x7fffffff;
 __device__ inline int flagged_index(int idx, double w0, double w1) { return (w0 != 1.0 || w1 != 1.0) ? (idx | IDX_FLAG) : idx; }
 
+template <int VCM = VEC_CAMS>
 __device__ inline int vec_camera(int n_cams) {      // camera of this thread in a camera-vector kernel, n_cams = none
-  return (threadIdx.x < VEC_CAMS) ? (int)(blockIdx.x * VEC_CAMS + threadIdx.x) : n_cams;
+  return (threadIdx.x < VCM) ? (int)(blockIdx.x * VCM + threadIdx.x) : n_cams;
 }
 
 // max that keeps a NaN (fmax drops it): a non-finite gradient must not read as "converged"
@@ -825,11 +824,11 @@ struct ScalarsArgs {
   long long* dev_flag;           // device word the point workgroups of the same launch wait on (rider mode)
   int on;
 };
-constexpr int CU_GROUPS = 4;          // camera groups (of VEC_CAMS cameras, one wave each) per riding 1024-thread workgroup
+constexpr int CU_GROUPS = 4;          // camera groups (of CM::VC cameras, one wave each) per riding 1024-thread workgroup
 template <class CM> __device__ void cam_update_body(const CamUpdateArgs& a, int blk, bool active, double* __restrict__ lds);
 template <class CM> __device__ __forceinline__ void cam_update_rider(const CamUpdateArgs& a, int rb, double* __restrict__ dyn_lds);
 template <class CM> __host__ __device__ constexpr int cam_update_lds_doubles() {
-  return 6 * VEC_CAMS + 3 * CM::NB * VEC_CAMS + CM::NH * VEC_CAMS + CS * VEC_CAMS + 6 * VEC_CAMS + CS * VEC_CAMS;
+  return CM::VC * (6 + 3 * CM::NB + CM::NH + CS + 6 + CS);
 }
 __device__ void scalars_body(const ScalarsArgs& a);
 
@@ -1326,8 +1325,8 @@ __device__ inline void slice_write_back(double* __restrict__ dst, const double* 
     else dst[2 * i] = lds[2 * i];
   }
 }
-constexpr int VC = VEC_CAMS;
-static_assert(VEC_CAMS == 16 || VEC_CAMS == 8 || VEC_CAMS == 4, "camera-vector workgroups: 4, 8 or 16 cameras per wave (the coarse level of ba_coarse.hpp and its oracle mirror assume 16)");
+static_assert(Pinhole::VC == 16, "the coarse level of ba_coarse.hpp and its oracle mirror assume aggregates of 16 cameras");
+static_assert(BalCam::VC == 16 || BalCam::VC == 8 || BalCam::VC == 4, "camera-vector workgroups: 4, 8 or 16 cameras per wave");
 constexpr int slice_chunks(int doubles) { return (doubles + 127) / 128; }      // double2 per lane that cover a slice
 
 // PCG setup at damping lambda: Hccd = Hcc + lam Dc (fixed camera: identity), Schur-Jacobi
@@ -1345,7 +1344,7 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
             double* __restrict__ s, double* __restrict__ z, double* __restrict__ vtil,
             double* __restrict__ partV, PcgState* __restrict__ st, double* __restrict__ partGc, double* __restrict__ rc,
             double* __restrict__ vx) {
-  constexpr int NB = CM::NB, NH = CM::NH, NL = CM::NL;
+  constexpr int NB = CM::NB, NH = CM::NH, NL = CM::NL, VC = CM::VC;
   // (rc != null: two-level preconditioner -- also the aggregate's restricted right-hand side; z, partV and vtil written
   // here are then the single-level ones and are redone by k_pcg_coarse once E^-1 exists)
   // LDS image of the workgroup's VC cameras.  Inputs: partition-folded sums (a: NL of the linearisation when
@@ -1355,7 +1354,7 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
       l_hd[NH * VC], l_mi[NH * VC], l_g[NB * VC], l_z[NB * VC];
   const int c0 = blockIdx.x * VC;
   const int nc = min(VC, n_cams - c0);
-  const int c = vec_camera(n_cams);
+  const int c = vec_camera<VC>(n_cams);
   const int lane = threadIdx.x;
   // ---- cooperative loads: every word of the workgroup's slices, lane-strided and coalesced; the partition
   // sums run k = 0, 1, ... in every element (the same fixed order as a thread-per-camera loop)
@@ -1513,13 +1512,13 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
            PcgState* __restrict__ st, long long* __restrict__ host_flag, long long flag_base,
            const double* __restrict__ verdict, double* __restrict__ rc, double* __restrict__ vx,
            double model_tol, int model_min_iters) {
-  constexpr int NB = CM::NB, NH = CM::NH;
+  constexpr int NB = CM::NB, NH = CM::NH, VC = CM::VC;
   // LDS image of the workgroup's cameras: Hccd | Minv | z p s r x | part6[NPART] | cs
   __shared__ double l_h[NH * VC], l_mi[NH * VC], l_v[5][NB * VC], l_p6[NPART][NB * VC], l_cs[CS * VC];
   BA_STAMP(2, 0); BA_STAMP(2, 1);
   const int c0 = blockIdx.x * VC;
   const int nc = min(VC, n_cams - c0);                         // cameras of this workgroup (>= 1)
-  const int c = vec_camera(n_cams);
+  const int c = vec_camera<VC>(n_cams);
   const bool live = c < n_cams && c != fixed_cam;
   // every operand is fetched before the verdict is known (one round trip for the whole kernel; an
   // early-exit launch wastes the loads)
@@ -1580,9 +1579,15 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
   const int t = threadIdx.x;
   if (live) {
     const double* M = l_cs + CS * t + 12;
-    double h[NH], mi[NH];                               // into registers once: LDS stores below would force re-reads
+    // pinhole: both blocks into registers once (42 words).  A 9-parameter camera's 90 words would fill the register file
+    // (256 VGPRs + spills into AGPRs): its products read the blocks from LDS where they are
+    double hreg[NB == 6 ? NH : 1], mireg[NB == 6 ? NH : 1];
+    const double *h = l_h + NH * t, *mi = l_mi + NH * t;
+    if (NB == 6) {
 #pragma unroll
-    for (int q = 0; q < NH; ++q) { h[q] = l_h[NH * t + q]; mi[q] = l_mi[NH * t + q]; }
+      for (int q = 0; q < NH; ++q) { hreg[q] = l_h[NH * t + q]; mireg[q] = l_mi[NH * t + q]; }
+      h = hreg; mi = mireg;
+    }
     double zz[NB], wy[NB], pp[NB], ss[NB], rr[NB], xx[NB], w[NB], hz[NB];
     {
       double a[NB];
@@ -1678,7 +1683,7 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
 // of LDS, 16-byte aligned.
 template <class CM>
 __device__ void cam_update_body(const CamUpdateArgs& a, int blk, bool active, double* __restrict__ lds) {
-  constexpr int NB = CM::NB, NH = CM::NH;
+  constexpr int NB = CM::NB, NH = CM::NH, VC = CM::VC;
   // LDS image of the workgroup's VC cameras (coalesced staging, see slice_load): cams | dc rpcg bc | Hcc | cs,
   // outputs cams_trial | cs_trial staged for a coalesced write-back
   double* l_cam = lds;
@@ -1692,7 +1697,7 @@ __device__ void cam_update_body(const CamUpdateArgs& a, int blk, bool active, do
   const int lane = threadIdx.x & 63;
   const int c0 = blk * VC;
   const int nc = min(VC, n_cams - c0);
-  const int c = (lane < VEC_CAMS) ? c0 + lane : n_cams;
+  const int c = (lane < VC) ? c0 + lane : n_cams;
   if (w0) {
     double2 v0[slice_chunks(6 * VC)], vi[3][slice_chunks(NB * VC)], vh[slice_chunks(NH * VC)], vc[slice_chunks(CS * VC)];
     const double* ins[3] = {a.dc, a.rpcg, a.bc};
@@ -1752,7 +1757,7 @@ template <class CM>
 __device__ __forceinline__ void cam_update_rider(const CamUpdateArgs& a, int rb, double* __restrict__ dyn_lds) {
   const int wv = threadIdx.x >> 6;
   const int grp = rb * CU_GROUPS + wv;
-  const int n_groups = (a.n_cams + VEC_CAMS - 1) / VEC_CAMS;
+  const int n_groups = (a.n_cams + CM::VC - 1) / CM::VC;
   cam_update_body<CM>(a, grp, wv < CU_GROUPS && grp < n_groups, dyn_lds + (wv < CU_GROUPS ? wv : 0) * cam_update_lds_doubles<CM>());
 }
 

@@ -29,6 +29,7 @@ struct Pinhole {
   static constexpr int LIN_ROW = 12;    // leading doubles of a table row the linearisation reads
   static constexpr int SCH_ROW = 18;    // ... the Schur point passes read
   static constexpr int VOFF = 12;       // offset of vt in a table row
+  static constexpr int VC = 16;         // cameras per wave in the camera-vector kernels (k_pcg_setup / k_pcg_step / k_cam_update)
 
   template <typename T>
   struct Obs {                           // what one observation contributes, in T (double, or float in the fp32-Jacobian PCG passes)
@@ -109,6 +110,10 @@ struct BalCam {
   static constexpr int LIN_ROW = 16;    // (15 used; loads are 16 bytes wide)
   static constexpr int SCH_ROW = 24;
   static constexpr int VOFF = 15;
+#ifndef BA_VEC_CAMS_BAL
+#define BA_VEC_CAMS_BAL 8
+#endif
+  static constexpr int VC = BA_VEC_CAMS_BAL;   // (a 9-parameter camera's slices are 2.2x the pinhole's: half the cameras per wave keep the loads in flight per lane the same)
 
   template <typename T>
   struct Obs {
