@@ -164,6 +164,7 @@ struct ba_handle {
   DBuf<int> c_ptf[2], p_camf[2];  // index streams with the "weights are not (1, 1)" flag (robust loss; c_ptf pairs with c_w, p_camf with p_w)
   int long_thr = 16;           // tracks longer than this get a DPP row each (set in ba_set_problem)
   int n_long = 0, nblkL = 0;   // points with more than LONG_TRACK observations: one DPP row each, own launch
+  int long_spb = PT_THREADS / LPP_LONG;   // long-track points per workgroup (a multiple of one round's 64)
   DBuf<int2> blk_win;          // per point-pass workgroup: first camera and number of cameras its points see
   DBuf<double2> c_uv, p_uv, c_w[2], p_w[2];   // both halves of the linearisation are double-buffered: the next one is
                                               // computed speculatively at the trial point while the host decides
@@ -840,19 +841,38 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   }
   for (int p = 0; p < Np; ++p) if (pt_off[p + 1] - pt_off[p] > h->long_thr) long_pts.push_back(p);
   h->n_long = (int)long_pts.size();
-  const int long_per_blk = PT_THREADS / LPP_LONG;
-  h->nblkL = (h->n_long + long_per_blk - 1) / long_per_blk;
-  // Windowed point passes hold ONE 1024-thread workgroup per compute unit (128 VGPRs x 16 waves).  When one-round ranges
-  // need somewhat more workgroups than the chip has units (config 5: 306 + 24 on 256), the second wave of workgroups
-  // runs on a quarter of the chip while the rest idles: instead every unit gets one workgroup and a slightly longer range
-  // (a full round plus a partial one).  Much larger problems keep one-round ranges (narrow windows matter more there).
+  h->long_spb = PT_THREADS / LPP_LONG;
+  if (const char* e = getenv("BA_LONG_SLOTS")) h->long_spb = std::max(1, atoi(e)) * (PT_THREADS / LPP_LONG);
+  h->nblkL = (h->n_long + h->long_spb - 1) / h->long_spb;
+  // A point-pass workgroup is 1024 threads at 128 VGPRs: ONE per compute unit.  When one-round ranges plus one-round
+  // long-track workgroups need somewhat more workgroups than the chip has units (config 5: 306 + 175 on 256), the
+  // second wave of workgroups runs on part of the chip while the rest idles, and every workgroup pays its launch and its
+  // window copy for one round of work.  A round (512 points at 2 lanes, 64 long tracks at 16) is latency-bound and costs
+  // about the same whatever it holds, so the cost of a launch is the largest number of ROUNDS any workgroup walks:
+  // choose the long-track workgroups' size (m rounds) and the ranges' length such that everything is resident at once and
+  // that number is smallest (config 5: 168 ranges of 932 points + 88 x 128 long tracks, two rounds each; Schur point
+  // pass 17.0 -> 15.2 us pinhole, 20.0 -> 18.0 us BAL camera).  Much larger problems (more than two rounds per unit)
+  // keep one-round ranges: narrow windows matter more there.
   if (!table_fits && !getenv("BA_PT_BLOCKS")) {
-    const int avail = h->n_cu - h->nblkL;
-    if (avail > 0 && want > avail && want <= 2 * avail) {
-      h->nblkP = avail;
-      h->ppb = (Np + avail - 1) / avail;
+    int best_m = 0, best_cost = 3, best_nb = 0;
+    const bool pick_m = !getenv("BA_LONG_SLOTS") && h->n_long > 0;
+    for (int m = 1; m <= (pick_m ? 4 : 1); ++m) {
+      const int spb = pick_m ? m * (PT_THREADS / LPP_LONG) : h->long_spb;
+      const int nl = (h->n_long + spb - 1) / spb;
+      const int avail = h->n_cu - nl;
+      if (avail < 1) continue;
+      const int nb = std::min(want, avail);
+      const int rounds = ((Np + nb - 1) / nb + pts_per_pass - 1) / pts_per_pass;
+      const int cost = std::max(rounds, h->n_long > 0 ? spb / (PT_THREADS / LPP_LONG) : 0);
+      if (cost < best_cost) { best_cost = cost; best_m = m; best_nb = nb; }
+    }
+    if (best_m && want + h->nblkL > h->n_cu) {
+      if (pick_m) { h->long_spb = best_m * (PT_THREADS / LPP_LONG); h->nblkL = (h->n_long + h->long_spb - 1) / h->long_spb; }
+      h->nblkP = best_nb;
+      h->ppb = (Np + best_nb - 1) / best_nb;
     }
   }
+  const int long_per_blk = h->long_spb;
   std::vector<int2> win(h->nblkP + h->nblkL);
   // a window is staged in LDS when its rows fit; the row stride depends on the camera model (18 doubles for the
   // reference's pinhole, 26 for the BAL camera), so the LDS size and the "every window fits" flag are kept per model
@@ -882,6 +902,10 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   }
   h->lds_bytes_m[0] = max_win[0]; h->lds_bytes_m[1] = max_win[1];
   stage("long tracks + windows");
+  if (timed)
+    fprintf(stderr, "ba_set_problem point passes: %d lanes/point, %d range workgroups x %d points + %d long-track workgroups x %d points "
+            "(%d points over %d observations), LDS window %zu / %zu bytes, every window in LDS %d / %d\n", h->lanes, h->nblkP, h->ppb,
+            h->nblkL, h->long_spb, h->n_long, h->long_thr, max_win[0], max_win[1], (int)h->all_lds_m[0], (int)h->all_lds_m[1]);
   const size_t nobs1 = std::max(No, 1), np1 = std::max(Np, 1);
   // Index uploads.  A window-sized problem (the reference's own use: a few thousand observations) sends a dozen small
   // arrays; copied from pageable memory each is a blocking staged transfer (~10 us), so they go through ONE pinned
@@ -1161,7 +1185,7 @@ static void launch_lin_finalize(ba_handle* h) {
 static PtWork pt_work(ba_handle* h) {        // every point; long tracks skipped when they have a launch of their own
   return PtWork{nullptr, h->Np, h->nblkL ? h->long_thr : 0x7fffffff, 0, h->ppb, h->xcd_ranges};
 }
-static PtWork pt_work_long(ba_handle* h) { return PtWork{h->long_pts.p, h->n_long, 0x7fffffff, h->nblkP, PT_THREADS / LPP_LONG, 0}; }
+static PtWork pt_work_long(ba_handle* h) { return PtWork{h->long_pts.p, h->n_long, 0x7fffffff, h->nblkP, h->long_spb, 0}; }
 // point half at parameter set `w` into point-buffer set `pbuf`, with the damped inverse / y0 at `lambda` fused in
 // (lam_dev != null: the damping is read from that device word instead -- a speculated pass, see ba_solve)
 template <class CM>

@@ -19,7 +19,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bundle_adjustment_amd import hip_backend as hb          # noqa: E402
-from bundle_adjustment_amd.synthetic import make_bal_like, make_config   # noqa: E402
+from bundle_adjustment_amd.synthetic import make_bal_like, make_bal_problem, make_config   # noqa: E402
 
 STAGES = {
     0: ("k_pt_schur<MODE 0>", ["entry", "verdict known", "table filled", "main loop done", "points stored (pre block sum)", "exit"], [1, 2, 3, 4, 5, 6]),
@@ -30,20 +30,26 @@ STAGES = {
 
 def main():
     cfg = sys.argv[1] if len(sys.argv) > 1 else "C3"
-    p = make_bal_like(seed=0) if cfg == "C5" else make_config(cfg, seed=0)
+    bal = make_bal_problem(seed=0) if cfg == "C5bal" else None          # config 5 with the BAL 9-parameter camera
+    p = bal if bal is not None else (make_bal_like(seed=0) if cfg == "C5" else make_config(cfg, seed=0))
     s = hb.Solver(0)
     lib = s._lib
     lib.ba_debug_stamps.restype = C.c_int
     lib.ba_debug_stamps.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.c_int]
-    s.set_problem(p)
+    intr = s.set_problem_bal(bal, fixed_cam=0) if bal is not None else s.set_problem(p)
     mode = int(os.environ.get("BA_DBG_MODE", "0"))
     if mode:
         lib.ba_debug_mode.restype = C.c_int
         lib.ba_debug_mode.argtypes = [C.c_void_p, C.c_int]
         hb._check(lib.ba_debug_mode(s._h, mode))
         print(f"camera-pass gather variant {mode} (results are meaningless; timing only)")
-    s.solve(loss="huber", max_iters=3, ftol=0.0, xtol=0.0, gtol=0.0, pcg_tol=0.0, pcg_max_iters=3, pcg_min_iters=3)
-    nblk = {0: min(8192, (p.n_pts + 511) // 512 + 64), 1: min(8192, ((p.n_cams + 3) // 4) * 8), 2: (p.n_cams + 15) // 16}
+    kw = dict(loss="huber", max_iters=3, ftol=0.0, xtol=0.0, gtol=0.0, pcg_tol=0.0, pcg_max_iters=3, pcg_min_iters=3)
+    if bal is not None:
+        s.solve_bal_resident(intr, **kw)
+    else:
+        s.solve(**kw)
+    vc = 8 if bal is not None else 16
+    nblk = {0: min(8192, (p.n_pts + 511) // 512 + 64), 1: min(8192, ((p.n_cams + 3) // 4) * 8), 2: (p.n_cams + vc - 1) // vc}
     for kind, (name, labels, slots) in STAGES.items():
         n = nblk[kind]
         buf = (C.c_uint64 * (n * 8))()
