@@ -851,10 +851,10 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   // about the same whatever it holds, so the cost of a launch is the largest number of ROUNDS any workgroup walks:
   // choose the long-track workgroups' size (m rounds) and the ranges' length such that everything is resident at once and
   // that number is smallest (config 5: 168 ranges of 932 points + 88 x 128 long tracks, two rounds each; Schur point
-  // pass 17.0 -> 15.2 us pinhole, 20.0 -> 18.0 us BAL camera).  Much larger problems (more than two rounds per unit)
-  // keep one-round ranges: narrow windows matter more there.
-  if (!table_fits && !getenv("BA_PT_BLOCKS")) {
-    int best_m = 0, best_cost = 3, best_nb = 0;
+  // pass 17.0 -> 15.2 us pinhole, 20.0 -> 18.0 us BAL camera).  Much larger WINDOWED problems (more than two rounds per
+  // unit) keep one-round ranges: narrow windows matter more there.
+  if (!getenv("BA_PT_BLOCKS") && (!table_fits || h->n_long > 0)) {
+    int best_m = 0, best_cost = table_fits ? 0x7fffffff : 3, best_nb = 0;   // (table in LDS: ranges of any length share one fill)
     const bool pick_m = !getenv("BA_LONG_SLOTS") && h->n_long > 0;
     for (int m = 1; m <= (pick_m ? 4 : 1); ++m) {
       const int spb = pick_m ? m * (PT_THREADS / LPP_LONG) : h->long_spb;
