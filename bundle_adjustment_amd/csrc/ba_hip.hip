@@ -714,6 +714,52 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
       p_cam[b] = cam_idx[i]; p_src[b] = i;
     }
   }
+  // long tracks: one DPP row (16 lanes) per point in a launch of their own
+  std::vector<int> long_pts;
+  {   // long = more than max(8, 2 x median track length) observations (BA_LONG_TRACK overrides)
+    std::vector<int> len(Np);
+    for (int p = 0; p < Np; ++p) len[p] = pt_off[p + 1] - pt_off[p];
+    int med = 0;
+    if (Np > 0) { std::nth_element(len.begin(), len.begin() + Np / 2, len.end()); med = len[Np / 2]; }
+    const char* e = getenv("BA_LONG_TRACK");
+    h->long_thr = e ? std::max(1, atoi(e)) : std::max(8, 2 * med);
+    if (h->lanes != LPP) h->long_thr = 0x7fffffff;           // more lanes per point already: no separate long-track rows
+  }
+  for (int p = 0; p < Np; ++p) if (pt_off[p + 1] - pt_off[p] > h->long_thr) long_pts.push_back(p);
+  h->n_long = (int)long_pts.size();
+  h->long_spb = PT_THREADS / LPP_LONG;
+  if (const char* e = getenv("BA_LONG_SLOTS")) h->long_spb = std::max(1, atoi(e)) * (PT_THREADS / LPP_LONG);
+  h->nblkL = (h->n_long + h->long_spb - 1) / h->long_spb;
+  // A point-pass workgroup is 1024 threads at 128 VGPRs: ONE per compute unit.  When one-round ranges plus one-round
+  // long-track workgroups need somewhat more workgroups than the chip has units (config 5: 306 + 175 on 256), the
+  // second wave of workgroups runs on part of the chip while the rest idles, and every workgroup pays its launch and its
+  // window copy for one round of work.  A round (512 points at 2 lanes, 64 long tracks at 16) is latency-bound and costs
+  // about the same whatever it holds, so the cost of a launch is the largest number of ROUNDS any workgroup walks:
+  // choose the long-track workgroups' size (m rounds) and the ranges' length such that everything is resident at once and
+  // that number is smallest (config 5: 168 ranges of 932 points + 88 x 128 long tracks, two rounds each; Schur point
+  // pass 17.0 -> 15.2 us pinhole, 20.0 -> 18.0 us BAL camera).  Much larger WINDOWED problems (more than two rounds per
+  // unit) keep one-round ranges: narrow windows matter more there.
+  if (!getenv("BA_PT_BLOCKS") && (!table_fits || h->n_long > 0)) {
+    int best_m = 0, best_cost = table_fits ? 0x7fffffff : 3, best_nb = 0;   // (table in LDS: ranges of any length share one fill)
+    const bool pick_m = !getenv("BA_LONG_SLOTS") && h->n_long > 0;
+    for (int m = 1; m <= (pick_m ? 4 : 1); ++m) {
+      const int spb = pick_m ? m * (PT_THREADS / LPP_LONG) : h->long_spb;
+      const int nl = (h->n_long + spb - 1) / spb;
+      const int avail = h->n_cu - nl;
+      if (avail < 1) continue;
+      const int nb = std::min(want, avail);
+      const int rounds = ((Np + nb - 1) / nb + pts_per_pass - 1) / pts_per_pass;
+      const int cost = std::max(rounds, h->n_long > 0 ? spb / (PT_THREADS / LPP_LONG) : 0);
+      if (cost < best_cost) { best_cost = cost; best_m = m; best_nb = nb; }
+    }
+    if (best_m && want + h->nblkL > h->n_cu) {
+      if (pick_m) { h->long_spb = best_m * (PT_THREADS / LPP_LONG); h->nblkL = (h->n_long + h->long_spb - 1) / h->long_spb; }
+      h->nblkP = best_nb;
+      h->ppb = (Np + best_nb - 1) / best_nb;
+    }
+  }
+  const int long_per_blk = h->long_spb;
+  // (the visiting order below is laid out for the ranges' final length)
   bank_aware_order(p_cam, p_src, pt_off);
   stage("sort by point");
   // camera order: stable counting sort of the POINT-ordered list by camera, so that every
@@ -828,51 +874,6 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   h->nblkV = (Nc + VEC_CAMS - 1) / VEC_CAMS;
   h->nblkVm[0] = (Nc + Pinhole::VC - 1) / Pinhole::VC; h->nblkVm[1] = (Nc + BalCam::VC - 1) / BalCam::VC;
   const size_t nbv_max = (size_t)std::max(h->nblkVm[0], h->nblkVm[1]);
-  // long tracks: one DPP row (16 lanes) per point in a launch of their own
-  std::vector<int> long_pts;
-  {   // long = more than max(8, 2 x median track length) observations (BA_LONG_TRACK overrides)
-    std::vector<int> len(Np);
-    for (int p = 0; p < Np; ++p) len[p] = pt_off[p + 1] - pt_off[p];
-    int med = 0;
-    if (Np > 0) { std::nth_element(len.begin(), len.begin() + Np / 2, len.end()); med = len[Np / 2]; }
-    const char* e = getenv("BA_LONG_TRACK");
-    h->long_thr = e ? std::max(1, atoi(e)) : std::max(8, 2 * med);
-    if (h->lanes != LPP) h->long_thr = 0x7fffffff;           // more lanes per point already: no separate long-track rows
-  }
-  for (int p = 0; p < Np; ++p) if (pt_off[p + 1] - pt_off[p] > h->long_thr) long_pts.push_back(p);
-  h->n_long = (int)long_pts.size();
-  h->long_spb = PT_THREADS / LPP_LONG;
-  if (const char* e = getenv("BA_LONG_SLOTS")) h->long_spb = std::max(1, atoi(e)) * (PT_THREADS / LPP_LONG);
-  h->nblkL = (h->n_long + h->long_spb - 1) / h->long_spb;
-  // A point-pass workgroup is 1024 threads at 128 VGPRs: ONE per compute unit.  When one-round ranges plus one-round
-  // long-track workgroups need somewhat more workgroups than the chip has units (config 5: 306 + 175 on 256), the
-  // second wave of workgroups runs on part of the chip while the rest idles, and every workgroup pays its launch and its
-  // window copy for one round of work.  A round (512 points at 2 lanes, 64 long tracks at 16) is latency-bound and costs
-  // about the same whatever it holds, so the cost of a launch is the largest number of ROUNDS any workgroup walks:
-  // choose the long-track workgroups' size (m rounds) and the ranges' length such that everything is resident at once and
-  // that number is smallest (config 5: 168 ranges of 932 points + 88 x 128 long tracks, two rounds each; Schur point
-  // pass 17.0 -> 15.2 us pinhole, 20.0 -> 18.0 us BAL camera).  Much larger WINDOWED problems (more than two rounds per
-  // unit) keep one-round ranges: narrow windows matter more there.
-  if (!getenv("BA_PT_BLOCKS") && (!table_fits || h->n_long > 0)) {
-    int best_m = 0, best_cost = table_fits ? 0x7fffffff : 3, best_nb = 0;   // (table in LDS: ranges of any length share one fill)
-    const bool pick_m = !getenv("BA_LONG_SLOTS") && h->n_long > 0;
-    for (int m = 1; m <= (pick_m ? 4 : 1); ++m) {
-      const int spb = pick_m ? m * (PT_THREADS / LPP_LONG) : h->long_spb;
-      const int nl = (h->n_long + spb - 1) / spb;
-      const int avail = h->n_cu - nl;
-      if (avail < 1) continue;
-      const int nb = std::min(want, avail);
-      const int rounds = ((Np + nb - 1) / nb + pts_per_pass - 1) / pts_per_pass;
-      const int cost = std::max(rounds, h->n_long > 0 ? spb / (PT_THREADS / LPP_LONG) : 0);
-      if (cost < best_cost) { best_cost = cost; best_m = m; best_nb = nb; }
-    }
-    if (best_m && want + h->nblkL > h->n_cu) {
-      if (pick_m) { h->long_spb = best_m * (PT_THREADS / LPP_LONG); h->nblkL = (h->n_long + h->long_spb - 1) / h->long_spb; }
-      h->nblkP = best_nb;
-      h->ppb = (Np + best_nb - 1) / best_nb;
-    }
-  }
-  const int long_per_blk = h->long_spb;
   std::vector<int2> win(h->nblkP + h->nblkL);
   // a window is staged in LDS when its rows fit; the row stride depends on the camera model (18 doubles for the
   // reference's pinhole, 26 for the BAL camera), so the LDS size and the "every window fits" flag are kept per model
