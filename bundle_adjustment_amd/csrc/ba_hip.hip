@@ -177,6 +177,8 @@ struct ba_handle {
   int pb = 0;                  // which point-half buffer set holds the current linearisation
   // partial sums
   DBuf<double> partR, partL[2], part6, partE, partA, partB, partC, partV;
+  DBuf<double> linmsg[2];            // multi-rank: a linearisation's camera half, folded, behind 8 header words (k_fold_lin)
+  DBuf<double> sysmsg;               // multi-rank: the damped system's message [u.y, 0 | part6 | partE | world maxima] (k_fold_msg)
   DBuf<double> partG[2], partGc;   // per-workgroup max |bp| (point half, double-buffered like it) and max |bc| (k_pcg_setup): the gtol test
   int lb = 0;                  // which c_w / partL buffer holds the current linearisation
   // PCG vectors, comm buffers (multi-rank), scalars
@@ -216,6 +218,7 @@ struct ba_handle {
   long long flag_base = 1, step_seq = 1;
   // comm
   int rank = 0, world = 1;
+  bool sys_diag = false;   // the last exchange_system carried Schur-Jacobi blocks (layout of sysmsg)
   bool one_part = false;       // multi-rank, thin shards: every camera's local observations in partition 0 (no fold kernels; ba_set_problem)
   bool multi = false;          // the multi-rank control flow is on: world > 1, or a communicator of ONE rank was forced
                                // (BA_COMM_FORCE=1: lets a single GPU execute every fold / all-reduce / decide step of the
@@ -354,7 +357,7 @@ extern "C" int ba_destroy(ba_handle* h) {
   DBuf<double>* db[] = {&h->cams[0], &h->cams[1], &h->cs[0], &h->cs[1], &h->ptab[0], &h->ptab[1], &h->stage,
                         &h->camA[0], &h->camA[1], &h->HccBc, &h->Hpp[0], &h->Hpp[1], &h->bp[0], &h->bp[1],
                         &h->Hppinv[0], &h->Hppinv[1], &h->y0[0], &h->y0[1], &h->Hccd, &h->Minv,
-                        &h->partR, &h->partL[0], &h->partL[1], &h->part6, &h->partE, &h->partA, &h->partB, &h->partC, &h->partV,
+                        &h->partR, &h->partL[0], &h->partL[1], &h->part6, &h->partE, &h->sysmsg, &h->linmsg[0], &h->linmsg[1], &h->partA, &h->partB, &h->partC, &h->partV,
                         &h->partG[0], &h->partG[1], &h->partGc,
                         &h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin, &h->vx, &h->scal, &h->rbuf, &h->gather};
   for (auto b : db) b->release();
@@ -961,6 +964,8 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(h->partL[0].alloc(NLX * (size_t)NPART * Nc)); HIPCHECK(h->partL[1].alloc(NLX * (size_t)NPART * Nc));
   HIPCHECK(h->part6.alloc(NBX * (size_t)NPART * Nc + 8));   // + the u.y word: one all-reduce carries both
   HIPCHECK(h->partE.alloc(NHX * (size_t)NPART * Nc));
+  if (h->multi) { HIPCHECK(h->linmsg[0].alloc(8 + NLX * (size_t)Nc)); HIPCHECK(h->linmsg[1].alloc(8 + NLX * (size_t)Nc)); }
+  if (h->multi) HIPCHECK(h->sysmsg.alloc(2 + (size_t)(NBX + NHX) * Nc + (size_t)h->world + 8));
   HIPCHECK(h->partA.alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partB.alloc(4 * (size_t)(h->nblkP + h->nblkL)));
   HIPCHECK(h->partC.alloc(5 * nbv_max)); HIPCHECK(h->partV.alloc(4 * nbv_max));
   HIPCHECK(h->partG[0].alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partG[1].alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partGc.alloc(nbv_max));
@@ -1015,6 +1020,11 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
 
 // block sizes of the running camera model
 static int nb_of(const ba_handle* h) { return h->model ? BalCam::NB : Pinhole::NB; }
+// partitions a consumer of the camera passes' partial sums adds up: all of them on one rank; in a multi-rank job the
+// arrays arrive folded into partition 0 and all-reduced (fold_and_reduce), the other partitions are stale
+static int nparts_of(const ba_handle* h) { return h->multi ? 1 : NPART; }
+// the camera half's running sums a consumer reads: all partitions on one rank; the folded, all-reduced message otherwise
+static const double* partL_of(const ba_handle* h, int buf) { return h->multi ? h->linmsg[buf].p + 8 : h->partL[buf].p; }
 static int nbv(const ba_handle* h) { return h->nblkVm[h->model]; }      // camera-vector workgroups of the active model
 static int nh_of(const ba_handle* h) { return h->model ? BalCam::NH : Pinhole::NH; }
 static int nl_of(const ba_handle* h) { return h->model ? BalCam::NL : Pinhole::NL; }
@@ -1178,8 +1188,8 @@ static void launch_lin_cam(ba_handle* h, int which, int buf, bool robust, double
 }
 static void launch_lin_finalize(ba_handle* h) {
   Scope sc(h, BA_K_MISC);
-#define CALL_T(CM) BA_LAUNCH(k_lin_finalize<CM::NB>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, h->partL[h->lb].p, \
-                             h->cs[h->cur].p, h->Nc, h->fixed, h->HccBc.p, bc_ptr(h))
+#define CALL_T(CM) BA_LAUNCH(k_lin_finalize<CM::NB>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, partL_of(h, h->lb), \
+                             nparts_of(h), h->cs[h->cur].p, h->Nc, h->fixed, h->HccBc.p, bc_ptr(h))
   BA_BY_MODEL(CALL_T);
 #undef CALL_T
 }
@@ -1244,6 +1254,14 @@ static void launch_point_invert(ba_handle* h, double lambda) {
 constexpr int GMAX_HOST_SLOT = 40;   // word of the host-mapped scalar block that receives max |gradient| (k_scalars uses [0, S_COUNT))
 static double* uy_ptr(ba_handle* h) { return h->part6.p; }
 static double* p6_ptr(ba_handle* h) { return h->part6.p + 2; }
+// (multi-rank: the damped system's sums are read from the all-reduced message of exchange_system)
+static double* sys_p6(ba_handle* h) { return h->multi ? h->sysmsg.p + 2 : p6_ptr(h); }
+static double* sys_E(ba_handle* h) { return h->multi ? h->sysmsg.p + 2 + nb_of(h) * (size_t)h->Nc : h->partE.p; }
+static size_t sys_nE(ba_handle* h) { return h->sys_diag ? nh_of(h) * (size_t)h->Nc : 0; }
+static const double* gmax_parts(ba_handle* h) {   // per-workgroup (single rank) / per-rank (multi-rank) maxima of |bp|
+  return h->multi ? h->sysmsg.p + 2 + nb_of(h) * (size_t)h->Nc + sys_nE(h) : h->partG[h->pb].p;
+}
+static int gmax_count(ba_handle* h) { return h->multi ? h->world : (h->Np > 0 ? h->nblkP + h->nblkL : 0); }
 // camera pass of the Schur product on the y slot of the current point table
 //   diag: also the Schur-Jacobi blocks; pcg: iteration k with early exit
 template <class CM>
@@ -1293,7 +1311,7 @@ static void launch_pt_schur_t(ba_handle* h, bool robust, int mode, int k, double
                 h->Hppinv[h->pb].p, h->blk_win.p
 #define PS_TAIL h->K4[0], h->K4[1], h->fixed, h->partA.p, k, h->st.p, h->partV.p, nbv(h), tol2, min_iters, h->y0[h->pb].p,     \
                 h->Hpp[h->pb].p, h->bp[h->pb].p, h->ptab[1 - w].p, h->partB.p, flag, flag_base, h->verdict.p,                      \
-                (const double*)h->partG[h->pb].p, h->nblkP + h->nblkL, (const double*)h->partGc.p, nbv(h), gmax_out, cu
+                gmax_parts(h), gmax_count(h), (const double*)h->partGc.p, nbv(h), gmax_out, cu
   const size_t lds = std::max(lds_of(h), ride ? CU_GROUPS * cam_update_lds_doubles<CM>() * sizeof(double) : (size_t)0) + (size_t)h->debug_lds_extra;
   long long* flag = (mode == 0 && flag_base > 0) ? h->d_flags : (long long*)nullptr;
   // data with long tracks: short and long tracks in one launch (workgroup 0 publishes the verdict)
@@ -1335,7 +1353,7 @@ static void launch_pt_schur(ba_handle* h, bool robust, int mode, int k, double t
     if (mode == 0 && flag_base > 0) {
       Scope sc(h, BA_K_SCHUR_PT);
       BA_LAUNCH(k_pcg_probe, dim3(1), dim3(64), 0, h->stream, k, h->st.p, h->partV.p, nbv(h), tol2, min_iters, h->d_flags,
-                flag_base, h->verdict.p, (const double*)h->partGc.p, nbv(h), gmax_out);
+                flag_base, h->verdict.p, gmax_parts(h), gmax_count(h), (const double*)h->partGc.p, nbv(h), gmax_out);
     }
     return;
   }
@@ -1360,20 +1378,41 @@ static int fold_and_reduce(ba_handle* h, double* parts, size_t n_per_part, doubl
   }
   return allreduce(h, msg, msg_count);
 }
-static int exchange_partL(ba_handle* h, int buf) {
-  return fold_and_reduce(h, h->partL[buf].p, nl_of(h) * (size_t)h->Nc, h->partL[buf].p, nl_of(h) * (size_t)h->Nc);
+// with_scalars: the step's six local sums (h->scal, written by k_scalars just before) ride in the message's header
+static int exchange_partL(ba_handle* h, int buf, bool with_scalars = false) {
+  if (!h->multi) return BA_OK;
+  const size_t n = nl_of(h) * (size_t)h->Nc;
+  {
+    Scope sc(h, BA_K_MISC);
+    BA_LAUNCH(k_fold_lin, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, with_scalars ? (const double*)h->scal.p : (const double*)nullptr,
+              (const double*)h->partL[buf].p, n, h->one_part ? 1 : NPART, h->linmsg[buf].p);
+  }
+  return allreduce(h, h->linmsg[buf].p, 8 + n);
 }
-static int exchange_schur(ba_handle* h, bool with_diag) {
+static int exchange_schur(ba_handle* h) {
   if (!h->multi) return BA_OK;
   // the message starts at the u.y word in front of partition 0
-  if (int rc = fold_and_reduce(h, p6_ptr(h), nb_of(h) * (size_t)h->Nc, uy_ptr(h), 2 + nb_of(h) * (size_t)h->Nc)) return rc;
-  if (with_diag) return fold_and_reduce(h, h->partE.p, nh_of(h) * (size_t)h->Nc, h->partE.p, nh_of(h) * (size_t)h->Nc);
-  return BA_OK;
+  return fold_and_reduce(h, p6_ptr(h), nb_of(h) * (size_t)h->Nc, uy_ptr(h), 2 + nb_of(h) * (size_t)h->Nc);
+}
+// The damped system's sums of a multi-rank job: W y0 (part6), the Schur-Jacobi blocks (partE, with_diag) and every rank's
+// max |bp| travel in ONE message (k_fold_msg gathers and folds them, one all-reduce); k_pcg_setup and the first PCG probe
+// read them from there.
+static int exchange_system(ba_handle* h, bool with_diag) {
+  if (!h->multi) return BA_OK;
+  h->sys_diag = with_diag;
+  const size_t n6 = nb_of(h) * (size_t)h->Nc, nE = sys_nE(h);
+  {
+    Scope sc(h, BA_K_MISC);
+    BA_LAUNCH(k_fold_msg, dim3((unsigned)((n6 + nE + 255) / 256)), dim3(256), 0, h->stream, (const double*)uy_ptr(h),
+              (const double*)p6_ptr(h), n6, (const double*)h->partE.p, nE, h->one_part ? 1 : NPART,
+              (const double*)h->partG[h->pb].p, h->Np > 0 ? h->nblkP + h->nblkL : 0, h->rank, h->world, h->sysmsg.p);
+  }
+  return allreduce(h, h->sysmsg.p, 2 + n6 + nE + (size_t)h->world);
 }
 // finalize = true: fold the fresh camera-half partials into Hcc | bc inside the same kernel
 static void launch_pcg_setup(ba_handle* h, double lambda, bool schur_diag, bool finalize) {
   Scope sc(h, BA_K_PCG_UPDATE);
-#define SU_ARGS h->partL[h->lb].p, h->HccBc.p, bc_ptr(h), p6_ptr(h), h->partE.p, NPART, h->cs[h->cur].p, lambda,           \
+#define SU_ARGS partL_of(h, h->lb), h->HccBc.p, bc_ptr(h), sys_p6(h), sys_E(h), nparts_of(h), h->cs[h->cur].p, lambda,           \
                 schur_diag ? 1 : 0, h->Nc, h->fixed, h->Hccd.p, h->Minv.p, h->gvec.p, h->x.p, h->r.p, h->p.p, h->s.p,     \
                 h->z.p, h->camA[h->cur].p, h->partV.p, h->st.p, h->partGc.p, (h->two_level ? h->coarse_rc.p : (double*)nullptr), h->vx.p
 #define CALL_T(CM)                                                                                               \
@@ -1509,7 +1548,7 @@ static void coarse_build(ba_handle* h);
 static int damped_system(ba_handle* h, double lambda, bool schur_diag, bool invert = true, bool finalize = false) {
   if (invert) launch_point_invert(h, lambda);
   launch_cam_schur(h, h->lin_robust, schur_diag, false, 0, 0.0, 0);
-  if (int rc = exchange_schur(h, schur_diag)) return rc;
+  if (int rc = exchange_system(h, schur_diag)) return rc;
   launch_pcg_setup(h, lambda, schur_diag, finalize);
   if (h->two_level) coarse_build(h);
   return BA_OK;
@@ -1539,11 +1578,11 @@ extern "C" int ba_schur_apply(ba_handle* h, double lambda, const double* v, doub
   }
   launch_pt_schur(h, h->lin_robust, 0, 0, -1.0, 1 << 30);        // y = Hppinv W^T v into the point table
   launch_cam_schur(h, h->lin_robust, false, false, 0, 0.0, 0);
-  if (int rc = exchange_schur(h, false)) return rc;
+  if (int rc = exchange_schur(h)) return rc;
   {
     Scope sc(h, BA_K_MISC);
     BA_LAUNCH(k_schur_combine, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->Hccd.p, h->vin.p, p6_ptr(h),
-                       NPART, h->cs[h->cur].p, h->Nc, h->fixed, h->z.p);
+                       nparts_of(h), h->cs[h->cur].p, h->Nc, h->fixed, h->z.p);
   }
   HIPCHECK(hipMemcpyAsync(out, h->z.p, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   BA_SYNC(h);
@@ -1846,18 +1885,8 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       // max |gradient| = max(|bc|, |bp|): per-workgroup maxima come out of the point half (partG) and of
       // k_pcg_setup (partGc); single rank: the first PCG probe folds them into host-mapped memory
       gtol_pending = true;
-      if (h->multi) {
-        // bc is all-reduced (identical on every rank); bp is shard-local -> max over the ranks' partial maxima, then
-        // the word goes to host-mapped memory ahead of the first probe (no copy, no stream synchronise)
-        {
-          Scope sc(h, BA_K_MISC);
-          BA_LAUNCH(k_max_partials, dim3(1), dim3(64), 0, h->stream, (const double*)h->partG[h->pb].p,
-                    h->Np > 0 ? h->nblkP + h->nblkL : 0, (const double*)h->partGc.p, nbv(h), h->scal.p + 18);
-        }
-        if (int rc = allreduce(h, h->scal.p + 18, 1, true)) return rc;
-        Scope sc(h, BA_K_MISC);
-        BA_LAUNCH(k_word_to_host, dim3(1), dim3(64), 0, h->stream, (const double*)(h->scal.p + 18), h->d_scal_host + GMAX_HOST_SLOT);
-      }
+      // (multi-rank: bc is all-reduced, identical on every rank; bp is shard-local -- every rank's maximum came with the
+      // damped system's message, exchange_system, and the probe folds those instead of partG)
     }
     double t1 = now_s();
     sum->seconds_linearize += t1 - t0;
@@ -1872,13 +1901,13 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     h->flag_base += opts->pcg_max_iters + 8;
     auto launch_point_pass = [&](int kk) {
       launch_pt_schur(h, robust, 0, kk, tol2, opts->pcg_min_iters, base,
-                      (kk == 0 && gtol_pending && !h->multi) ? h->d_scal_host + GMAX_HOST_SLOT : (double*)nullptr);
+                      (kk == 0 && gtol_pending) ? h->d_scal_host + GMAX_HOST_SLOT : (double*)nullptr);
     };
     auto launch_rest = [&](int kk) -> int {
       launch_cam_schur(h, robust, false, true, kk, tol2, opts->pcg_min_iters);
-      if (int rc = exchange_schur(h, false)) return rc;
+      if (int rc = exchange_schur(h)) return rc;
       Scope sc(h, BA_K_PCG_UPDATE);
-#define STEP_ARGS kk, p6_ptr(h), NPART, (const double*)uy_ptr(h), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc, h->fixed, tol2,       \
+#define STEP_ARGS kk, p6_ptr(h), nparts_of(h), (const double*)uy_ptr(h), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc, h->fixed, tol2,       \
                   opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA[h->cur].p, h->partV.p, nbv(h), h->st.p, \
                   h->d_flags, base, (const double*)h->verdict.p
 #define STEP_TAIL h->vx.p, opts->pcg_model_tol, opts->pcg_model_min_iters
@@ -1944,22 +1973,24 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     // GPU already runs the point half at the trial point with that damping, into the other point buffers.  An accepted
     // step finds its linearisation done; a rejected one ignores both.
     const bool speculated = (it + 1 < opts->max_iters);
-    if (speculated) {
-      launch_lin_cam(h, 1 - h->cur, 1 - h->lb, robust, fs, true);
-      if (int rc = exchange_partL(h, 1 - h->lb)) return rc;
-    } else {
-      launch_residual(h, 1 - h->cur, robust, fs, nullptr);
-    }
+    if (speculated) launch_lin_cam(h, 1 - h->cur, 1 - h->lb, robust, fs, true);
+    else            launch_residual(h, 1 - h->cur, robust, fs, nullptr);
     if (debug_poison) BA_LAUNCH(k_poison, dim3(1), dim3(64), 0, h->stream, h->partR.p);
     const long long seq = ++h->step_seq;
     // the step's scalar fold + verdict: single rank with a speculated point half behind it -> workgroup 0 of that launch
     // (the point workgroups pick the next damping up through a device word); else a launch of its own
     const bool ride_scalars = (riders & 2) && speculated && !h->multi && h->Np > 0;
     if (!ride_scalars) launch_scalars(h, true, k, tol2, opts->pcg_min_iters, seq, cost, lambda);
-    if (h->multi) {           // the six sums over ranks, then the verdict on the all-reduced block; same host-mapped mirror + word
-      if (int rc = allreduce(h, h->scal.p, 6)) return rc;
+    if (h->multi) {
+      // the six sums over ranks, then the verdict on the all-reduced block (same host-mapped mirror + word).  A speculated
+      // camera half has to be all-reduced anyway: the six words travel in the header of that message, one collective
+      const double* reduced6 = nullptr;
+      if (speculated) {
+        if (int rc = exchange_partL(h, 1 - h->lb, true)) return rc;
+        reduced6 = h->linmsg[1 - h->lb].p;
+      } else if (int rc = allreduce(h, h->scal.p, 6)) return rc;
       Scope sc(h, BA_K_MISC);
-      BA_LAUNCH(k_decide, dim3(1), dim3(64), 0, h->stream, h->scal.p, cost, lambda, h->d_scal_host, h->d_flags + 2, seq);
+      BA_LAUNCH(k_decide, dim3(1), dim3(64), 0, h->stream, h->scal.p, reduced6, cost, lambda, h->d_scal_host, h->d_flags + 2, seq);
     }
     if (speculated) {
       ScalarsArgs sa = scalars_args(h, true, k, tol2, opts->pcg_min_iters, seq, cost, lambda);

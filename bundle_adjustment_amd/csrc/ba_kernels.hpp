@@ -111,13 +111,67 @@ __global__ void k_cam_prepare(const double* __restrict__ cams, const double* __r
 }
 
 // In-place fold of nparts per-partition partial-sum arrays of n values each (multi-rank jobs, ahead of
-// the all-reduce): partition 0 <- sum over the partitions in partition order, the others <- 0.
+// the all-reduce): partition 0 <- sum over the partitions in partition order.  The other partitions keep their
+// (now stale) local sums: every consumer of an all-reduced array reads partition 0 only (nparts = 1).
 __global__ void k_fold_parts(double* __restrict__ parts, size_t n, int nparts) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  double s = parts[i];
-  for (int k = 1; k < nparts; ++k) { s += parts[(size_t)k * n + i]; parts[(size_t)k * n + i] = 0.0; }
+  double v[NPART];
+#pragma unroll
+  for (int k = 0; k < NPART; ++k) v[k] = (k < nparts) ? parts[(size_t)k * n + i] : 0.0;     // all loads in flight at once
+  double s = v[0];
+#pragma unroll
+  for (int k = 1; k < NPART; ++k) s += v[k];
   parts[i] = s;
+}
+
+// The damped system's message of a multi-rank job, gathered into ONE buffer for ONE all-reduce:
+//   msg = [ u.y word, 0 | sum_k part6[k] (n6 values) | sum_k partE[k] (nE values, 0 without Schur-Jacobi blocks) | world slots ]
+// Slot `rank` of the tail holds this rank's max |bp| (the per-workgroup maxima of the point half, partG), the other
+// slots 0: after the sum all-reduce every rank holds every rank's maximum, and the first PCG probe takes the largest
+// (the reference's gtol test) exactly as it folds partG on a single rank.  nparts: partitions to add up (1 when the
+// camera passes already wrote whole lists into partition 0).
+__global__ void __launch_bounds__(256)
+k_fold_msg(const double* __restrict__ uy_src, const double* __restrict__ part6, size_t n6, const double* __restrict__ partE,
+           size_t nE, int nparts, const double* __restrict__ partG, int nG, int rank, int world, double* __restrict__ msg) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n6 + nE) {
+    const double* src = (i < n6) ? part6 + i : partE + (i - n6);
+    const size_t stride = (i < n6) ? n6 : nE;
+    double v[NPART];
+#pragma unroll
+    for (int k = 0; k < NPART; ++k) v[k] = (k < nparts) ? src[(size_t)k * stride] : 0.0;
+    double s = v[0];
+#pragma unroll
+    for (int k = 1; k < NPART; ++k) s += v[k];
+    msg[2 + i] = s;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 64) {
+    double m = 0.0;
+    for (int b = threadIdx.x; b < nG; b += 64) m = nanmax(m, partG[b]);
+    m = wave_nanmax(m);
+    double* tail = msg + 2 + n6 + nE;
+    for (int r = threadIdx.x; r < world; r += 64) tail[r] = (r == rank) ? m : 0.0;
+    if (threadIdx.x == 0) { msg[0] = uy_src[0]; msg[1] = 0.0; }
+  }
+}
+
+// The camera half of a linearisation in a multi-rank job: msg = [ 8 header words | sum_k partL[k] (n values) ], one
+// all-reduce.  The header carries the step's six local sums (k_scalars' block, scal6 != null) when the pass was speculated
+// at a trial point -- the trial cost comes out of the same pass, so verdict and linearisation share one collective.
+__global__ void __launch_bounds__(256)
+k_fold_lin(const double* __restrict__ scal6, const double* __restrict__ partL, size_t n, int nparts, double* __restrict__ msg) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    double v[NPART];
+#pragma unroll
+    for (int k = 0; k < NPART; ++k) v[k] = (k < nparts) ? partL[(size_t)k * n + i] : 0.0;
+    double s = v[0];
+#pragma unroll
+    for (int k = 1; k < NPART; ++k) s += v[k];
+    msg[8 + i] = s;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 8) msg[threadIdx.x] = (scal6 && threadIdx.x < 6) ? scal6[threadIdx.x] : 0.0;
 }
 
 // out[j] = uv[idx[j]]: the caller-order pixels into point order / camera order (ba_set_problem)
@@ -325,13 +379,13 @@ __device__ inline void lin_finalize_sums(const double* __restrict__ a, const dou
   for (int q = 3; q < NB; ++q) b[q] = a[NH + q];
 }
 template <int NB>
-__device__ inline void lin_finalize_camera(const double* __restrict__ partL, const double* __restrict__ cam, int n_cams,
+__device__ inline void lin_finalize_camera(const double* __restrict__ partL, int nparts, const double* __restrict__ cam, int n_cams,
                                            int c, int fixed_cam, double* __restrict__ H, double* __restrict__ b) {
   constexpr int NL = NB * (NB + 1) / 2 + NB;
   double a[NL];
   for (int q = 0; q < NL; ++q) a[q] = 0.0;
   if (c != fixed_cam) {
-    for (int k = 0; k < NPART; ++k) {
+    for (int k = 0; k < nparts; ++k) {
       const double* src = partL + ((size_t)k * n_cams + c) * NL;
       for (int q = 0; q < NL; ++q) a[q] += src[q];
     }
@@ -341,11 +395,11 @@ __device__ inline void lin_finalize_camera(const double* __restrict__ partL, con
 // stand-alone form (multi-rank jobs all-reduce Hcc|bc between this and k_pcg_setup; test hook)
 template <int NB>
 __global__ void __launch_bounds__(VEC_BLOCK)
-k_lin_finalize(const double* __restrict__ partL, const double* __restrict__ cs, int n_cams, int fixed_cam,
+k_lin_finalize(const double* __restrict__ partL, int nparts, const double* __restrict__ cs, int n_cams, int fixed_cam,
                double* __restrict__ Hcc, double* __restrict__ bc) {
   const int c = vec_camera(n_cams);
   if (c >= n_cams) return;
-  lin_finalize_camera<NB>(partL, cs + CS * c, n_cams, c, fixed_cam, Hcc + (NB * (NB + 1) / 2) * (size_t)c, bc + NB * (size_t)c);
+  lin_finalize_camera<NB>(partL, nparts, cs + CS * c, n_cams, c, fixed_cam, Hcc + (NB * (NB + 1) / 2) * (size_t)c, bc + NB * (size_t)c);
 }
 
 // K4b: camera pass of the Schur product, pre-M:  part6[(k*Nc + c)*6 + ..] = sum Jc^T w (Jp y_p)
@@ -1066,8 +1120,8 @@ __device__ inline bool pcg_probe(int kit, const PcgState* __restrict__ st, const
 __global__ void __launch_bounds__(64)
 k_pcg_probe(int kit, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2, int min_iters,
             long long* __restrict__ host_flag, long long flag_base, double* __restrict__ verdict,
-            const double* __restrict__ partGc, int nGc, double* __restrict__ gmax_out) {
-  (void)pcg_probe(kit, st, partV, nblkV, tol2, min_iters, host_flag, flag_base, verdict, nullptr, 0, partGc, nGc, gmax_out);
+            const double* __restrict__ partG, int nG, const double* __restrict__ partGc, int nGc, double* __restrict__ gmax_out) {
+  (void)pcg_probe(kit, st, partV, nblkV, tol2, min_iters, host_flag, flag_base, verdict, partG, nG, partGc, nGc, gmax_out);
 }
 
 template <class CM, bool ROBUST, int MODE, bool ALL_LDS, int LANES, typename JT>
@@ -1333,8 +1387,8 @@ constexpr int slice_chunks(int doubles) { return (doubles + 127) / 128; }      /
 // or Jacobi preconditioner Minv = (Hccd - E)^-1, right-hand side g = -(bc - W y0), and the
 // (FINALIZE: first folds the fresh linearisation partials into Hcc | bc, single rank)
 // first PCG vectors: x = 0, r = g, z = Minv r, p = s = 0, vtil, gamma/zeta partials.
-// E / Wy0 come either as NPART partial sums (nparts = NPART) or already folded and
-// all-reduced (nparts = 1).  CM: the camera model (block size NB = 6 or 9, table row layout).
+// The partial sums (linearisation, E, Wy0) come either as NPART partitions (nparts = NPART) or already folded and
+// all-reduced in partition 0 (nparts = 1; the other partitions are stale then).  CM: the camera model (block size NB = 6 or 9, table row layout).
 template <class CM, bool FINALIZE>
 __global__ void __launch_bounds__(VEC_BLOCK)
 k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* __restrict__ bc, const double* __restrict__ part6,
@@ -1381,7 +1435,7 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
       const double* pe = partE + ((size_t)k * n_cams + c0) * NH;
       const double* pw = part6 + ((size_t)k * n_cams + c0) * NB;
 #pragma unroll
-      for (int j = 0; j < NA; ++j) { const int i = j * 64 + lane; ta[j] = (FINALIZE && i < la) ? pa[i] : 0.0; }
+      for (int j = 0; j < NA; ++j) { const int i = j * 64 + lane; ta[j] = (FINALIZE && k < nparts && i < la) ? pa[i] : 0.0; }
 #pragma unroll
       for (int j = 0; j < NE; ++j) { const int i = j * 64 + lane; te[j] = (use_schur_diag && k < nparts && i < le) ? pe[i] : 0.0; }
 #pragma unroll
@@ -1783,10 +1837,11 @@ __device__ inline void lm_decide(double* __restrict__ res, double cost_cur, doub
 // multi-rank form: the scalars are all-reduced between k_scalars and the decision; like k_scalars on a single rank,
 // the kernel mirrors the block into host-mapped memory and publishes the step's sequence word (one wave)
 __global__ void __launch_bounds__(64)
-k_decide(double* __restrict__ scal, double cost_cur, double lambda, double* __restrict__ scal_host,
-         long long* __restrict__ host_flag, long long seq) {
+k_decide(double* __restrict__ scal, const double* __restrict__ reduced6, double cost_cur, double lambda,
+         double* __restrict__ scal_host, long long* __restrict__ host_flag, long long seq) {
   __shared__ double res[S_COUNT];
-  if (threadIdx.x < S_COUNT) res[threadIdx.x] = scal[threadIdx.x];
+  // (reduced6: the six all-reduced sums arrived in the header of another message, k_fold_lin)
+  if (threadIdx.x < S_COUNT) res[threadIdx.x] = (reduced6 && threadIdx.x < 6) ? reduced6[threadIdx.x] : scal[threadIdx.x];
   __syncthreads();
   if (threadIdx.x == 0) lm_decide(res, cost_cur, lambda);
   __syncthreads();
@@ -1798,11 +1853,6 @@ k_decide(double* __restrict__ scal, double cost_cur, double lambda, double* __re
     __threadfence_system();
     if (threadIdx.x == 0) publish_flag(host_flag, seq, 0);
   }
-}
-// one device word into host-mapped memory (multi-rank: the all-reduced gradient maximum, read by the host at the
-// first PCG verdict -- no copy, no stream synchronise)
-__global__ void k_word_to_host(const double* __restrict__ src, double* __restrict__ dst_host) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) dst_host[0] = src[0];
 }
 
 __device__ void scalars_body(const ScalarsArgs& a) {
@@ -1877,15 +1927,6 @@ __device__ void scalars_body(const ScalarsArgs& a) {
 __global__ void __launch_bounds__(1024)
 k_scalars(ScalarsArgs a) { scalars_body(a); }
 
-// out[0] = max over two arrays of per-workgroup maxima (multi-rank gtol path; single wave)
-__global__ void __launch_bounds__(64)
-k_max_partials(const double* __restrict__ a, int na, const double* __restrict__ b, int nb, double* __restrict__ out) {
-  double m = 0.0;
-  for (int i = threadIdx.x; i < na; i += 64) m = nanmax(m, a[i]);
-  for (int i = threadIdx.x; i < nb; i += 64) m = nanmax(m, b[i]);
-  m = wave_nanmax(m);
-  if (threadIdx.x == 0) out[0] = m;
-}
 
 // test hook (BA_DEBUG_POISON_TRIAL): makes the trial cost of every LM step non-finite
 __global__ void k_poison(double* __restrict__ partR) {
