@@ -784,11 +784,12 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   // uniformly spread observations chunk k covers about the k-th eighth of the point table (what
   // keeps it resident in XCD k's L2); for band-structured data the chunks stay balanced and are
   // narrow in point index anyway.
-  // A rank of a multi-GPU job holds 1/world of every camera's observations: when that leaves fewer than 32 per
-  // (camera, partition) segment, the whole local list of a camera goes into partition 0 (the others stay empty and
-  // their partial sums zero).  The camera passes then work on segments of a useful length, and -- the point -- the
-  // partial sums come out already "folded": the fold kernels in front of every all-reduce (fold_and_reduce) disappear.
-  h->one_part = h->world > 1 && Nc > 0 && (long long)No / Nc / NPART < 32;
+  // BA_ONE_PART=1 (experiment, multi-rank only): the whole local list of a camera goes into partition 0, the others stay
+  // empty -- the partial sums then come out already "folded" and the fold kernels in front of the all-reduces
+  // (fold_and_reduce) disappear.  Measured on a rank's share of C3 with every collective issued (tools/shard_times.py):
+  // slower at every shard size (1/8 of the points: 240 against 182 us per LM iteration, 1/4: 279 against 184) -- a
+  // camera's list handled by ONE 16-lane row in the camera passes costs more than the 3 us fold it saves.  Off by default.
+  h->one_part = false;
   if (const char* e = getenv("BA_ONE_PART")) h->one_part = atoi(e) != 0 && h->multi;
   std::vector<int> offk((size_t)Nc * (NPART + 1));
   for (int c = 0; c < Nc; ++c) {

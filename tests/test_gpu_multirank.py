@@ -53,8 +53,8 @@ dist.destroy_process_group()
 
 @pytest.mark.parametrize("one_part", ["0", "1"])
 def test_two_ranks_on_one_gpu_match_single_rank(tmp_path, one_part):
-    """one_part = 1: every camera's shard-local observations in partition 0 (what thin shards of a many-rank job get
-    by themselves, ba_set_problem): partial sums come out folded, no fold kernel runs ahead of the all-reduces."""
+    """one_part = 1: every camera's shard-local observations in partition 0 (BA_ONE_PART, an experiment switch of
+    ba_set_problem): partial sums come out folded, no fold kernel runs ahead of the all-reduces."""
     from bundle_adjustment_amd import hip_backend
     from bundle_adjustment_amd.problem import shard_by_landmark
     from bundle_adjustment_amd.synthetic import make_problem
