@@ -17,6 +17,8 @@ python3 bench.py --jacobian f32 --no-cpu-baseline > $P/${TAG}_f32_bench.json 2>>
 python3 tools/solve_times.py C2 C3 C5 > $P/${TAG}_solve_times.txt 2>> $O/misc.err
 python3 tools/bal_solve_times.py > $P/${TAG}_bal_solve_times.txt 2>> $O/misc.err
 python3 tools/window_latency.py > $P/${TAG}_window_latency.txt 2>> $O/misc.err
+python3 tools/shard_times.py 1 2 4 8 > $P/${TAG}_shard_times.txt 2>> $O/misc.err
+python3 tools/bal_like_times.py 1000 100000 450000 > $P/${TAG}_bal_like_times.txt 2>> $O/misc.err
 python3 tools/run_end_to_end.py C3 > $P/${TAG}_end_to_end_c3.txt 2>> $O/misc.err
 for f in $P/${TAG}_*bench.json; do python3 - $f <<'PY'
 import json, sys
@@ -26,4 +28,4 @@ print(sys.argv[1].split("/")[-1], d["value"], "LM it/s", d["config"]["pcg_iterat
       "|", r["kernel"], r["mean_launch_us"], "us frac", r["frac"], "iter frac", r["lm_iteration"]["frac"])
 PY
 done
-cat $P/${TAG}_solve_times.txt $P/${TAG}_bal_solve_times.txt $P/${TAG}_window_latency.txt; tail -8 $P/${TAG}_end_to_end_c3.txt
+cat $P/${TAG}_shard_times.txt $P/${TAG}_bal_like_times.txt $P/${TAG}_solve_times.txt $P/${TAG}_bal_solve_times.txt $P/${TAG}_window_latency.txt; tail -8 $P/${TAG}_end_to_end_c3.txt
