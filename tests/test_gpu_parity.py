@@ -409,3 +409,34 @@ def test_camera_windows_that_do_not_fit_in_lds_follow_the_oracle(solver):
         assert abs(t["cost_trial"] - h["cost_new"]) <= 1e-7 * h["cost_new"], (t, h)
         assert bool(t["accepted"]) == bool(h["rho"] > 0)
     assert abs(out["final_cost"] - ref["cost"]) <= 1e-7 * ref["cost"]
+
+
+@pytest.mark.parametrize("long_slots", [None, "3"])
+def test_chain_with_long_tracks_and_camera_windows_follows_the_oracle(monkeypatch, long_slots):
+    """A 1300-camera chain with BAL-like track lengths (median 3, up to ~80): the camera table exceeds LDS, every workgroup
+    stages its own window of cameras, tracks longer than 8 observations run as 16-lane rows behind the 2-lane ranges in the
+    same launch.  long_slots = 3: the long-track workgroups walk three rounds of 64 points each (BA_LONG_SLOTS; what
+    ba_set_problem chooses by itself when one-round workgroups would not all be resident, config 5).  Same LM trajectory
+    as the oracle either way, and the two grids agree to rounding."""
+    from bundle_adjustment_amd import hip_backend
+    from bundle_adjustment_amd.synthetic import make_bal_like
+    if long_slots is not None:
+        monkeypatch.setenv("BA_LONG_SLOTS", long_slots)
+    p = make_bal_like(1300, 9000, 40000, seed=5)
+    # (three LM iterations: from the fourth on the chain's inner solves take ~100 PCG iterations, over which two
+    # implementations' rounding separates the iterates by more than a trajectory comparison tolerates)
+    kw = dict(max_iters=3, ftol=0.0, xtol=0.0, gtol=0.0, pcg_tol=1e-2, pcg_max_iters=300)
+    ref = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, fixed_cam=0, loss="huber", **kw)
+    with hip_backend.Solver(0) as s:
+        s.set_problem(p)
+        r, sse, _ = s.residuals("huber")
+        assert np.abs(r - o.residuals(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4)).max() <= 1e-9
+        out = s.solve(loss="huber", pcg_min_iters=0, **kw)
+        tr = s.trace()
+    assert out["iterations"] == len(ref["history"]) == 3
+    for t, h in zip(tr, ref["history"]):
+        assert abs(t["pcg_iterations"] - h["pcg"]) <= max(1, 0.1 * h["pcg"]), (t, h)
+        assert abs(t["cost_trial"] - h["cost_new"]) <= 1e-6 * h["cost_new"], (t, h)
+        assert bool(t["accepted"]) == bool(h["rho"] > 0)
+    assert abs(out["final_cost"] - ref["cost"]) <= 1e-6 * ref["cost"]
+
