@@ -34,6 +34,7 @@
 #include "ba_triangulate.hpp"
 #include "ba_coarse.hpp"
 #include "ba_small.hpp"
+#include "ba_small_mw.hpp"
 
 using namespace ba;
 
@@ -194,6 +195,8 @@ struct ba_handle {
   DBuf<double> intr[2];        // per-camera intrinsics (f, k1, k2) of the BAL model, current / trial like cams[]
   DBuf<double> small_V, small_gS;   // k_small_lm: V = W L (49 x 3 Np_pad, zero where unwritten), per-wave partial V V^T
   int small_np_pad = -1;
+  // k_small_mw (ba_small_mw.hpp): the window solver on mw_G workgroups; mw_ok: this problem fits its limits
+  DBuf<int> mw_woff; DBuf<double> mw_buf; bool mw_ok = false; int mw_G = 0;
   // two-level preconditioner for band-structured problems (ba_coarse.hpp): structures built by ba_set_problem
   bool two_level_ok = false;   // this problem has them
   bool two_level = false;      // the current solve uses them
@@ -364,6 +367,7 @@ extern "C" int ba_destroy(ba_handle* h) {
   h->st.release();
   h->tri.release();
   h->small_V.release();
+  h->mw_woff.release(); h->mw_buf.release();
   h->intr[0].release(); h->intr[1].release();
   h->small_gS.release();
   h->small_np_pad = -1;
@@ -941,6 +945,30 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(upload(h->blk_win.p, win.data(), win.size() * sizeof(int2)));
   HIPCHECK(h->long_pts.alloc(std::max(h->n_long, 1)));
   if (h->n_long) HIPCHECK(upload(h->long_pts.p, long_pts.data(), h->n_long * sizeof(int)));
+  // the multi-workgroup window solver (ba_small_mw.hpp): five cameras at most, 129 .. 512 landmarks in ranges of 64, no
+  // landmark seen twice by one camera; every camera's list is ascending in landmark index, so a range is a slice of it
+  h->mw_ok = false;
+  if (!h->multi && Nc <= MW_MAX_CAMS && Np >= MW_MIN_PTS && Np <= MW_MAX_WG * MW_PTS && No > 0) {
+    bool dup = false;
+    for (int p = 0; p < Np && !dup; ++p) {
+      unsigned seen = 0;
+      for (int j = pt_off[p]; j < pt_off[p + 1]; ++j) { if ((seen >> p_cam[j]) & 1u) { dup = true; break; } seen |= 1u << p_cam[j]; }
+    }
+    if (!dup) {
+      h->mw_G = (Np + MW_PTS - 1) / MW_PTS;
+      std::vector<int> woff((size_t)(h->mw_G + 1) * MW_MAX_CAMS, 0);
+      for (int c = 0; c < MW_MAX_CAMS; ++c)
+        for (int gq = 0; gq <= h->mw_G; ++gq) {
+          int v = No;
+          if (c < Nc) v = (int)(std::lower_bound(c_pt.begin() + cam_off[c], c_pt.begin() + cam_off[c + 1], gq * MW_PTS) - c_pt.begin());
+          woff[(size_t)gq * MW_MAX_CAMS + c] = v;
+        }
+      HIPCHECK(h->mw_woff.alloc(woff.size()));
+      HIPCHECK(upload(h->mw_woff.p, woff.data(), woff.size() * sizeof(int)));
+      HIPCHECK(h->mw_buf.alloc((size_t)2 * MW_MAX_WG * (MW_MSG + MW_SCAL) + 8));
+      h->mw_ok = true;
+    }
+  }
   HIPCHECK(h->c_pt.alloc(nobs1)); HIPCHECK(h->c_orig.alloc(nobs1)); HIPCHECK(h->p_cam.alloc(nobs1));
   HIPCHECK(h->c_uv.alloc(nobs1)); HIPCHECK(h->p_uv.alloc(nobs1));
   HIPCHECK(h->c_w[0].alloc(nobs1)); HIPCHECK(h->c_w[1].alloc(nobs1)); HIPCHECK(h->p_w[0].alloc(nobs1)); HIPCHECK(h->p_w[1].alloc(nobs1));
@@ -1690,7 +1718,16 @@ static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   h->profile = opts->profile != 0;
   A.stamps = getenv("BA_SMALL_STAMPS") ? (long long*)(h->small_gS.p + (size_t)SMALL_WAVES * SMALL_TILES * 256) : nullptr;   // device memory: a host store would stall the wave
   A.seq = ++h->small_seq;
-  {
+  const char* mw_env = getenv("BA_SMALL_MW");           // BA_SMALL_MW=0: always the one-workgroup kernel
+  if (h->mw_ok && (!mw_env || atoi(mw_env) != 0)) {        // several workgroups: 64 landmarks each, two exchanges per LM iteration (ba_small_mw.hpp)
+    MwArgs M;
+    M.A = A; M.woff = h->mw_woff.p; M.G = h->mw_G;
+    M.slots = h->mw_buf.p; M.sslots = h->mw_buf.p + (size_t)2 * MW_MAX_WG * MW_MSG;
+    M.ctr = (unsigned long long*)(h->mw_buf.p + (size_t)2 * MW_MAX_WG * (MW_MSG + MW_SCAL));
+    HIPCHECK(hipMemsetAsync(M.ctr, 0, sizeof(unsigned long long), h->stream));
+    Scope sc(h, BA_K_MISC);
+    BA_LAUNCH(k_small_mw, dim3(h->mw_G), dim3(MW_THREADS), 0, h->stream, M);
+  } else {
     Scope sc(h, BA_K_MISC);
     BA_LAUNCH(k_small_lm, dim3(1), dim3(SMALL_THREADS), 0, h->stream, A);
   }
@@ -1700,6 +1737,7 @@ static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   memcpy(sum, h->h_small, sizeof(ba_summary));
   if (h->profile) flush_profile(h);
   h->profile = false;
+  if (sum->status == BA_ERR_HIP) return fail(BA_ERR_HIP, "k_small_mw: a workgroup was not served at a barrier (bounded spin ran out)");
   if (sum->status == BA_ERR_NUMERIC)
     return fail(BA_ERR_NUMERIC, sum->iterations == 0 ? "non-finite cost at the initial parameters"
                                                      : "non-finite cost / gradient during the solve (LM iteration %d)", sum->iterations);

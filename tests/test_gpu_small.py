@@ -79,6 +79,12 @@ def _with_duplicates(p, n_dup, seed):
     (6, 700, 4, "linear", 9),       # 36 + 1 rows: 3 tile rows; more points than threads
     (7, 256, 5, "huber", 0),        # 42 + 1 rows
     (8, 513, 6, "linear", 0),       # 48 + 1 rows: the z row alone in tile row 3
+    # five cameras at most, 129 .. 1024 landmarks, no repeated pairs: the multi-workgroup kernel (ba_small_mw.hpp)
+    (5, 129, 4, "huber", 0),        # 3 workgroups, the last one with a single landmark
+    (4, 512, 3, "linear", 0),       # 8 full workgroups
+    (5, 1000, 5, "huber", 0),       # 16 workgroups, every landmark seen by every camera
+    (3, 700, 2, "linear", 0),       # 11 workgroups, 18 + 1 rows
+    (2, 300, 2, "huber", 0),        # 12 + 1 rows, one adjustable camera
 ])
 def test_small_solver_follows_the_oracles_dense_lm_step_by_step(n_cams, n_pts, k, loss, dups):
     """Every LM iteration of k_small_lm against the oracle's LM with the explicit reduced system solved exactly
@@ -204,3 +210,32 @@ def test_small_solver_on_a_reused_handle_with_fewer_landmarks():
         assert abs(t["cost_trial"] - h["cost_new"]) <= 1e-9 * h["cost_new"], (t, h)
         assert bool(t["accepted"]) == bool(h["rho"] > 0)
     assert abs(got["final_cost"] - ref["cost"]) <= 1e-9 * ref["cost"]
+
+
+@pytest.mark.parametrize("n_cams,n_pts,k,fixed", [(5, 500, 4, 0), (5, 777, 3, 2), (4, 130, 4, 3)])
+def test_multi_workgroup_window_solver_agrees_with_the_single_workgroup_one(monkeypatch, n_cams, n_pts, k, fixed):
+    """k_small_mw (several workgroups, two exchanges per LM iteration) against k_small_lm (BA_SMALL_MW=0) on the same
+    handle and problem: same iteration count, verdicts and damping, costs to 1e-10 relative (the partial sums are
+    grouped by workgroup instead of by wave), parameters to 1e-9; the multi-workgroup result repeats bit for bit.
+    fixed = 2 / 3: the held camera in the middle / at the end."""
+    p = make_problem(n_cams, n_pts, k, seed=40 + n_pts, outlier_frac=0.02)
+    p = type(p)(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, fixed)
+    kw = dict(loss="huber", max_iters=8, ftol=0.0, xtol=0.0, gtol=0.0)
+    res = {}
+    with hip_backend.Solver(0) as s:
+        for mode in ("1", "0", "1"):
+            monkeypatch.setenv("BA_SMALL_MW", mode)
+            s.set_problem(p)
+            out = s.solve(**kw)
+            res.setdefault(mode, []).append((out, s.trace(), s.get_params()))
+    (o1, t1, (c1, x1)), (o1b, _, (c1b, x1b)) = res["1"]
+    (o0, t0, (c0, x0)), = res["0"]
+    assert o1["pcg_iterations"] == 0 and o1["iterations"] == o0["iterations"] == 8
+    assert o1["final_cost"] == o1b["final_cost"] and np.array_equal(c1, c1b) and np.array_equal(x1, x1b)
+    for a, b in zip(t1, t0):
+        assert a["accepted"] == b["accepted"]
+        assert abs(a["cost_trial"] - b["cost_trial"]) <= 1e-10 * b["cost_trial"]
+        assert abs(a["damping"] - b["damping"]) <= 1e-7 * b["damping"]
+    assert abs(o1["final_cost"] - o0["final_cost"]) <= 1e-10 * o0["final_cost"]
+    assert np.abs(c1 - c0).max() <= 1e-9 * max(1.0, np.abs(c0).max()) and np.abs(x1 - x0).max() <= 1e-9 * max(1.0, np.abs(x0).max())
+
