@@ -945,10 +945,12 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(upload(h->blk_win.p, win.data(), win.size() * sizeof(int2)));
   HIPCHECK(h->long_pts.alloc(std::max(h->n_long, 1)));
   if (h->n_long) HIPCHECK(upload(h->long_pts.p, long_pts.data(), h->n_long * sizeof(int)));
-  // the multi-workgroup window solver (ba_small_mw.hpp): five cameras at most, 129 .. 512 landmarks in ranges of 64, no
+  // the multi-workgroup window solver (ba_small_mw.hpp): five cameras at most, up to 2048 landmarks in ranges of 64, no
   // landmark seen twice by one camera; every camera's list is ascending in landmark index, so a range is a slice of it
   h->mw_ok = false;
-  if (!h->multi && Nc <= MW_MAX_CAMS && Np >= MW_MIN_PTS && Np <= MW_MAX_WG * MW_PTS && No > 0) {
+  const char* mw_min_env = getenv("BA_SMALL_MW_MIN");            // (tuning: smallest landmark count that goes to k_small_mw)
+  const int mw_min_pts = mw_min_env ? std::max(1, atoi(mw_min_env)) : MW_MIN_PTS;
+  if (!h->multi && Nc <= MW_MAX_CAMS && Np >= mw_min_pts && Np <= MW_MAX_WG * MW_PTS && No > 0) {
     bool dup = false;
     for (int p = 0; p < Np && !dup; ++p) {
       unsigned seen = 0;

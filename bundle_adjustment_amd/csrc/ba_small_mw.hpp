@@ -1,6 +1,6 @@
 // The window solver of ba_small.hpp on SEVERAL workgroups of one launch, for the reference's default window
 // (BundleAdjuster(window_size=5), src/pipeline.py:39,99: five keyframes, a few hundred landmarks).  One LM iteration of
-// k_small_lm is ~62 us on one compute unit, every phase a handful of dependent round trips; here G <= 16 workgroups each
+// k_small_lm is ~62 us on one compute unit, every phase a handful of dependent round trips; here G <= 32 workgroups each
 // own 64 consecutive landmarks:
 //
 //   C1   camera half of the normal equations over the workgroup's SLICE of every camera's observation list (the lists
@@ -21,14 +21,14 @@
 // and the barrier is one agent-scope counter (1.1 - 1.5 us).  Every spin is bounded: a workgroup that is not served
 // leaves with BA_ERR_HIP instead of hanging the device.  All sums keep a fixed order (lanes, waves, workgroups).
 //
-// Limits (checked by the host, else k_small_lm runs): Nc <= 5, 64 (G - 1) < Np <= 64 G with 3 <= G <= 16, no landmark observed
+// Limits (checked by the host, else k_small_lm runs): Nc <= 5, 64 (G - 1) < Np <= 64 G with G <= 32, no landmark observed
 // twice by one camera (so a track has at most Nc <= 8 observations: one per lane), single rank.
 #pragma once
 #include "ba_small.hpp"
 
 namespace ba {
 
-constexpr int MW_MAX_WG = 16;
+constexpr int MW_MAX_WG = 32;
 constexpr int MW_PTS = 64;                         // landmarks per workgroup
 constexpr int MW_LPP = 8;                          // lanes per landmark
 constexpr int MW_THREADS = MW_PTS * MW_LPP;        // 512
@@ -41,7 +41,7 @@ constexpr int MW_SLAB = MW_VR * 16;                // doubles per slab
 constexpr int MW_SYRK_WAVES = 4;                   // waves that multiply (3 slabs each)
 constexpr int MW_MSG = MW_N * (MW_N + 1) / 2 + 3 * MW_N + 1 + 4;     // 560 words at most (layout below, by the run-time n)
 constexpr int MW_SCAL = 8;
-constexpr int MW_MIN_PTS = 2 * MW_PTS + 1;         // fewer landmarks: one or two workgroups' worth -- k_small_lm
+constexpr int MW_MIN_PTS = 1;                     // (measured: no slower than k_small_lm even with one or two workgroups)
 constexpr int MW_SPIN_LIMIT = 1 << 20;
 
 struct MwArgs {
@@ -112,12 +112,20 @@ k_small_mw(MwArgs M) {
     if (!barrier()) return false;
     const double* all = slots + (size_t)xpar * G * stride;
     for (int i = tid; i < len; i += MW_THREADS) {
-      double v[MW_MAX_WG];
+      double a = 0.0;                                    // (sums start from +0: every partial of a maximum is >= 0 as well)
+      for (int q0 = 0; q0 < G; q0 += 8) {                // eight loads in flight, added in workgroup order
+        double v[8];
 #pragma unroll
-      for (int q = 0; q < MW_MAX_WG; ++q) v[q] = q < G ? __hip_atomic_load(all + (size_t)q * stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-      double a = v[0];
-      if (i == max_at) { for (int q = 1; q < MW_MAX_WG; ++q) a = nanmax(a, v[q]); }
-      else { for (int q = 1; q < MW_MAX_WG; ++q) a += v[q]; }
+        for (int q = 0; q < 8; ++q)
+          v[q] = q0 + q < G ? __hip_atomic_load(all + (size_t)(q0 + q) * stride + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        if (i == max_at) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) a = nanmax(a, v[q]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) a += v[q];
+        }
+      }
       dst[i] = a;
     }
     xpar ^= 1;

@@ -79,12 +79,13 @@ def _with_duplicates(p, n_dup, seed):
     (6, 700, 4, "linear", 9),       # 36 + 1 rows: 3 tile rows; more points than threads
     (7, 256, 5, "huber", 0),        # 42 + 1 rows
     (8, 513, 6, "linear", 0),       # 48 + 1 rows: the z row alone in tile row 3
-    # five cameras at most, 129 .. 1024 landmarks, no repeated pairs: the multi-workgroup kernel (ba_small_mw.hpp)
+    # five cameras at most, 129 .. 2048 landmarks, no repeated pairs: the multi-workgroup kernel (ba_small_mw.hpp)
     (5, 129, 4, "huber", 0),        # 3 workgroups, the last one with a single landmark
     (4, 512, 3, "linear", 0),       # 8 full workgroups
     (5, 1000, 5, "huber", 0),       # 16 workgroups, every landmark seen by every camera
     (3, 700, 2, "linear", 0),       # 11 workgroups, 18 + 1 rows
     (2, 300, 2, "huber", 0),        # 12 + 1 rows, one adjustable camera
+    (5, 1531, 4, "huber", 0),       # 24 workgroups, 6124 observations: just under the dispatch limit of the window solver
 ])
 def test_small_solver_follows_the_oracles_dense_lm_step_by_step(n_cams, n_pts, k, loss, dups):
     """Every LM iteration of k_small_lm against the oracle's LM with the explicit reduced system solved exactly
