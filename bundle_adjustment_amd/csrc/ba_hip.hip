@@ -1721,7 +1721,8 @@ static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   A.stamps = getenv("BA_SMALL_STAMPS") ? (long long*)(h->small_gS.p + (size_t)SMALL_WAVES * SMALL_TILES * 256) : nullptr;   // device memory: a host store would stall the wave
   A.seq = ++h->small_seq;
   const char* mw_env = getenv("BA_SMALL_MW");           // BA_SMALL_MW=0: always the one-workgroup kernel
-  if (h->mw_ok && (!mw_env || atoi(mw_env) != 0)) {        // several workgroups: 64 landmarks each, two exchanges per LM iteration (ba_small_mw.hpp)
+  const bool used_mw = h->mw_ok && (!mw_env || atoi(mw_env) != 0);
+  if (used_mw) {        // several workgroups: 64 landmarks each, two exchanges per LM iteration (ba_small_mw.hpp)
     MwArgs M;
     M.A = A; M.woff = h->mw_woff.p; M.G = h->mw_G;
     M.slots = h->mw_buf.p; M.sslots = h->mw_buf.p + (size_t)2 * MW_MAX_WG * MW_MSG;
@@ -1748,7 +1749,14 @@ static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     memcpy(h->trace.data(), h->h_small + off_trace, sizeof(ba_iter_record) * (size_t)sum->iterations);
   }
   memcpy(&h->cur, h->h_small + off_cur, sizeof(int));
-  if (A.stamps) {
+  if (A.stamps && used_mw) {
+    long long st[16];
+    HIPCHECK(hipMemcpy(st, A.stamps, sizeof st, hipMemcpyDeviceToHost));
+    static const char* names[] = {"C1 camera half (slices)", "P1 point half + V (8 lanes / landmark)", "G  [V;z][V;z]^T (MFMA, LDS) + message",
+                                  "exchange 1 (barrier + gather)", "S, g", "elimination + back substitution", "camera update + P2", "C3 trial cost (slices)", "exchange 2"};
+    for (int k = 0; k < 9; ++k) fprintf(stderr, "[k_small_mw, LM iteration 2, workgroup 0] %-40s %7.2f us\n", names[k], (st[k + 1] - st[k]) * 0.01);
+    fprintf(stderr, "[k_small_mw] elimination %.2f us, back substitution %.2f us\n", (st[13] - st[12]) * 0.01, (st[6] - st[13]) * 0.01);
+  } else if (A.stamps) {
     long long st[16];
     HIPCHECK(hipMemcpy(st, A.stamps, sizeof st, hipMemcpyDeviceToHost));
     static const char* names[] = {"C1 camera half", "P1 point half + V", "G  [V;z][V;z]^T (MFMA)", "S, g from the tiles", "Cholesky + solves (1 wave)",

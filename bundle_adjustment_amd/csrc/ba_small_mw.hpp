@@ -60,6 +60,8 @@ __device__ inline double mw_allreduce8(double x) {     // sum over the 8 lanes o
   return x;
 }
 
+#define MW_STAMP(k) do { if (A.stamps && g == 0 && tid == 0 && s_it == 1) A.stamps[k] = (long long)wall_clock64(); } while (0)
+
 __global__ void __launch_bounds__(MW_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_small_mw(MwArgs M) {
   const SmallArgs& A = M.A;
@@ -69,8 +71,9 @@ k_small_mw(MwArgs M) {
   __shared__ double l_cam[2][MW_MAX_CAMS][6];
   __shared__ double l_Hccp[MW_MAX_CAMS][27];                               // this workgroup's share of Hcc | bc
   __shared__ double l_msg[MW_MSG];
-  __shared__ double l_S[MW_N][MW_N + 1];
-  __shared__ double l_g[MW_N], l_dc[MW_N], l_bc[MW_N], l_dH[MW_N];
+  __shared__ unsigned short l_ij[MW_MSG];             // (i | j << 8) of message word t < nS + n: built once
+  __shared__ double l_S[MW_N][MW_N + 3];             // [S | g]; odd row stride: a column is read without bank conflicts
+  __shared__ double l_dc[MW_N], l_bc[MW_N], l_dH[MW_N];
   __shared__ double l_red[MW_WAVES * 8], l_tot[8], l_camred[MW_MAX_CAMS][4], l_wcost[MW_WAVES][2], l_sc[MW_SCAL];
   __shared__ double s_lambda, s_cost, s_sse, s_cost_new, s_sse_new, s_gmax, s_nu;
   __shared__ int s_cur, s_stop, s_it, s_acc, s_status, s_ok;
@@ -147,6 +150,16 @@ k_small_mw(MwArgs M) {
     camera_state(&l_cam[A.cur][tid][0], &l_cs[A.cur][tid][0]);
   }
   for (int i = tid; i < MW_SLABS * MW_SLAB; i += MW_THREADS) l_V[i] = 0.0;
+  for (int t = tid; t < nS + n; t += MW_THREADS) {      // row-major upper triangle, then column n (V z)
+    int i, j;
+    if (t < nS) {
+      i = 0;
+      int base = 0;
+      while (base + (n - i) <= t) { base += n - i; ++i; }
+      j = i + (t - base);
+    } else { i = t - nS; j = n; }
+    l_ij[t] = (unsigned short)(i | (j << 8));
+  }
   if (tid == 0) { s_cur = A.cur; s_lambda = A.lambda0; s_nu = 2.0; s_stop = 0; s_it = 0; s_acc = 0; s_status = 0; }
   __syncthreads();
 
@@ -208,6 +221,7 @@ k_small_mw(MwArgs M) {
   while (!s_stop) {
     const int cur = s_cur, tr = 1 - cur;
     const double lambda = s_lambda;
+    MW_STAMP(0);
     if (need_lin) {
       // ---- C1: camera half over the workgroup's slices (post-M rows, as k_small_lm)
       if (wv < Nc) {
@@ -244,6 +258,7 @@ k_small_mw(MwArgs M) {
         }
       }
     }
+    MW_STAMP(1);
     // ---- P1: eight lanes per landmark
     double gmp = 0.0;
     {
@@ -306,6 +321,7 @@ k_small_mw(MwArgs M) {
     gmp = wave_nanmax(gmp);
     if (lane == 0) l_red[wv] = gmp;
     __syncthreads();                                     // V image, l_Hccp, l_red complete
+    MW_STAMP(2);
     // ---- G: [V; z][V; z]^T of the workgroup's 192 columns, waves 0 .. 3 take slabs w, w + 4, w + 8
     if (wv < MW_SYRK_WAVES) {
       small_d4 acc[3];
@@ -333,13 +349,7 @@ k_small_mw(MwArgs M) {
     for (int t = tid; t < msg_len; t += MW_THREADS) {
       double out;
       if (t < nS + n) {
-        int i, j;
-        if (t < nS) {                                    // row-major upper triangle: find i with i n - i (i - 1) / 2 <= t
-          i = 0;
-          int base = 0;
-          while (base + (n - i) <= t) { base += n - i; ++i; }
-          j = i + (t - base);
-        } else { i = t - nS; j = n; }
+        const int i = l_ij[t] & 0xff, j = l_ij[t] >> 8;
         const int ti = i >> 4, tj = j >> 4, ri = i & 15, rj = j & 15;
         const double* ps = l_part + (size_t)(tj * (tj + 1) / 2 + ti) * 256 + 4 * (rj + 16 * (ri & 3)) + (ri >> 2);
         double vv = 0.0;
@@ -361,76 +371,77 @@ k_small_mw(MwArgs M) {
       l_msg[t] = out;
     }
     __syncthreads();
+    MW_STAMP(3);
     // ---- exchange 1
     if (!exchange(M.slots, MW_MSG, l_msg, msg_len, l_msg, msg_len - 1)) { give_up(); return; }
+    MW_STAMP(4);
     // ---- S, g (every workgroup the same): damping from the summed diagonal; fixed camera: identity rows / columns
-    for (int t = tid; t < n * n; t += MW_THREADS) {
-      const int i = t / n, j = t % n, ci = i / 6, cj = j / 6;
-      const int a = i < j ? i : j, b = i < j ? j : i;
-      double v = l_msg[a * n - a * (a - 1) / 2 + (b - a)];
+    for (int t = tid; t < nS; t += MW_THREADS) {         // both triangles from the message's upper one
+      const int i = l_ij[t] & 0xff, j = l_ij[t] >> 8, ci = i / 6, cj = j / 6;
+      double v = l_msg[t];
       if (i == j) v += lambda * fmax(l_msg[nS + 2 * n + i], DIAG_FLOOR);
       if (ci == A.fixed_cam || cj == A.fixed_cam) v = (i == j) ? 1.0 : 0.0;
       l_S[i][j] = v;
+      l_S[j][i] = v;
     }
     if (tid < n) {
       const int i = tid, ci = i / 6;
       l_bc[i] = l_msg[nS + n + i];
       l_dH[i] = l_msg[nS + 2 * n + i];
-      l_g[i] = (ci == A.fixed_cam) ? 0.0 : -(l_msg[nS + n + i] - l_msg[nS + i]);
+      l_S[i][n] = (ci == A.fixed_cam) ? 0.0 : -(l_msg[nS + n + i] - l_msg[nS + i]);     // right-hand side g: the augmented column
     }
     __syncthreads();
-    if (need_lin && tid == 0) {
-      double m = l_msg[msg_len - 1];
-      for (int i = 0; i < n; ++i) m = nanmax(m, fabs(l_bc[i]));
-      s_gmax = m;
-      if (!isfinite(m)) { s_stop = 1; s_status = -4; }
-      else if (A.gtol > 0 && m <= A.gtol) { s_stop = 1; s_status = 3; }
+    if (need_lin && wv == 0) {                           // max |gradient| = max(max |bp| over the workgroups, max |bc|)
+      double m = lane < n ? fabs(l_bc[lane]) : 0.0;
+      if (lane == 0) m = nanmax(m, l_msg[msg_len - 1]);
+      m = wave_nanmax(m);
+      if (lane == 0) {
+        s_gmax = m;
+        if (!isfinite(m)) { s_stop = 1; s_status = -4; }
+        else if (A.gtol > 0 && m <= A.gtol) { s_stop = 1; s_status = 3; }
+      }
     }
     __syncthreads();
     if (s_stop) break;
-    // ---- Cholesky and both triangular solves in wave 0 (lane = row, the row of L in registers; see k_small_lm)
-    if (wv == 0) {
-      double row[MW_N];
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      const int li = ln < n ? ln : 0;
-#pragma unroll
-      for (int k = 0; k < MW_N; ++k) row[k] = k < n ? l_S[li][k] : 0.0;
-#pragma unroll
-      for (int j = 0; j < MW_N; ++j) {
-        if (j < n) {
-          double sa[4] = {row[j], 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int k = 0; k < j; ++k) sa[k & 3] -= row[k] * readlane_f64(row[k], j);
-          const double sacc = (sa[0] + sa[1]) + (sa[2] + sa[3]);
-          const double d = fmax(readlane_f64(sacc, j), DIAG_FLOOR);
-          double inv = __builtin_amdgcn_rsq(d);
-          inv = inv * (1.5 - 0.5 * d * inv * inv);
-          inv = inv * (1.5 - 0.5 * d * inv * inv);
-          row[j] = ln == j ? inv : sacc * inv;
-        }
+    MW_STAMP(5);
+    // ---- S dc = g.  Gauss-Jordan elimination on the augmented [S | g] in LDS, ALL waves: step k subtracts
+    //      (S[i][k] / S[k][k]) x row k from every OTHER row i -- (n - 1)(n - k) independent updates, one or two per
+    //      thread, a workgroup barrier per step; what is left is a diagonal system.  (k_small_lm factors in one wave, lane = row, 3 j instructions for
+    //      column j: 10 us of its 62 us iteration; with the rest of the iteration spread over G workgroups that would
+    //      be a third of the time here.)  S is symmetric positive definite: no pivoting, pivots floored like the
+    //      Cholesky's diagonal.
+    MW_STAMP(12);
+    {
+      // a thread owns elements (ia, ja) and (ib, ja) for the whole elimination: rows tid / 32 and 16 + tid / 32, column
+      // tid % 32 (column n = the right-hand side), kept in registers and stored after every step (the next step's pivot
+      // row and column are read by everybody).  Every read of a step is unconditional (clamped addresses) and issued
+      // before the first use: one LDS round trip per step.
+      const int ja = tid & 31, ia = tid >> 5, ib = 16 + (tid >> 5);
+      const bool col_ok = ja <= n;
+      const int jc = col_ok ? ja : n, iac = ia < n ? ia : n - 1, ibc = ib < n ? ib : n - 1;
+      double va = l_S[iac][jc], vb = l_S[ibc][jc];
+      for (int k = 0; k < n; ++k) {
+        if (k / 6 == A.fixed_cam) continue;               // identity rows and columns of the held camera: nothing to eliminate
+        const double piv0 = l_S[k][k], u = l_S[k][jc], la = l_S[iac][k], lb = l_S[ibc][k];
+        const double piv = fmax(piv0, DIAG_FLOOR);
+        double rp = __builtin_amdgcn_rcp(piv);
+        rp = rp * (2.0 - piv * rp);
+        rp = rp * (2.0 - piv * rp);
+        const bool act = col_ok && ja > k;
+        if (act && ia != k && ia < n) { va -= (la * rp) * u; l_S[ia][ja] = va; }
+        if (act && ib != k && ib < n) { vb -= (lb * rp) * u; l_S[ib][ja] = vb; }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS only: nothing else is in flight here
       }
-#pragma unroll
-      for (int k = 0; k < MW_N; ++k)
-        if (k < n && ln < n) l_S[ln][k] = row[k];
-      double b = ln < n ? l_g[ln] : 0.0, y = 0.0, x = 0.0;
-#pragma unroll
-      for (int j = 0; j < MW_N; ++j) {
-        if (j < n) {
-          const double yj = readlane_f64(b, j) * readlane_f64(row[j], j);
-          if (ln == j) y = yj;
-          else if (ln > j) b -= row[j] * yj;
-        }
-      }
-      for (int j = n - 1; j >= 0; --j) {
-        const double lji = ln < j ? l_S[j][ln] : 0.0;
-        const double xj = readlane_f64(y, j) * l_S[j][j];
-        if (ln == j) x = xj;
-        y -= lji * xj;
-      }
-      if (lane < n) l_dc[lane] = x;
+    }
+    MW_STAMP(13);
+    // every row is reduced to its diagonal element and the right-hand side (Gauss-Jordan: the rows ABOVE a pivot were
+    // swept in the same steps by threads that would have idled)
+    if (tid < n) {
+      const double dg = fmax(l_S[tid][tid], DIAG_FLOOR);
+      l_dc[tid] = l_S[tid][n] / dg;
     }
     __syncthreads();
+    MW_STAMP(6);
     // ---- camera update + camera-side scalars (every workgroup the same)
     if (tid < Nc) {
       const int c = tid;
@@ -478,9 +489,12 @@ k_small_mw(MwArgs M) {
     small_block_sum<4>(ps, l_red, l_sc);                 // l_sc[0 .. 3]
     __threadfence_block();
     __syncthreads();                                     // trial points visible to the slice cost pass
+    MW_STAMP(7);
     slice_cost(tr);                                      // l_sc[4], l_sc[5]
+    MW_STAMP(8);
     // ---- exchange 2: the step's scalars; then the verdict, the same in every workgroup
     if (!exchange(M.sslots, MW_SCAL, l_sc, 6, l_tot, -1)) { give_up(); return; }
+    MW_STAMP(9);
     if (tid == 0) {
       double gTd = l_tot[0], dDd = l_tot[1], step2 = l_tot[2], x2 = l_tot[3];
       for (int c = 0; c < Nc; ++c) { gTd += l_camred[c][0]; dDd += l_camred[c][1]; step2 += l_camred[c][2]; x2 += l_camred[c][3]; }
