@@ -42,7 +42,7 @@ constexpr int MW_SYRK_WAVES = 4;                   // waves that multiply (3 sla
 constexpr int MW_MSG = MW_N * (MW_N + 1) / 2 + 3 * MW_N + 1 + 4;     // 560 words at most (layout below, by the run-time n)
 constexpr int MW_SCAL = 8;
 constexpr int MW_MIN_PTS = 1;                     // (measured: no slower than k_small_lm even with one or two workgroups)
-constexpr int MW_SPIN_LIMIT = 1 << 20;
+constexpr int MW_SPIN_LIMIT = 1 << 24;         // (seconds: only a workgroup that is never scheduled gets there)
 
 struct MwArgs {
   SmallArgs A;
