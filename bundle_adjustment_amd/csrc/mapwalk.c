@@ -18,6 +18,7 @@
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -390,12 +391,88 @@ done:
   return result;
 }
 
+/*
+ * rvecs_from_matrices(R[f64, n x 9], out[f64, n x 3]) -> number converted, or -1 (no exception) when a matrix is singular
+ * (the caller then takes the SVD route).  What cv2.Rodrigues(matrix) does (src/bundle_adjuster.py:157): project onto the
+ * nearest orthogonal matrix -- the polar factor U V^T, here by Newton's iteration Q <- (Q + Q^-T) / 2 (a fixed point for a
+ * matrix that already is a rotation) -- then the logarithm, with OpenCV's branch near theta = pi.  A window has five of
+ * them: numpy's batched SVD plus a dozen small array operations cost more than the rest of the packing.
+ */
+static int polar3(const double *R, double *Q) {
+  memcpy(Q, R, 9 * sizeof(double));
+  for (int it = 0; it < 60; ++it) {
+    double C[9];                                   /* cofactors: C = det(Q) Q^-T */
+    C[0] = Q[4] * Q[8] - Q[5] * Q[7]; C[1] = Q[5] * Q[6] - Q[3] * Q[8]; C[2] = Q[3] * Q[7] - Q[4] * Q[6];
+    C[3] = Q[2] * Q[7] - Q[1] * Q[8]; C[4] = Q[0] * Q[8] - Q[2] * Q[6]; C[5] = Q[1] * Q[6] - Q[0] * Q[7];
+    C[6] = Q[1] * Q[5] - Q[2] * Q[4]; C[7] = Q[2] * Q[3] - Q[0] * Q[5]; C[8] = Q[0] * Q[4] - Q[1] * Q[3];
+    const double det = Q[0] * C[0] + Q[1] * C[1] + Q[2] * C[2];
+    if (!(det != 0.0) || det != det) return -1;
+    double delta = 0.0, scale = 0.0;
+    for (int q = 0; q < 9; ++q) {
+      const double v = 0.5 * (Q[q] + C[q] / det);
+      const double d = v > Q[q] ? v - Q[q] : Q[q] - v, a = v > 0 ? v : -v;
+      if (d > delta) delta = d;
+      if (a > scale) scale = a;
+      Q[q] = v;
+    }
+    if (delta <= 4e-16 * scale) return 0;
+  }
+  return 0;
+}
+static PyObject *rvecs_from_matrices(PyObject *self, PyObject *args) {
+  PyObject *o_in, *o_out;
+  if (!PyArg_ParseTuple(args, "OO", &o_in, &o_out)) return NULL;
+  Py_buffer b_in, b_out;
+  if (PyObject_GetBuffer(o_in, &b_in, PyBUF_C_CONTIGUOUS) < 0) return NULL;
+  if (get_out(o_out, &b_out, sizeof(double), "out") < 0) { PyBuffer_Release(&b_in); return NULL; }
+  PyObject *result = NULL;
+  if (b_in.itemsize != (Py_ssize_t)sizeof(double) || b_in.len % (9 * (Py_ssize_t)sizeof(double)) != 0 ||
+      b_out.len / 3 != b_in.len / 9) {
+    PyErr_SetString(PyExc_ValueError, "rvecs_from_matrices: (n, 3, 3) and (n, 3) float64 arrays expected");
+    goto done;
+  }
+  {
+    const Py_ssize_t n = b_in.len / (9 * (Py_ssize_t)sizeof(double));
+    const double *R = (const double *)b_in.buf;
+    double *out = (double *)b_out.buf;
+    long converted = 0;
+    for (Py_ssize_t k = 0; k < n; ++k, ++converted) {
+      double Q[9];
+      if (polar3(R + 9 * k, Q) < 0) { converted = -1; break; }
+      const double a0 = Q[7] - Q[5], a1 = Q[2] - Q[6], a2 = Q[3] - Q[1];
+      const double s = sqrt((a0 * a0 + a1 * a1 + a2 * a2) * 0.25);
+      double c = (Q[0] + Q[4] + Q[8] - 1.0) * 0.5;
+      c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+      const double theta = acos(c);
+      double *o = out + 3 * k;
+      o[0] = o[1] = o[2] = 0.0;
+      if (s >= 1e-5) {
+        const double f = theta / (2.0 * s);
+        o[0] = a0 * f; o[1] = a1 * f; o[2] = a2 * f;
+      } else if (!(c > 0)) {                       /* theta ~ pi: axis from the diagonal */
+        double rx = sqrt(fmax((Q[0] + 1.0) * 0.5, 0.0));
+        double ry = sqrt(fmax((Q[4] + 1.0) * 0.5, 0.0)) * (Q[1] < 0 ? -1.0 : 1.0);
+        double rz = sqrt(fmax((Q[8] + 1.0) * 0.5, 0.0)) * (Q[2] < 0 ? -1.0 : 1.0);
+        if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && ((Q[5] > 0) != (ry * rz > 0))) rz = -rz;
+        const double nv = sqrt(rx * rx + ry * ry + rz * rz);
+        if (nv > 0) { o[0] = rx * theta / nv; o[1] = ry * theta / nv; o[2] = rz * theta / nv; }
+      }
+    }
+    result = PyLong_FromLong(converted);
+  }
+done:
+  PyBuffer_Release(&b_in);
+  PyBuffer_Release(&b_out);
+  return result;
+}
+
 static PyMethodDef methods[] = {
   {"walk_window", walk_window, METH_VARARGS, "walk a keyframe window into flat observation arrays"},
   {"gather_positions", gather_positions, METH_VARARGS, "copy MapPoint.position of the given ids into (n,3)"},
   {"scatter_positions", scatter_positions, METH_VARARGS, "write rows of (n,3) into MapPoint.position in place where it is a (3,1) float64 array"},
   {"rebind_positions", rebind_positions, METH_VARARGS, "map_points[ids[i]].position = views[i] (a fresh (3,1) array per landmark, as the reference)"},
   {"count_present", count_present, METH_VARARGS, "how many of the ids are keys of the map-point dict"},
+  {"rvecs_from_matrices", rvecs_from_matrices, METH_VARARGS, "rotation matrices (n,3,3) -> rotation vectors (n,3), cv2.Rodrigues semantics"},
   {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_mapwalk", "native walk over Map objects", -1, methods};

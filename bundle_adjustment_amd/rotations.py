@@ -15,8 +15,17 @@ _EPS = float(np.finfo(np.float64).eps)
 
 
 def matrices_to_rvecs(Rs):
-    """(N,3,3) -> (N,3)."""
-    Rs = np.asarray(Rs, dtype=np.float64).reshape(-1, 3, 3)
+    """(N,3,3) -> (N,3).  A handful of matrices (a window's keyframes) go through the native walk extension (the same
+    projection by Newton's polar iteration instead of an SVD, the same branches); many, or singular ones, through numpy."""
+    Rs = np.ascontiguousarray(np.asarray(Rs, dtype=np.float64).reshape(-1, 3, 3))
+    if 0 < Rs.shape[0] <= 64:
+        try:
+            from . import _mapwalk
+            out = np.empty((Rs.shape[0], 3))
+            if _mapwalk.rvecs_from_matrices(Rs, out) == Rs.shape[0]:
+                return out
+        except (ImportError, AttributeError):
+            pass
     U, _, Vt = np.linalg.svd(Rs)
     Q = U @ Vt
     a = np.stack([Q[:, 2, 1] - Q[:, 1, 2], Q[:, 0, 2] - Q[:, 2, 0], Q[:, 1, 0] - Q[:, 0, 1]], axis=1)
