@@ -34,7 +34,7 @@ import numpy as np
 from . import hip_backend
 from .map_structures import Map
 from .parameters import DEBUG_DIRS
-from .problem import BAProblem, WindowCache, extract_shard, flatten_map_window, gather_window, shard_by_landmark
+from .problem import BAProblem, WindowCache, extract_shard, flatten_map_window_ids, gather_window, shard_by_landmark
 from .rotations import matrices_to_rvecs
 
 
@@ -190,8 +190,8 @@ class BundleAdjuster:
         if self._window is not None:
             prob, local_map_point_ids, token = self._window.flatten(gmap, local_kf_ids, self.camera_matrix)
         else:
-            prob, ids_list = flatten_map_window(gmap, local_kf_ids, self.camera_matrix)
-            local_map_point_ids, token = np.asarray(ids_list, dtype=np.int64), None
+            prob, local_map_point_ids = flatten_map_window_ids(gmap, local_kf_ids, self.camera_matrix)
+            token = None
         if len(local_map_point_ids) == 0:
             print("    -> LBA Skipped: No points in the local window.")
             return

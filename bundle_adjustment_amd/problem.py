@@ -145,23 +145,29 @@ def flatten_map_window_numpy(gmap, local_kf_ids, camera_matrix):
 
 
 def flatten_map_window(gmap, local_kf_ids, camera_matrix):
+    """``flatten_map_window_ids`` with the sorted map-point ids as a list (the reference's ``local_map_point_ids``)."""
+    prob, mp_ids = flatten_map_window_ids(gmap, local_kf_ids, camera_matrix)
+    return prob, mp_ids.tolist()
+
+
+def flatten_map_window_ids(gmap, local_kf_ids, camera_matrix):
     """``gather_window`` + ``flatten_window`` in one pass: same ``BAProblem`` (same row order, same
     last-pixel-wins rule for a repeated ``(keyframe, map point)`` pair) plus the sorted map-point
-    ids.  The walk over the Map objects runs in the ``_mapwalk`` C extension (``csrc/mapwalk.c``,
+    ids (int64 array).  The walk over the Map objects runs in the ``_mapwalk`` C extension (``csrc/mapwalk.c``,
     built by ``__graft_entry__.build()``); what is left here is array work on its outputs.  Used by
     ``BundleAdjuster.run``; the tuple/dict form stays available through ``_gather_local_data``."""
     from . import _mapwalk
     keyframes, have = gmap.keyframes, gmap.map_points
     cap = sum(len(keyframes[k].observations) for k in local_kf_ids)
     if cap == 0:
-        return None, []
+        return None, np.empty(0, dtype=np.int64)
     cam_idx = np.empty(cap, dtype=np.int32)
     first_seen = np.empty(cap, dtype=np.int64)
     uv = np.empty((cap, 2), dtype=np.float64)
     distinct = np.empty(cap, dtype=np.int64)
     nobs, npts = _mapwalk.walk_window(keyframes, have, list(local_kf_ids), cam_idx, first_seen, uv, distinct)
     if nobs == 0:
-        return None, []
+        return None, np.empty(0, dtype=np.int64)
     distinct = distinct[:npts]
     order = np.argsort(distinct, kind="stable")          # map-point ids ascending (:210 sorted(...))
     rank = np.empty(npts, dtype=np.int32)
@@ -171,7 +177,7 @@ def flatten_map_window(gmap, local_kf_ids, camera_matrix):
     _mapwalk.gather_positions(have, mp_ids, pts)
     cams, K4 = _window_cameras(gmap, local_kf_ids, camera_matrix)
     prob = BAProblem(cams, pts, cam_idx[:nobs], rank[first_seen[:nobs]], uv[:nobs], K4, fixed_cam=0).validate()
-    return prob, mp_ids.tolist()
+    return prob, mp_ids
 
 
 def shard_by_landmark(problem: BAProblem, n_shards: int):
@@ -250,7 +256,7 @@ class WindowCache:
                  and w["lens"] == lens and (w["all_present"] or w["n_have"] == len(have))
                  and _mapwalk.count_present(have, w["mp_ids"]) == w["mp_ids"].shape[0])
         if not reuse:
-            prob, ids_list = flatten_map_window(gmap, local_kf_ids, camera_matrix)
+            prob, mp_ids = flatten_map_window_ids(gmap, local_kf_ids, camera_matrix)
             self.hits["walked"] += len(kfs)
             if prob is None:
                 self.window = None
@@ -258,7 +264,7 @@ class WindowCache:
             self.tokens += 1
             self.window = dict(ids=list(local_kf_ids), kfs=kfs, lists=lists, lens=lens, n_have=len(have),
                                all_present=(prob.n_obs == sum(lens)), cam_idx=prob.cam_idx, pt_idx=prob.pt_idx, uv=prob.uv,
-                               mp_ids=np.asarray(ids_list, dtype=np.int64), token=self.tokens)
+                               mp_ids=mp_ids, token=self.tokens)
             return prob, self.window["mp_ids"], self.tokens
         self.hits["window"] += 1
         mp_ids = w["mp_ids"]
