@@ -176,7 +176,8 @@ def flatten_map_window_ids(gmap, local_kf_ids, camera_matrix):
     pts = np.empty((npts, 3), dtype=np.float64)
     _mapwalk.gather_positions(have, mp_ids, pts)
     cams, K4 = _window_cameras(gmap, local_kf_ids, camera_matrix)
-    prob = BAProblem(cams, pts, cam_idx[:nobs], rank[first_seen[:nobs]], uv[:nobs], K4, fixed_cam=0).validate()
+    # (indices come out of the walk itself; hip_backend.set_problem and ba_set_problem both check ranges again)
+    prob = BAProblem(cams, pts, cam_idx[:nobs], rank[first_seen[:nobs]], uv[:nobs], K4, fixed_cam=0)
     return prob, mp_ids
 
 
