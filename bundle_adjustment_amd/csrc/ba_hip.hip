@@ -1727,7 +1727,6 @@ static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     M.A = A; M.woff = h->mw_woff.p; M.G = h->mw_G;
     M.slots = h->mw_buf.p; M.sslots = h->mw_buf.p + (size_t)2 * MW_MAX_WG * MW_MSG;
     M.ctr = (unsigned long long*)(h->mw_buf.p + (size_t)2 * MW_MAX_WG * (MW_MSG + MW_SCAL));
-    HIPCHECK(hipMemsetAsync(M.ctr, 0, sizeof(unsigned long long), h->stream));
     Scope sc(h, BA_K_MISC);
     BA_LAUNCH(k_small_mw, dim3(h->mw_G), dim3(MW_THREADS), 0, h->stream, M);
   } else {

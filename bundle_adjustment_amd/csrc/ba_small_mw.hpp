@@ -50,7 +50,7 @@ struct MwArgs {
   int G;
   double* slots;                   // [2][G][MW_MSG]   exchange 1, double-buffered by parity
   double* sslots;                  // [2][G][MW_SCAL]  exchange 2
-  unsigned long long* ctr;         // barrier counter, zero at launch
+  unsigned long long* ctr;         // barrier counter; every launch counts from (its sequence number << 32): no clearing between launches
 };
 
 __device__ inline double mw_allreduce8(double x) {     // sum over the 8 lanes of a landmark, the same bits in all of them
@@ -88,6 +88,10 @@ k_small_mw(MwArgs M) {
   const int p = g * MW_PTS + pl;
   const bool have_p = p < Np;
   int xpar = 0;                                      // parity of the next exchange (both kinds share the counter)
+  // the counter of this launch starts at (sequence number << 32): whichever workgroup comes first raises it there (an
+  // idempotent maximum: later ones find it at or above), so no launch has to clear what the previous one left
+  const unsigned long long ctr_base = (unsigned long long)A.seq << 32;
+  if (tid == 0) __hip_atomic_fetch_max(M.ctr, ctr_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   unsigned long long bar = 0;                        // barriers passed
 
   // counter barrier: everything this workgroup stored (agent-scope atomic stores) is visible to whoever passes it
@@ -95,7 +99,7 @@ k_small_mw(MwArgs M) {
     __syncthreads();
     if (tid == 0) {
       __hip_atomic_fetch_add(M.ctr, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long target = (bar + 1) * (unsigned long long)G;
+      const unsigned long long target = ctr_base + (bar + 1) * (unsigned long long)G;
       int spins = 0, ok = 1;
       while (__hip_atomic_load(M.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
