@@ -1701,10 +1701,12 @@ static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   A.Hpp = h->Hpp[h->pb].p; A.bp = h->bp[h->pb].p; A.Lf = h->Hppinv[h->pb].p; A.y0 = h->y0[h->pb].p;
   A.Np_pad = (h->Np + 15) & ~15;
   A.Kp = 3 * A.Np_pad;
-  if (h->small_np_pad != A.Np_pad) {                      // columns of padding points and rows past 6 Nc stay zero for good
-    const size_t nv = (size_t)SMALL_VROWS * A.Kp;
+  const char* mw_env = getenv("BA_SMALL_MW");           // BA_SMALL_MW=0: always the one-workgroup kernel
+  const bool used_mw = h->mw_ok && (!mw_env || atoi(mw_env) != 0);
+  HIPCHECK(h->small_gS.alloc((size_t)SMALL_WAVES * SMALL_TILES * 256 + 16));        // + 16 words of diagnostic stamps
+  if (!used_mw && h->small_np_pad != A.Np_pad) {          // columns of padding points and rows past 6 Nc stay zero for good
+    const size_t nv = (size_t)SMALL_VROWS * A.Kp;         // (k_small_mw keeps its columns of V in LDS: nothing to clear)
     HIPCHECK(h->small_V.alloc(nv));
-    HIPCHECK(h->small_gS.alloc((size_t)SMALL_WAVES * SMALL_TILES * 256 + 16));      // + 16 words of diagnostic stamps
     HIPCHECK(hipMemsetAsync(h->small_V.p, 0, nv * sizeof(double), h->stream));
     h->small_np_pad = A.Np_pad;
   }
@@ -1720,8 +1722,6 @@ static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   h->profile = opts->profile != 0;
   A.stamps = getenv("BA_SMALL_STAMPS") ? (long long*)(h->small_gS.p + (size_t)SMALL_WAVES * SMALL_TILES * 256) : nullptr;   // device memory: a host store would stall the wave
   A.seq = ++h->small_seq;
-  const char* mw_env = getenv("BA_SMALL_MW");           // BA_SMALL_MW=0: always the one-workgroup kernel
-  const bool used_mw = h->mw_ok && (!mw_env || atoi(mw_env) != 0);
   if (used_mw) {        // several workgroups: 64 landmarks each, two exchanges per LM iteration (ba_small_mw.hpp)
     MwArgs M;
     M.A = A; M.woff = h->mw_woff.p; M.G = h->mw_G;
