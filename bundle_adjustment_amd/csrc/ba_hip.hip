@@ -1680,7 +1680,11 @@ extern "C" int ba_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
 // system instead of PCG.  Same options, summary and trace as the multi-kernel path.
 static bool small_applies(const ba_handle* h, const ba_options* opts) {
   static const long max_obs = [] { const char* e = getenv("BA_SMALL_MAX_OBS"); return e ? atol(e) : (long)SMALL_DEFAULT_MAX_OBS; }();
-  return opts->small_solver == 0 && !h->multi && h->Nc <= SMALL_MAX_CAMS && h->Np > 0 && h->Nobs > 0 && h->Nobs <= max_obs &&
+  // (the observation limit is the measured crossover of the ONE-workgroup kernel with the multi-kernel path; a window that
+  // fits the multi-workgroup kernel -- five cameras, 2048 landmarks: at most 10 k observations -- is far below its own)
+  const char* mw_env = getenv("BA_SMALL_MW");
+  const bool mw = h->mw_ok && (!mw_env || atoi(mw_env) != 0);
+  return opts->small_solver == 0 && !h->multi && h->Nc <= SMALL_MAX_CAMS && h->Np > 0 && h->Nobs > 0 && (h->Nobs <= max_obs || mw) &&
          opts->max_iters >= 1 && getenv("BA_NO_SMALL_SOLVER") == nullptr;
 }
 static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
