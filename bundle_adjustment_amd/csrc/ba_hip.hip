@@ -1413,6 +1413,7 @@ static int fold_and_reduce(ba_handle* h, double* parts, size_t n_per_part, doubl
 static int exchange_partL(ba_handle* h, int buf, bool with_scalars = false) {
   if (!h->multi) return BA_OK;
   const size_t n = nl_of(h) * (size_t)h->Nc;
+  HIPCHECK(h->linmsg[buf].alloc(8 + n));           // (sized in ba_set_problem; a communicator that joined after it: here)
   {
     Scope sc(h, BA_K_MISC);
     BA_LAUNCH(k_fold_lin, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, with_scalars ? (const double*)h->scal.p : (const double*)nullptr,
@@ -1432,6 +1433,7 @@ static int exchange_system(ba_handle* h, bool with_diag) {
   if (!h->multi) return BA_OK;
   h->sys_diag = with_diag;
   const size_t n6 = nb_of(h) * (size_t)h->Nc, nE = sys_nE(h);
+  HIPCHECK(h->sysmsg.alloc(2 + n6 + nE + (size_t)h->world + 8));
   {
     Scope sc(h, BA_K_MISC);
     BA_LAUNCH(k_fold_msg, dim3((unsigned)((n6 + nE + 255) / 256)), dim3(256), 0, h->stream, (const double*)uy_ptr(h),
