@@ -945,7 +945,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(upload(h->blk_win.p, win.data(), win.size() * sizeof(int2)));
   HIPCHECK(h->long_pts.alloc(std::max(h->n_long, 1)));
   if (h->n_long) HIPCHECK(upload(h->long_pts.p, long_pts.data(), h->n_long * sizeof(int)));
-  // the multi-workgroup window solver (ba_small_mw.hpp): five cameras at most, up to 2048 landmarks in ranges of 64, no
+  // the multi-workgroup window solver (ba_small_mw.hpp): eight cameras at most, up to 2048 landmarks in ranges of 64, no
   // landmark seen twice by one camera; every camera's list is ascending in landmark index, so a range is a slice of it
   h->mw_ok = false;
   const char* mw_min_env = getenv("BA_SMALL_MW_MIN");            // (tuning: smallest landmark count that goes to k_small_mw)
@@ -1734,7 +1734,10 @@ static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     M.slots = h->mw_buf.p; M.sslots = h->mw_buf.p + (size_t)2 * MW_MAX_WG * MW_MSG;
     M.ctr = (unsigned long long*)(h->mw_buf.p + (size_t)2 * MW_MAX_WG * (MW_MSG + MW_SCAL));
     Scope sc(h, BA_K_MISC);
-    BA_LAUNCH(k_small_mw, dim3(h->mw_G), dim3(MW_THREADS), 0, h->stream, M);
+    // instantiated per number of 16-row tiles of [V; z]: 6 Nc + 1 rows
+    if (h->Nc <= 5)      BA_LAUNCH(k_small_mw<2>, dim3(h->mw_G), dim3(MW_THREADS), 0, h->stream, M);
+    else if (h->Nc <= 7) BA_LAUNCH(k_small_mw<3>, dim3(h->mw_G), dim3(MW_THREADS), 0, h->stream, M);
+    else                 BA_LAUNCH(k_small_mw<4>, dim3(h->mw_G), dim3(MW_THREADS), 0, h->stream, M);
   } else {
     Scope sc(h, BA_K_MISC);
     BA_LAUNCH(k_small_lm, dim3(1), dim3(SMALL_THREADS), 0, h->stream, A);

@@ -1,5 +1,5 @@
-// The window solver of ba_small.hpp on SEVERAL workgroups of one launch, for the reference's default window
-// (BundleAdjuster(window_size=5), src/pipeline.py:39,99: five keyframes, a few hundred landmarks).  One LM iteration of
+// The window solver of ba_small.hpp on SEVERAL workgroups of one launch, for the reference's windows
+// (BundleAdjuster(window_size=5), src/pipeline.py:39,99: five keyframes, a few hundred landmarks; up to eight keyframes).  One LM iteration of
 // k_small_lm is ~62 us on one compute unit, every phase a handful of dependent round trips; here G <= 32 workgroups each
 // own 64 consecutive landmarks:
 //
@@ -21,8 +21,9 @@
 // and the barrier is one agent-scope counter (1.1 - 1.5 us).  Every spin is bounded: a workgroup that is not served
 // leaves with BA_ERR_HIP instead of hanging the device.  All sums keep a fixed order (lanes, waves, workgroups).
 //
-// Limits (checked by the host, else k_small_lm runs): Nc <= 5, 64 (G - 1) < Np <= 64 G with G <= 32, no landmark observed
-// twice by one camera (so a track has at most Nc <= 8 observations: one per lane), single rank.
+// Limits (checked by the host, else k_small_lm runs): Nc <= 8 (instantiated for two, three and four 16-row tiles of [V; z]:
+// up to 5 / 7 / 8 cameras), 64 (G - 1) < Np <= 64 G with G <= 32, no landmark observed twice by one camera (so a track has at
+// most Nc <= 8 observations: one per lane), single rank.
 #pragma once
 #include "ba_small.hpp"
 
@@ -33,13 +34,22 @@ constexpr int MW_PTS = 64;                         // landmarks per workgroup
 constexpr int MW_LPP = 8;                          // lanes per landmark
 constexpr int MW_THREADS = MW_PTS * MW_LPP;        // 512
 constexpr int MW_WAVES = MW_THREADS / 64;
-constexpr int MW_MAX_CAMS = 5;
-constexpr int MW_N = 6 * MW_MAX_CAMS;              // 30: with the z row 31 <= 32 = two 16-row tiles
-constexpr int MW_VR = 32;                          // rows of the LDS image of V
+constexpr int MW_MAX_CAMS = SMALL_MAX_CAMS;        // 8
+// The kernel is instantiated per number of 16-row tiles NT of [V; z]: 2 (up to 5 cameras: 30 + 1 rows), 3 (6 or 7 cameras),
+// 4 (8 cameras: 48 rows and the z row alone in the fourth tile) -- what sizes the LDS images.
+template <int NT> struct MwDim {
+  static constexpr int NMAX = NT == 2 ? 30 : (NT == 3 ? 42 : 48);            // largest 6 Nc with 6 Nc + 1 <= 16 NT
+  static constexpr int VR = 16 * NT;                                         // rows of the LDS image of V
+  static constexpr int SLAB = VR * 16;                                       // doubles per 16-column slab
+  static constexpr int NTILE = NT > 3 ? 9 : NT * (NT + 1) / 2;               // upper tiles (the z row's own square is not needed)
+  static constexpr int SYRK_WAVES = NT > 3 ? 2 : 4;                          // waves that multiply (LDS for their partial tiles)
+  static constexpr int MSG = NMAX * (NMAX + 1) / 2 + 3 * NMAX + 1;           // words of exchange 1
+  static constexpr int SROW = NMAX + 3;                                      // row stride of [S | g]: odd, a column reads conflict-free
+  static constexpr int POOL = (SYRK_WAVES * NTILE * 256 > NMAX * SROW) ? SYRK_WAVES * NTILE * 256 : NMAX * SROW;
+  static constexpr int EROWS = (NMAX + 7) / 8;                               // elements a thread owns in the elimination
+};
 constexpr int MW_SLABS = 3 * MW_PTS / 16;          // 12 slabs of 16 columns
-constexpr int MW_SLAB = MW_VR * 16;                // doubles per slab
-constexpr int MW_SYRK_WAVES = 4;                   // waves that multiply (3 slabs each)
-constexpr int MW_MSG = MW_N * (MW_N + 1) / 2 + 3 * MW_N + 1 + 4;     // 560 words at most (layout below, by the run-time n)
+constexpr int MW_MSG = MwDim<4>::MSG + 3;          // stride of a workgroup's slot in the exchange buffer (any NT)
 constexpr int MW_SCAL = 8;
 constexpr int MW_MIN_PTS = 1;                     // (measured: no slower than k_small_lm even with one or two workgroups)
 constexpr int MW_SPIN_LIMIT = 1 << 24;         // (seconds: only a workgroup that is never scheduled gets there)
@@ -62,17 +72,23 @@ __device__ inline double mw_allreduce8(double x) {     // sum over the 8 lanes o
 
 #define MW_STAMP(k) do { if (A.stamps && g == 0 && tid == 0 && s_it == 1) A.stamps[k] = (long long)wall_clock64(); } while (0)
 
+template <int NT>
 __global__ void __launch_bounds__(MW_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_small_mw(MwArgs M) {
+  using D = MwDim<NT>;
+  constexpr int MW_N = D::NMAX, MW_SLAB = D::SLAB, MW_SYRK_WAVES = D::SYRK_WAVES, NTILE = D::NTILE, SROW = D::SROW;
   const SmallArgs& A = M.A;
-  __shared__ __align__(16) double l_V[MW_SLABS * MW_SLAB];                 // 48 KB: [slab][row][16 columns]
-  __shared__ __align__(16) double l_part[MW_SYRK_WAVES * 3 * 256];         // 24 KB: partial tiles of the multiplying waves
+  __shared__ __align__(16) double l_V[MW_SLABS * MW_SLAB];                 // [slab][row][16 columns]: 48 / 72 / 96 KB
+  // one pool for two images that are never alive together: the multiplying waves' partial tiles (product -> message)
+  // and the augmented [S | g] (after exchange 1 -> step)
+  __shared__ __align__(16) double l_pool[D::POOL];
+  double* const l_part = l_pool;
+  double (*const l_S)[SROW] = (double (*)[SROW])l_pool;
   __shared__ double l_cs[2][MW_MAX_CAMS][CS];
   __shared__ double l_cam[2][MW_MAX_CAMS][6];
   __shared__ double l_Hccp[MW_MAX_CAMS][27];                               // this workgroup's share of Hcc | bc
-  __shared__ double l_msg[MW_MSG];
-  __shared__ unsigned short l_ij[MW_MSG];             // (i | j << 8) of message word t < nS + n: built once
-  __shared__ double l_S[MW_N][MW_N + 3];             // [S | g]; odd row stride: a column is read without bank conflicts
+  __shared__ double l_msg[D::MSG];
+  __shared__ unsigned short l_ij[D::MSG];            // (i | j << 8) of message word t < nS + n: built once
   __shared__ double l_dc[MW_N], l_bc[MW_N], l_dH[MW_N];
   __shared__ double l_red[MW_WAVES * 8], l_tot[8], l_camred[MW_MAX_CAMS][4], l_wcost[MW_WAVES][2], l_sc[MW_SCAL];
   __shared__ double s_lambda, s_cost, s_sse, s_cost_new, s_sse_new, s_gmax, s_nu;
@@ -326,26 +342,33 @@ k_small_mw(MwArgs M) {
     if (lane == 0) l_red[wv] = gmp;
     __syncthreads();                                     // V image, l_Hccp, l_red complete
     MW_STAMP(2);
-    // ---- G: [V; z][V; z]^T of the workgroup's 192 columns, waves 0 .. 3 take slabs w, w + 4, w + 8
+    // ---- G: [V; z][V; z]^T of the workgroup's 192 columns; the multiplying waves take slabs w, w + W, ...
     if (wv < MW_SYRK_WAVES) {
-      small_d4 acc[3];
+      small_d4 acc[NTILE];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) acc[q] = (small_d4){0.0, 0.0, 0.0, 0.0};
+      for (int q = 0; q < NTILE; ++q) acc[q] = (small_d4){0.0, 0.0, 0.0, 0.0};
       const double* vrow = l_V + (lane & 15) * 16 + 4 * (lane >> 4);
 #pragma unroll
       for (int u = 0; u < MW_SLABS / MW_SYRK_WAVES; ++u) {
         const int sl = wv + MW_SYRK_WAVES * u;
-        const small_d4 a0 = *(const small_d4*)(vrow + MW_SLAB * sl), a1 = *(const small_d4*)(vrow + MW_SLAB * sl + 256);
+        small_d4 a[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a[t] = *(const small_d4*)(vrow + MW_SLAB * sl + 256 * t);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], a0[e], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[e], a1[e], acc[1], 0, 0, 0);
-          acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[e], a1[e], acc[2], 0, 0, 0);
+#pragma unroll
+          for (int tj = 0; tj < NT; ++tj) {
+#pragma unroll
+            for (int ti = 0; ti <= tj; ++ti) {
+              if (NT > 3 && ti == 3) continue;
+              acc[tj * (tj + 1) / 2 + ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ti][e], a[tj][e], acc[tj * (tj + 1) / 2 + ti], 0, 0, 0);
+            }
+          }
         }
       }
-      small_d4* out = (small_d4*)l_part + (size_t)(wv * 3) * 64 + lane;
+      small_d4* out = (small_d4*)l_part + (size_t)(wv * NTILE) * 64 + lane;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) out[q * 64] = acc[q];
+      for (int q = 0; q < NTILE; ++q) out[q * 64] = acc[q];
     }
     __syncthreads();
     // ---- this workgroup's message: element (i, j), i <= j, of blockdiag(Hcc_g) - (V V^T)_g | (V z)_g | bc_g | diag Hcc_g | max |bp|
@@ -358,7 +381,7 @@ k_small_mw(MwArgs M) {
         const double* ps = l_part + (size_t)(tj * (tj + 1) / 2 + ti) * 256 + 4 * (rj + 16 * (ri & 3)) + (ri >> 2);
         double vv = 0.0;
 #pragma unroll
-        for (int w = 0; w < MW_SYRK_WAVES; ++w) vv += ps[(size_t)w * 3 * 256];
+        for (int w = 0; w < MW_SYRK_WAVES; ++w) vv += ps[(size_t)w * NTILE * 256];
         out = (j == n) ? vv : -vv;
         if (j < n && i / 6 == j / 6) out += l_Hccp[i / 6][U6(i % 6, j % 6)];
       } else if (t < nS + 2 * n) {
@@ -416,24 +439,34 @@ k_small_mw(MwArgs M) {
     //      Cholesky's diagonal.
     MW_STAMP(12);
     {
-      // a thread owns elements (ia, ja) and (ib, ja) for the whole elimination: rows tid / 32 and 16 + tid / 32, column
-      // tid % 32 (column n = the right-hand side), kept in registers and stored after every step (the next step's pivot
-      // row and column are read by everybody).  Every read of a step is unconditional (clamped addresses) and issued
-      // before the first use: one LDS round trip per step.
-      const int ja = tid & 31, ia = tid >> 5, ib = 16 + (tid >> 5);
+      // a thread owns column ja = tid % 64 (column n = the right-hand side) of rows tid / 64 + 8 r, r = 0 .. EROWS - 1, for
+      // the whole elimination, kept in registers and stored after every step (the next step's pivot row and column are
+      // read by everybody).  Every read of a step is unconditional (clamped addresses) and issued before the first use:
+      // one LDS round trip per step.
+      constexpr int ER = D::EROWS;
+      const int ja = tid & 63, i0 = tid >> 6;
       const bool col_ok = ja <= n;
-      const int jc = col_ok ? ja : n, iac = ia < n ? ia : n - 1, ibc = ib < n ? ib : n - 1;
-      double va = l_S[iac][jc], vb = l_S[ibc][jc];
+      const int jc = col_ok ? ja : n;
+      int ic[ER];
+      double va[ER];
+#pragma unroll
+      for (int r = 0; r < ER; ++r) { const int i = i0 + 8 * r; ic[r] = i < n ? i : n - 1; va[r] = l_S[ic[r]][jc]; }
       for (int k = 0; k < n; ++k) {
         if (k / 6 == A.fixed_cam) continue;               // identity rows and columns of the held camera: nothing to eliminate
-        const double piv0 = l_S[k][k], u = l_S[k][jc], la = l_S[iac][k], lb = l_S[ibc][k];
+        const double piv0 = l_S[k][k], u = l_S[k][jc];
+        double lk[ER];
+#pragma unroll
+        for (int r = 0; r < ER; ++r) lk[r] = l_S[ic[r]][k];
         const double piv = fmax(piv0, DIAG_FLOOR);
         double rp = __builtin_amdgcn_rcp(piv);
         rp = rp * (2.0 - piv * rp);
         rp = rp * (2.0 - piv * rp);
         const bool act = col_ok && ja > k;
-        if (act && ia != k && ia < n) { va -= (la * rp) * u; l_S[ia][ja] = va; }
-        if (act && ib != k && ib < n) { vb -= (lb * rp) * u; l_S[ib][ja] = vb; }
+#pragma unroll
+        for (int r = 0; r < ER; ++r) {
+          const int i = i0 + 8 * r;
+          if (act && i != k && i < n) { va[r] -= (lk[r] * rp) * u; l_S[i][ja] = va[r]; }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // LDS only: nothing else is in flight here
       }
     }

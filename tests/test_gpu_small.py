@@ -79,7 +79,7 @@ def _with_duplicates(p, n_dup, seed):
     (6, 700, 4, "linear", 9),       # 36 + 1 rows: 3 tile rows; more points than threads
     (7, 256, 5, "huber", 0),        # 42 + 1 rows
     (8, 513, 6, "linear", 0),       # 48 + 1 rows: the z row alone in tile row 3
-    # five cameras at most, 129 .. 2048 landmarks, no repeated pairs: the multi-workgroup kernel (ba_small_mw.hpp)
+    # no repeated pairs, up to 2048 landmarks: the multi-workgroup kernel (ba_small_mw.hpp; the 7- and 8-camera rows above too)
     (5, 129, 4, "huber", 0),        # 3 workgroups, the last one with a single landmark
     (4, 512, 3, "linear", 0),       # 8 full workgroups
     (5, 1000, 5, "huber", 0),       # 16 workgroups, every landmark seen by every camera
@@ -162,13 +162,18 @@ def test_small_solver_is_bit_reproducible_and_honours_the_options():
         s.set_problem(p)
         loose = s.solve(loss="huber")                      # the reference's tolerances: stops on ftol
         assert loose["status_name"] in ("ftol", "xtol") and loose["final_cost"] < 0.2 * loose["initial_cost"]      # (2 % gross outliers stay in the Huber cost)
-        # nine cameras, or more than 6144 observations (the measured crossover, tools/small_crossover.py): not the
-        # single-launch solver's case any more
+        # nine cameras: not the single-launch solver's case any more.  More than 6144 observations (the ONE-workgroup
+        # kernel's measured crossover, tools/small_crossover.py): still its case while the window fits the multi-workgroup
+        # kernel (2048 landmarks), the multi-kernel path beyond that
         q = make_problem(9, 600, 4, seed=1)
         s.set_problem(q)
         assert s.solve(max_iters=5)["pcg_iterations"] > 0
         q = make_problem(8, 1300, 5, seed=1)
         assert q.n_obs > 6144
+        s.set_problem(q)
+        assert s.solve(max_iters=5)["pcg_iterations"] == 0
+        q = make_problem(8, 2100, 3, seed=1)
+        assert q.n_obs > 6144 and q.n_pts > 2048
         s.set_problem(q)
         assert s.solve(max_iters=5)["pcg_iterations"] > 0
         # NaN pixel: the same failure code as the multi-kernel path
@@ -213,7 +218,7 @@ def test_small_solver_on_a_reused_handle_with_fewer_landmarks():
     assert abs(got["final_cost"] - ref["cost"]) <= 1e-9 * ref["cost"]
 
 
-@pytest.mark.parametrize("n_cams,n_pts,k,fixed", [(5, 500, 4, 0), (5, 777, 3, 2), (4, 130, 4, 3)])
+@pytest.mark.parametrize("n_cams,n_pts,k,fixed", [(5, 500, 4, 0), (5, 777, 3, 2), (4, 130, 4, 3), (6, 400, 4, 0), (7, 300, 5, 6), (8, 900, 6, 0)])
 def test_multi_workgroup_window_solver_agrees_with_the_single_workgroup_one(monkeypatch, n_cams, n_pts, k, fixed):
     """k_small_mw (several workgroups, two exchanges per LM iteration) against k_small_lm (BA_SMALL_MW=0) on the same
     handle and problem: same iteration count, verdicts and damping, costs to 1e-10 relative (the partial sums are
