@@ -356,7 +356,7 @@ def main():
         k_us = prof.get("misc", {}).get("mean_us", 0.0)
         b_solve = (ab["lin"] + ab["back"] + ab["evalc"]) * max(out["iterations"], 1)
         achieved = b_solve / (k_us * 1e-6) / 1e9 if k_us > 0 else 0.0
-        roofline = dict(bound="hbm", kernel="k_small_lm (whole solve in one launch)", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+        roofline = dict(bound="hbm", kernel="window solver (whole solve in one launch: k_small_mw / k_small_lm)", achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None, algorithmic_bytes_per_launch=round(b_solve),
                         mean_launch_us=round(k_us, 3), launches=prof.get("misc", {}).get("launches", 0), early_exit_launches=0,
                         mean_launch_us_all_launches=round(k_us, 3))

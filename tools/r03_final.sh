@@ -20,6 +20,7 @@ python3 tools/window_latency.py > $P/${TAG}_window_latency.txt 2>> $O/misc.err
 python3 tools/shard_times.py 1 2 4 8 > $P/${TAG}_shard_times.txt 2>> $O/misc.err
 python3 tools/bal_like_times.py 1000 100000 450000 > $P/${TAG}_bal_like_times.txt 2>> $O/misc.err
 python3 tools/run_end_to_end.py C3 > $P/${TAG}_end_to_end_c3.txt 2>> $O/misc.err
+( for a in "5 500 4" "5 1500 4" "2 100 2" "8 1000 5"; do BA_SMALL_STAMPS=1 python3 tools/small_phases.py $a; done; echo "--- BA_SMALL_MW=0 (one workgroup, k_small_lm)"; for a in "5 500 4" "5 1500 4" "2 100 2" "8 1000 5"; do BA_SMALL_MW=0 BA_SMALL_STAMPS=1 python3 tools/small_phases.py $a; done ) > $P/${TAG}_small_phases.txt 2>&1
 for f in $P/${TAG}_*bench.json; do python3 - $f <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
