@@ -91,7 +91,7 @@ k_small_mw(MwArgs M) {
   __shared__ unsigned short l_ij[D::MSG];            // (i | j << 8) of message word t < nS + n: built once
   __shared__ double l_dc[MW_N], l_bc[MW_N], l_dH[MW_N];
   __shared__ double l_red[MW_WAVES * 8], l_tot[8], l_camred[MW_MAX_CAMS][4], l_wcost[MW_WAVES][2], l_sc[MW_SCAL];
-  __shared__ double s_lambda, s_cost, s_sse, s_cost_new, s_sse_new, s_gmax, s_nu;
+  __shared__ double s_lambda, s_cost, s_sse, s_nu;
   __shared__ int s_cur, s_stop, s_it, s_acc, s_status, s_ok;
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -423,7 +423,6 @@ k_small_mw(MwArgs M) {
       if (lane == 0) m = nanmax(m, l_msg[msg_len - 1]);
       m = wave_nanmax(m);
       if (lane == 0) {
-        s_gmax = m;
         if (!isfinite(m)) { s_stop = 1; s_status = -4; }
         else if (A.gtol > 0 && m <= A.gtol) { s_stop = 1; s_status = 3; }
       }
