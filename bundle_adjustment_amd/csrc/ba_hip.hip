@@ -195,6 +195,8 @@ struct ba_handle {
   DBuf<double> intr[2];        // per-camera intrinsics (f, k1, k2) of the BAL model, current / trial like cams[]
   DBuf<double> small_V, small_gS;   // k_small_lm: V = W L (49 x 3 Np_pad, zero where unwritten), per-wave partial V V^T
   int small_np_pad = -1;
+  char* h_par = nullptr; size_t h_par_cap = 0;   // pinned bounce buffer of ba_set_params / ba_get_params (window-sized problems)
+  hipEvent_t par_event = nullptr; bool par_pending = false;   // the last upload from it (ba_set_params returns without waiting)
   // k_small_mw (ba_small_mw.hpp): the window solver on mw_G workgroups; mw_ok: this problem fits its limits
   DBuf<int> mw_woff; DBuf<double> mw_buf; bool mw_ok = false; int mw_G = 0;
   // two-level preconditioner for band-structured problems (ba_coarse.hpp): structures built by ba_set_problem
@@ -368,6 +370,9 @@ extern "C" int ba_destroy(ba_handle* h) {
   h->tri.release();
   h->small_V.release();
   h->mw_woff.release(); h->mw_buf.release();
+  if (h->h_par) { (void)hipStreamSynchronize(h->stream); (void)hipHostFree(h->h_par); h->h_par = nullptr; h->h_par_cap = 0; }
+  if (h->par_event) { (void)hipEventDestroy(h->par_event); h->par_event = nullptr; }
+  h->par_pending = false;
   h->intr[0].release(); h->intr[1].release();
   h->small_gS.release();
   h->small_np_pad = -1;
@@ -1065,19 +1070,49 @@ static double* bc_ptr(ba_handle* h) { return h->HccBc.p + nh_of(h) * (size_t)h->
 static int cam_grid(ba_handle* h, int segl = 64) { const int cpb = 64 * WPB / segl; return ((h->Nc + cpb - 1) / cpb) * NPART; }
 static int row_grid(ba_handle* h) { return ((h->Nc + ROWS - 1) / ROWS) * NPART; }
 
+// pinned bounce buffer for parameter transfers of at most 1 MB (grow-only); false: copy from / to the caller's memory
+static bool par_bounce(ba_handle* h, size_t bytes) {
+  if (bytes == 0 || bytes > ((size_t)1 << 20)) return false;
+  if (h->par_pending) { (void)hipEventSynchronize(h->par_event); h->par_pending = false; }     // the buffer's last upload has landed
+  if (h->h_par_cap < bytes) {
+    if (h->h_par) { (void)hipStreamSynchronize(h->stream); (void)hipHostFree(h->h_par); h->h_par = nullptr; h->h_par_cap = 0; }
+    const size_t cap = std::max<size_t>(2 * bytes, (size_t)64 << 10);
+    if (hipHostMalloc((void**)&h->h_par, cap, hipHostMallocDefault) != hipSuccess) { h->h_par = nullptr; (void)hipGetLastError(); return false; }
+    h->h_par_cap = cap;
+  }
+  return true;
+}
 extern "C" int ba_set_params(ba_handle* h, const double* cams, const double* pts) {
   if (!h || !cams || (!pts && h->Np > 0)) return fail(BA_ERR_INVALID, "null argument");
   if (!h->have_problem) return fail(BA_ERR_STATE, "ba_set_problem has not been called");
   if (set_device(h)) return BA_ERR_HIP;
   h->cur = 0;
-  HIPCHECK(hipMemcpyAsync(h->cams[0].p, cams, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  // a window's worth of parameters goes through a pinned bounce buffer: copies from pageable memory are staged by the
+  // runtime one blocking transfer at a time (~10 us each), more than the kernels behind them take
+  const size_t cb = 6 * (size_t)h->Nc * sizeof(double), pb = 3 * (size_t)h->Np * sizeof(double);
+  const double *cams_src = cams, *pts_src = pts;
+  if (par_bounce(h, cb + pb)) {
+    memcpy(h->h_par, cams, cb);
+    if (pb) memcpy(h->h_par + cb, pts, pb);
+    cams_src = (const double*)h->h_par; pts_src = (const double*)(h->h_par + cb);
+  }
+  HIPCHECK(hipMemcpyAsync(h->cams[0].p, cams_src, cb, hipMemcpyHostToDevice, h->stream));
   if (h->Np > 0) {
-    HIPCHECK(hipMemcpyAsync(h->stage.p, pts, 3 * (size_t)h->Np * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(hipMemcpyAsync(h->stage.p, pts_src, pb, hipMemcpyHostToDevice, h->stream));
     BA_LAUNCH(k_pack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->stage.p, h->slot.p, h->Np, h->ptab[0].p);
   }
   BA_LAUNCH(k_cam_prepare<Pinhole>, dim3((h->Nc + 63) / 64), dim3(64), 0, h->stream, h->cams[0].p, (const double*)h->intr[0].p,
             h->cs[0].p, h->camA[0].p, h->Nc);
-  BA_SYNC(h);
+  if (cams_src != cams) {
+    // the caller's arrays are no longer referenced: no need to wait for the two kernels (whatever comes next is ordered
+    // behind them on the stream; a launch failure surfaces at the next synchronisation)
+    if (!h->par_event) HIPCHECK(hipEventCreateWithFlags(&h->par_event, hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(h->par_event, h->stream));
+    h->par_pending = true;
+    if (int rc = check_launches(h)) return rc;
+  } else {
+    BA_SYNC(h);
+  }
   h->have_params = true;
   h->linearized = false;
   return BA_OK;
@@ -1087,12 +1122,18 @@ extern "C" int ba_get_params(ba_handle* h, double* cams, double* pts) {
   if (!h) return fail(BA_ERR_INVALID, "null handle");
   if (!h->have_params) return fail(BA_ERR_STATE, "no parameters set");
   if (set_device(h)) return BA_ERR_HIP;
-  if (cams) HIPCHECK(hipMemcpyAsync(cams, h->cams[h->cur].p, 6 * (size_t)h->Nc * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  const size_t cb = cams ? 6 * (size_t)h->Nc * sizeof(double) : 0, pb = (pts && h->Np > 0) ? 3 * (size_t)h->Np * sizeof(double) : 0;
+  const bool bounce = par_bounce(h, cb + pb);
+  if (cams) HIPCHECK(hipMemcpyAsync(bounce ? (void*)h->h_par : (void*)cams, h->cams[h->cur].p, cb, hipMemcpyDeviceToHost, h->stream));
   if (pts && h->Np > 0) {
     BA_LAUNCH(k_unpack_points, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->ptab[h->cur].p, h->slot.p, h->Np, h->stage.p);
-    HIPCHECK(hipMemcpyAsync(pts, h->stage.p, 3 * (size_t)h->Np * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipMemcpyAsync(bounce ? (void*)(h->h_par + cb) : (void*)pts, h->stage.p, pb, hipMemcpyDeviceToHost, h->stream));
   }
   BA_SYNC(h);
+  if (bounce) {
+    if (cb) memcpy(cams, h->h_par, cb);
+    if (pb) memcpy(pts, h->h_par + cb, pb);
+  }
   return BA_OK;
 }
 
