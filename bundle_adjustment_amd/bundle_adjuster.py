@@ -42,7 +42,7 @@ class BundleAdjuster:
     def __init__(self, camera_matrix, window_size=5, *, device_id=0, loss='huber', f_scale=1.0, ftol=1e-5,
                  xtol=1e-5, gtol=1e-8, max_iters=50, pcg_tol=0.1, pcg_max_iters=200, pcg_model_tol=0.0, preconditioner='schur_jacobi',
                  jacobian='f64', comm=None, sparsity_plot_hook=None, verbose=0, reuse_window=True, metrics_path=None,
-                 inplace_writeback=False):
+                 inplace_writeback=False, reuse_min_obs=20000):
         self.camera_matrix = camera_matrix
         self.window_size = window_size
         self.device_id = device_id
@@ -61,7 +61,8 @@ class BundleAdjuster:
         # what survives between consecutive run() calls (src/pipeline.py:99 calls run after every keyframe): the
         # flattened window (problem.WindowCache) and, while its observation structure is unchanged, the problem the
         # solver already holds on the device
-        self._window = WindowCache() if reuse_window else None
+        # (windows with fewer observation-list entries than reuse_min_obs are walked afresh on every call: problem.WindowCache)
+        self._window = WindowCache(min_obs=reuse_min_obs) if reuse_window else None
         self._uploaded_token = None
 
     # -- device -------------------------------------------------------------------------

@@ -235,13 +235,20 @@ class WindowCache:
 
     Assumption, stated: observation lists are append-only (what the reference does); an element replaced in place
     without changing the length is not noticed.  The cache holds references to the list objects it has seen, so an
-    ``id()`` can never be recycled behind its back.  ``BundleAdjuster(..., reuse_window=False)`` turns it off.
+    ``id()`` can never be recycled behind its back.  ``BundleAdjuster(..., reuse_window=False)`` turns it off; windows with
+    fewer than ``min_obs`` observation-list entries (``BundleAdjuster(..., reuse_min_obs=20000)``) bypass it: walking a
+    sliding window of five keyframes costs 0.1 ms, less than three times the cache's own bookkeeping, and such a window
+    moves on every call.
     """
 
-    def __init__(self):
+    def __init__(self, min_obs=20000):
         self.window = None          # dict: ids, kfs, lists, lens, n_have, all_present, cam_idx, pt_idx, uv, mp_ids, token
         self.tokens = 0
         self.hits = dict(window=0, walked=0)
+        # windows with fewer observation-list entries than this are simply walked every time (a sliding window of five
+        # keyframes: the walk is 0.1 ms, the cache's bookkeeping and validation would be a third of that, for a window
+        # that moves on every call anyway)
+        self.min_obs = int(min_obs)
 
     def flatten(self, gmap, local_kf_ids, camera_matrix):
         """-> (BAProblem or None, sorted landmark ids as int64 array, structure token).  The token changes whenever the
@@ -251,6 +258,12 @@ class WindowCache:
         kfs = [keyframes[k] for k in local_kf_ids]
         lists = [kf.observations for kf in kfs]
         lens = [len(o) for o in lists]
+        if sum(lens) < self.min_obs:
+            prob, mp_ids = flatten_map_window_ids(gmap, local_kf_ids, camera_matrix)
+            self.hits["walked"] += len(kfs)
+            self.window = None
+            self.tokens += 1
+            return prob, mp_ids, (self.tokens if prob is not None else -1)
         w = self.window
         reuse = (w is not None and len(w["kfs"]) == len(kfs) and w["ids"] == list(local_kf_ids)
                  and all(a is b for a, b in zip(w["kfs"], kfs)) and all(a is b for a, b in zip(w["lists"], lists))

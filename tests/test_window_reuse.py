@@ -48,7 +48,7 @@ def test_cached_window_equals_a_fresh_walk_on_a_growing_map():
     p = make_problem(7, 300, 4, seed=2)
     gmap = problem_to_map(p)
     K = np.array([[p.K4[0], 0, p.K4[2]], [0, p.K4[1], p.K4[3]], [0, 0, 1.0]])
-    cache = WindowCache()
+    cache = WindowCache(min_obs=0)                  # (small test maps: the cache is on whatever the window's size)
     w = 5
     tokens = []
     for step in range(7):
@@ -90,7 +90,7 @@ def test_large_windows_reuse_the_whole_window():
     gmap = problem_to_map(p)
     K = np.array([[p.K4[0], 0, p.K4[2]], [0, p.K4[1], p.K4[3]], [0, 0, 1.0]])
     local = sorted(gmap.keyframes)[:-1]
-    cache = WindowCache()
+    cache = WindowCache(min_obs=0)                  # (small test maps: the cache is on whatever the window's size)
     a, ids_a, ta = cache.flatten(gmap, local, K)
     b, ids_b, tb = cache.flatten(gmap, local, K)
     ref, ref_ids = flatten_map_window(gmap, local, K)
@@ -171,7 +171,7 @@ def test_run_sends_parameters_only_when_the_structure_is_unchanged(monkeypatch):
     p = make_problem(6, 250, 4, seed=6)
     gmap = problem_to_map(p)
     K = np.array([[p.K4[0], 0, p.K4[2]], [0, p.K4[1], p.K4[3]], [0, 0, 1.0]])
-    ba = ba_mod.BundleAdjuster(K, window_size=5, ftol=1e-10, xtol=1e-10)
+    ba = ba_mod.BundleAdjuster(K, window_size=5, ftol=1e-10, xtol=1e-10, reuse_min_obs=0)
     ref = ba_mod.BundleAdjuster(K, window_size=5, ftol=1e-10, xtol=1e-10, reuse_window=False)
     gref = problem_to_map(p)
     logs = []

@@ -40,7 +40,7 @@ extra = 25
 # free depths, dozens of LM iterations -- not what a sliding window is)
 from bundle_adjustment_amd.synthetic import make_bal_like
 pl = make_bal_like(n_cams=n_cams + extra, n_pts=n_pts * 6, n_obs_target=n_pts * 6 * k, seed=1)
-for reuse in (True, False):
+for reuse in (False, True, False):
     full = problem_to_map(pl, extra_newest=False)       # a fresh (unoptimised) map for each mode
     gv = Map()
     gv.map_points = full.map_points
