@@ -172,6 +172,44 @@ class _stdout_to_stderr:
         return False
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks as children -- the same
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+    the driver uses -- from a parent that makes no GPU call at all.  Rank 0's stdout (the one JSON line, or the error
+    object of a run that could not bring its transport up) is relayed; the return value is the launcher's exit code, or 4
+    when the children ended 'successfully' without a JSON line that names N ranks."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL / device-memory sharing across processes needs here
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:                                  # (stderr goes straight through)
+        out = out.strip()
+        if out.startswith("{"):
+            line = out
+            print(out, flush=True)
+        elif out:
+            print(out, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc != 0:
+        return rc
+    try:
+        ok = line is not None and json.loads(line).get("n_gpus") == n and "error" not in json.loads(line)
+    except ValueError:
+        ok = False
+    if not ok:
+        print(f"bench.py: the {n} ranks ended without a result line for n_gpus={n}", file=sys.stderr)
+        return 4
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,8 +236,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: this process starts the N ranks itself (before it has touched the GPU in any way),
+        # relays rank 0's JSON line and exits with the launcher's code -- it never times ONE GPU under the name of N
+        raise SystemExit(launch_ranks(args.gpus))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to time {world} rank(s) under the name of {args.gpus}")
     dist = None
     if world > 1:
         import torch.distributed as dist          # plumbing only: id exchange, barrier, max over ranks
@@ -239,6 +283,14 @@ def main():
         # -- a scaling line over the wrong transport would be worse than none.
         transport = "shm" if os.environ.get("BA_COMM") == "shm" else "rccl"
         ok, err, uid = 1, "", None
+        if transport == "rccl" and ndev < world:
+            # one rank per GPU: RCCL refuses two ranks on one device, and a line over fewer GPUs than it names is worse than none
+            if rank == 0:
+                print(json.dumps({"error": f"--gpus {world} but only {ndev} device(s) visible (BA_COMM=shm lets ranks share a GPU for tests)",
+                                  "n_gpus": world}), flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+            raise SystemExit(3)
         if rank == 0:                         # rank 0 ALWAYS reaches the broadcast, with or without an id
             try:
                 with _stdout_to_stderr():

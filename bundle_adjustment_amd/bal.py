@@ -17,9 +17,11 @@ then y, the reference's sign (``src/bundle_adjuster.py:68-69``).
 What runs where: ``read_bal`` / ``write_bal`` are host code; ``Solver.residuals_bal`` evaluates the BAL residual on the
 GPU (``ba_residuals_bal``: K1 with per-camera ``f, k1, k2``); ``to_pinhole`` converts a BAL problem whose cameras share
 one focal length and have no distortion into the reference's model (z flipped, shared K), which the LM / Schur / PCG
-solver then adjusts as it stands; ``solve`` / ``Solver.solve_bal`` adjust the full 9-parameter cameras (``ba_solve_bal``,
-``csrc/ba_bal.hpp``: LM + Schur + PCG with 2x9 camera blocks, checked step by step against
-``oracle.lm_solve(model='bal')``), ``Solver.linearize_bal`` returns the block normal equations (``ba_linearize_bal``).
+solver then adjusts as it stands; ``solve`` / ``Solver.solve_bal`` adjust the full 9-parameter cameras (``ba_solve_bal``:
+the same kernels and host loop as ``ba_solve``, instantiated for the ``BalCam`` model of ``csrc/ba_models.hpp`` -- LM + Schur
++ PCG with 2x9 camera blocks, ``jacobian_precision`` and multi-rank jobs included; checked step by step against
+``oracle.lm_solve(model='bal')``, which is test infrastructure and never imported here), ``Solver.linearize_bal`` returns
+the block normal equations (``ba_linearize_bal``).
 """
 from __future__ import annotations
 

@@ -155,6 +155,7 @@ struct ba_handle {
   int lanes = LPP;             // lanes per point in the point passes: 2, or 4 / 8 / 16 for every point of a smaller problem
   int cam_band = 0;            // camera passes: XCD x takes camera range x (1) or partition x of every camera (0); see group_of_block
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // second stream: test hook ba_debug_occupy only
   bool have_problem = false, have_params = false, linearized = false;
   int lin_robust = 0;
   double lin_fscale = 1.0;
@@ -199,6 +200,8 @@ struct ba_handle {
   hipEvent_t par_event = nullptr; bool par_pending = false;   // the last upload from it (ba_set_params returns without waiting)
   // k_small_mw (ba_small_mw.hpp): the window solver on mw_G workgroups; mw_ok: this problem fits its limits
   DBuf<int> mw_woff; DBuf<double> mw_buf; bool mw_ok = false; int mw_G = 0;
+  int mw_resident[3] = {-1, -1, -1};   // workgroups of k_small_mw<2 / 3 / 4> the device holds at once (occupancy query, once per handle)
+  long long stats[BA_STAT_COUNT] = {0};   // ba_get_stat
   // two-level preconditioner for band-structured problems (ba_coarse.hpp): structures built by ba_set_problem
   bool two_level_ok = false;   // this problem has them
   bool two_level = false;      // the current solve uses them
@@ -207,7 +210,7 @@ struct ba_handle {
   DBuf<int2> run_pairs;
   DBuf<double> coarseU, coarseE, coarseEinv, coarse_rc, coarse_info;
   DBuf<long long> coarseEint;
-  DBuf<long long> dev_seq;     // device word a riding k_scalars publishes the step's sequence number in (ba_kernels.hpp, "riders")
+  DBuf<double> dev_lam;        // device word a riding k_scalars stores the next damping in; 0 = not yet (ba_kernels.hpp, ScalarsArgs::lam_slot)
   DBuf<double> verdict;        // PCG verdict words {gamma, zeta, finished, -} x 2 iteration parities (point pass -> camera pass, vector kernel)
   int cam_segl = 64;           // lanes per (camera, partition) segment in the PCG camera pass (BA_CAM_SEGL, tuning)
   int nblkP = 1, ppb = 1, nblkV = 1;   // nblkV: camera-vector workgroups of the pinhole (VEC_CAMS cameras each)
@@ -380,11 +383,12 @@ extern "C" int ba_destroy(ba_handle* h) {
   h->coarseU.release(); h->coarseE.release(); h->coarseEinv.release(); h->coarse_rc.release(); h->coarse_info.release();
   h->coarseEint.release();
   h->verdict.release();
-  h->dev_seq.release();
+  h->dev_lam.release();
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->h_flags) (void)hipHostFree(h->h_flags);
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->h_up) (void)hipHostFree(h->h_up);
+  if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return BA_OK;
@@ -973,7 +977,19 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
       HIPCHECK(h->mw_woff.alloc(woff.size()));
       HIPCHECK(upload(h->mw_woff.p, woff.data(), woff.size() * sizeof(int)));
       HIPCHECK(h->mw_buf.alloc((size_t)2 * MW_MAX_WG * (MW_MSG + MW_SCAL) + 8));
-      h->mw_ok = true;
+      // the workgroups of k_small_mw meet at a counter barrier: the kernel is only chosen when the device can hold all of
+      // them at once (occupancy query x compute units; the launch itself is an ordinary one, and a barrier that is not
+      // served in time -- somebody else holds the units -- ends in the fall-back of small_solve, not in a hang)
+      const int nt = Nc <= 5 ? 0 : (Nc <= 7 ? 1 : 2);
+      if (h->mw_resident[nt] < 0) {
+        int per_cu = 0;
+        hipError_t e = nt == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_small_mw<2>, MW_THREADS, 0)
+                     : nt == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_small_mw<3>, MW_THREADS, 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_small_mw<4>, MW_THREADS, 0);
+        if (e != hipSuccess) { per_cu = 0; (void)hipGetLastError(); }
+        h->mw_resident[nt] = per_cu * h->n_cu;
+      }
+      h->mw_ok = h->mw_resident[nt] >= h->mw_G;
     }
   }
   HIPCHECK(h->c_pt.alloc(nobs1)); HIPCHECK(h->c_orig.alloc(nobs1)); HIPCHECK(h->p_cam.alloc(nobs1));
@@ -1022,8 +1038,8 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   HIPCHECK(h->st.alloc(2));
   HIPCHECK(h->verdict.alloc(8));
   HIPCHECK(hipMemsetAsync(h->verdict.p, 0, 8 * sizeof(double), h->stream));
-  HIPCHECK(h->dev_seq.alloc(2));
-  // (dev_seq only ever grows with the handle's step sequence; camA rows: geometry by k_cam_prepare / k_cam_update, vt by the
+  HIPCHECK(h->dev_lam.alloc(2));
+  // (dev_lam is cleared by every back substitution; camA rows: geometry by k_cam_prepare / k_cam_update, vt by the
   //  PCG setup before any pass reads it)
   h->lb = 0;
   stage("allocations");
@@ -1208,7 +1224,7 @@ static ScalarsArgs scalars_args(ba_handle* h, bool with_step, int k, double tol2
   a.scal = h->scal.p; a.scal_host = direct ? h->d_scal_host : (double*)nullptr;
   a.host_flag = direct ? h->d_flags + 2 : (long long*)nullptr; a.seq = seq;
   a.decide = direct ? 1 : 0; a.cost_cur = cost_cur; a.lambda = lambda;
-  a.dev_flag = nullptr; a.on = 0;
+  a.lam_slot = nullptr; a.err_flag = nullptr; a.on = 0;
   return a;
 }
 static void launch_scalars(ba_handle* h, bool with_step, int k = 0, double tol2 = 0.0, int min_iters = 0, long long seq = 0,
@@ -1740,7 +1756,6 @@ static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     HIPCHECK(hipHostGetDevicePointer((void**)&h->d_small_host, h->h_small, 0));
     h->h_small_bytes = bytes;
   }
-  memset(h->h_small, 0, off_trace);
   SmallArgs A;
   for (int k = 0; k < 2; ++k) { A.cams[k] = h->cams[k].p; A.cs[k] = h->cs[k].p; A.ptab[k] = h->ptab[k].p; A.camA[k] = h->camA[k].p; }
   A.offk = h->offk.p; A.c_pt = h->c_pt.p; A.c_uv = h->c_uv.p;
@@ -1749,15 +1764,9 @@ static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   A.Np_pad = (h->Np + 15) & ~15;
   A.Kp = 3 * A.Np_pad;
   const char* mw_env = getenv("BA_SMALL_MW");           // BA_SMALL_MW=0: always the one-workgroup kernel
-  const bool used_mw = h->mw_ok && (!mw_env || atoi(mw_env) != 0);
+  bool used_mw = h->mw_ok && (!mw_env || atoi(mw_env) != 0);
   HIPCHECK(h->small_gS.alloc((size_t)SMALL_WAVES * SMALL_TILES * 256 + 16));        // + 16 words of diagnostic stamps
-  if (!used_mw && h->small_np_pad != A.Np_pad) {          // columns of padding points and rows past 6 Nc stay zero for good
-    const size_t nv = (size_t)SMALL_VROWS * A.Kp;         // (k_small_mw keeps its columns of V in LDS: nothing to clear)
-    HIPCHECK(h->small_V.alloc(nv));
-    HIPCHECK(hipMemsetAsync(h->small_V.p, 0, nv * sizeof(double), h->stream));
-    h->small_np_pad = A.Np_pad;
-  }
-  A.V = h->small_V.p; A.gS = h->small_gS.p;
+  A.gS = h->small_gS.p;
   A.n_cams = h->Nc; A.n_pts = h->Np; A.fixed_cam = h->fixed; A.robust = opts->loss == BA_LOSS_HUBER;
   A.fx = h->K4[0]; A.fy = h->K4[1]; A.cx = h->K4[2]; A.cy = h->K4[3]; A.hub_c = opts->f_scale;
   A.max_iters = opts->max_iters; A.ftol = opts->ftol; A.xtol = opts->xtol; A.gtol = opts->gtol; A.lambda0 = opts->initial_lambda;
@@ -1768,28 +1777,57 @@ static int small_solve(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   A.host_flag = h->d_flags + 4;
   h->profile = opts->profile != 0;
   A.stamps = getenv("BA_SMALL_STAMPS") ? (long long*)(h->small_gS.p + (size_t)SMALL_WAVES * SMALL_TILES * 256) : nullptr;   // device memory: a host store would stall the wave
-  A.seq = ++h->small_seq;
-  if (used_mw) {        // several workgroups: 64 landmarks each, two exchanges per LM iteration (ba_small_mw.hpp)
-    MwArgs M;
-    M.A = A; M.woff = h->mw_woff.p; M.G = h->mw_G;
-    M.slots = h->mw_buf.p; M.sslots = h->mw_buf.p + (size_t)2 * MW_MAX_WG * MW_MSG;
-    M.ctr = (unsigned long long*)(h->mw_buf.p + (size_t)2 * MW_MAX_WG * (MW_MSG + MW_SCAL));
-    Scope sc(h, BA_K_MISC);
-    // instantiated per number of 16-row tiles of [V; z]: 6 Nc + 1 rows
-    if (h->Nc <= 5)      BA_LAUNCH(k_small_mw<2>, dim3(h->mw_G), dim3(MW_THREADS), 0, h->stream, M);
-    else if (h->Nc <= 7) BA_LAUNCH(k_small_mw<3>, dim3(h->mw_G), dim3(MW_THREADS), 0, h->stream, M);
-    else                 BA_LAUNCH(k_small_mw<4>, dim3(h->mw_G), dim3(MW_THREADS), 0, h->stream, M);
-  } else {
-    Scope sc(h, BA_K_MISC);
-    BA_LAUNCH(k_small_lm, dim3(1), dim3(SMALL_THREADS), 0, h->stream, A);
+  // one launch of either kernel and the wait for its result word: the kernel's last act is a system-scope release of the
+  // sequence word -- summary, parameter set and trace are in host memory by then, and whatever the caller queues next on
+  // the stream is ordered behind the kernel as usual
+  auto run_once = [&](bool mw) -> int {
+    if (!mw && h->small_np_pad != A.Np_pad) {             // columns of padding points and rows past 6 Nc stay zero for good
+      const size_t nv = (size_t)SMALL_VROWS * A.Kp;       // (k_small_mw keeps its columns of V in LDS: nothing to clear)
+      HIPCHECK(h->small_V.alloc(nv));
+      HIPCHECK(hipMemsetAsync(h->small_V.p, 0, nv * sizeof(double), h->stream));
+      h->small_np_pad = A.Np_pad;
+    }
+    A.V = h->small_V.p;
+    memset(h->h_small, 0, off_trace);
+    A.seq = ++h->small_seq;
+    if (mw) {           // several workgroups: 64 landmarks each, two exchanges per LM iteration (ba_small_mw.hpp)
+      MwArgs M;
+      M.A = A; M.woff = h->mw_woff.p; M.G = h->mw_G;
+      // (test hook BA_DEBUG_MW_EXTRA_WG: every barrier waits for one workgroup more than the launch has -- the time-out path)
+      M.G_barrier = h->mw_G + (getenv("BA_DEBUG_MW_EXTRA_WG") ? 1 : 0);
+      M.slots = h->mw_buf.p; M.sslots = h->mw_buf.p + (size_t)2 * MW_MAX_WG * MW_MSG;
+      M.ctr = (unsigned long long*)(h->mw_buf.p + (size_t)2 * MW_MAX_WG * (MW_MSG + MW_SCAL));
+      Scope sc(h, BA_K_MISC);
+      // instantiated per number of 16-row tiles of [V; z]: 6 Nc + 1 rows
+      if (h->Nc <= 5)      BA_LAUNCH(k_small_mw<2>, dim3(h->mw_G), dim3(MW_THREADS), 0, h->stream, M);
+      else if (h->Nc <= 7) BA_LAUNCH(k_small_mw<3>, dim3(h->mw_G), dim3(MW_THREADS), 0, h->stream, M);
+      else                 BA_LAUNCH(k_small_mw<4>, dim3(h->mw_G), dim3(MW_THREADS), 0, h->stream, M);
+      h->stats[BA_STAT_WINDOW_MW_LAUNCHES]++;
+    } else {
+      Scope sc(h, BA_K_MISC);
+      BA_LAUNCH(k_small_lm, dim3(1), dim3(SMALL_THREADS), 0, h->stream, A);
+      h->stats[BA_STAT_WINDOW_LM_LAUNCHES]++;
+    }
+    if (int rc = wait_flag(h, 4, A.seq)) return rc;
+    memcpy(sum, h->h_small, sizeof(ba_summary));
+    return BA_OK;
+  };
+  if (int rc = run_once(used_mw)) return rc;
+  if (used_mw && sum->status == BA_ERR_HIP) {
+    // A workgroup of k_small_mw was not served at a barrier within MW_SPIN_TICKS: its G workgroups were not resident
+    // together (another stream, handle or tool holds compute units).  The window is solved again, in this process, by the
+    // one-workgroup kernel from the SAME start point: the cameras of the start set were never written (only the final block
+    // of a successful solve stores them), the landmarks' start positions are restored from the y slots every workgroup
+    // parked them in.  Workgroups of the failed launch that were still queued run (and give up) first: stream order.
+    if (h->Np > 0)
+      BA_LAUNCH(k_small_restore, dim3((h->Np + 255) / 256), dim3(256), 0, h->stream, h->ptab[A.cur].p, h->Np);
+    h->stats[BA_STAT_WINDOW_FALLBACKS]++;
+    used_mw = false;
+    if (int rc = run_once(false)) return rc;
   }
-  // the kernel's last act is a system-scope release of the sequence word: summary, parameter set and trace are in host
-  // memory by then, and whatever the caller queues next on the stream is ordered behind the kernel as usual
-  if (int rc = wait_flag(h, 4, A.seq)) return rc;
-  memcpy(sum, h->h_small, sizeof(ba_summary));
   if (h->profile) flush_profile(h);
   h->profile = false;
-  if (sum->status == BA_ERR_HIP) return fail(BA_ERR_HIP, "k_small_mw: a workgroup was not served at a barrier (bounded spin ran out)");
+  if (sum->status == BA_ERR_HIP) return fail(BA_ERR_HIP, "the window solver reported a device-side failure");
   if (sum->status == BA_ERR_NUMERIC)
     return fail(BA_ERR_NUMERIC, sum->iterations == 0 ? "non-finite cost at the initial parameters"
                                                      : "non-finite cost / gradient during the solve (LM iteration %d)", sum->iterations);
@@ -2055,6 +2093,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       cu.cs = h->cs[h->cur].p; cu.cams_trial = h->cams[1 - h->cur].p; cu.intr_trial = h->intr[1 - h->cur].p; cu.cs_trial = h->cs[1 - h->cur].p;
       cu.vtil = h->camA[h->cur].p; cu.camA_trial = h->camA[1 - h->cur].p; cu.partC = h->partC.p;
       cu.vx = h->vx.p;
+      cu.lam_slot = h->dev_lam.p;
       // (riding workgroups: a multiple of NPART, so that the point workgroups behind them keep their XCD = index mod NPART)
       cu.n_cams = Nc; cu.fixed_cam = h->fixed; cu.n_blocks = (((nbv(h) + CU_GROUPS - 1) / CU_GROUPS + NPART - 1) / NPART) * NPART;
       const bool ride = (riders & 1) && all_lds_of(h) && h->Np > 0;
@@ -2063,7 +2102,8 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
         if (h->model) BA_LAUNCH(k_cam_update<BalCam>, dim3(nbv(h)), dim3(VEC_BLOCK), 0, h->stream, cu);
         else          BA_LAUNCH(k_cam_update<Pinhole>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, cu);
       }
-      launch_pt_schur(h, robust, 1, 0, 0.0, 0, 0, nullptr, ride ? &cu : nullptr);
+      if (!ride) cu.n_blocks = 0;            // (the arguments still travel: the launch clears the riding verdict's damping word)
+      launch_pt_schur(h, robust, 1, 0, 0.0, 0, 0, nullptr, &cu);
     }
     // Speculation: unless this is the last iteration, the cost at the trial point comes out of the camera half of
     // the NEXT linearisation computed there (one pass instead of two), into the other c_w / partL buffers; the step's
@@ -2092,10 +2132,14 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     }
     if (speculated) {
       ScalarsArgs sa = scalars_args(h, true, k, tol2, opts->pcg_min_iters, seq, cost, lambda);
-      sa.on = 1; sa.dev_flag = h->dev_seq.p;
+      sa.on = 1; sa.lam_slot = h->dev_lam.p; sa.err_flag = h->d_flags + 6;
       launch_lin_pt(h, 1 - h->cur, 1 - h->pb, robust, fs, 0.0, h->scal.p + S_LAM_NEXT, ride_scalars ? &sa : nullptr);
     }
     if (int rc = wait_flag(h, 2, seq)) return rc;
+    if (h->h_flags[6] != 0) {          // a point workgroup of the speculated pass waited RIDER_WAIT_TICKS for the riding verdict
+      h->h_flags[6] = 0;
+      return fail(BA_ERR_HIP, "LM iteration %d: the point workgroups of the speculated linearisation were not served by the riding scalar fold", it);
+    }
     if (pcg_done_iters < 0) pcg_done_iters = (h->h_scal[S_PCG_FIN] != 0.0) ? (int)h->h_scal[S_PCG_ITERS] : k;
     sum->pcg_iterations += pcg_done_iters;
     double t2 = now_s();
@@ -2149,6 +2193,31 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   h->profile = false;
   h->jac_f32 = false;
   h->two_level = false;
+  return BA_OK;
+}
+
+// ------------------------------------------------------------------ counters, test hooks
+extern "C" int ba_get_stat(ba_handle* h, int32_t which, int64_t* value) {
+  if (!h || !value || which < 0 || which >= BA_STAT_COUNT) return fail(BA_ERR_INVALID, "bad argument");
+  *value = (int64_t)h->stats[which];
+  return BA_OK;
+}
+// workgroups that hold their compute unit's LDS for a bounded time and do nothing (ba_debug_occupy)
+__global__ void __launch_bounds__(256) k_debug_occupy(long long ticks, double* __restrict__ sink) {
+  extern __shared__ __align__(16) double hog[];
+  if (threadIdx.x == 0) hog[0] = (double)blockIdx.x;
+  const long long t0 = (long long)wall_clock64();
+  while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(127);
+  if (threadIdx.x == 0 && sink && hog[0] < 0.0) sink[0] = hog[0];          // (keeps the LDS word alive; never true)
+}
+extern "C" int ba_debug_occupy(ba_handle* h, int32_t n_workgroups, int32_t lds_bytes, double milliseconds) {
+  if (!h || n_workgroups < 1 || n_workgroups > 4096 || lds_bytes < 8 || lds_bytes > 160 * 1024 || !(milliseconds > 0) || milliseconds > 2000.0)
+    return fail(BA_ERR_INVALID, "bad argument");
+  if (set_device(h)) return BA_ERR_HIP;
+  if (!h->stream2) HIPCHECK(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  HIPCHECK(hipFuncSetAttribute((const void*)k_debug_occupy, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  hipLaunchKernelGGL(k_debug_occupy, dim3(n_workgroups), dim3(256), (size_t)lds_bytes, h->stream2, (long long)(milliseconds * 1e5), (double*)nullptr);
+  HIPCHECK(hipGetLastError());
   return BA_OK;
 }
 

@@ -859,6 +859,7 @@ __device__ inline void write_vtil(const double* __restrict__ M, const double (&v
 //     invert their first Hpp, a whole observation loop later, and pick it up through one device-scope word.
 // CamUpdateArgs / ScalarsArgs are the riders' arguments (n_blocks / on = 0: no rider in this launch).
 struct CamUpdateArgs {
+  double* lam_slot;              // cleared by every back-substitution launch: see ScalarsArgs::lam_slot
   const double *cams, *intr, *dc, *rpcg, *Hcc, *bc, *cs;
   const double* vx;              // (M x_r, x_t, ..) of the PCG iterate, NB per camera, kept current by k_pcg_setup / k_pcg_step
   double *cams_trial, *intr_trial, *cs_trial, *vtil, *camA_trial, *partC;
@@ -875,9 +876,13 @@ struct ScalarsArgs {
   double *scal, *scal_host;
   long long* host_flag; long long seq;
   int decide; double cost_cur, lambda;
-  long long* dev_flag;           // device word the point workgroups of the same launch wait on (rider mode)
+  double* lam_slot;              // rider mode: device word the point workgroups of the same launch wait on.  It holds 0 (cleared by
+                                 // the back substitution of the same step, two kernels earlier) until the rider stores the next
+                                 // damping (> 0) into it: ONE word carries "ready" and the value, one relaxed load reads both
+  long long* err_flag;           // host-mapped word a point workgroup sets when that wait runs out (RIDER_WAIT_TICKS)
   int on;
 };
+constexpr long long RIDER_WAIT_TICKS = 100000000;   // 1 s of the 100 MHz wall clock: only a rider that is never dispatched gets there
 constexpr int CU_GROUPS = 4;          // camera groups (of CM::VC cameras, one wave each) per riding 1024-thread workgroup
 template <class CM> __device__ void cam_update_body(const CamUpdateArgs& a, int blk, bool active, double* __restrict__ lds);
 template <class CM> __device__ __forceinline__ void cam_update_rider(const CamUpdateArgs& a, int rb, double* __restrict__ dyn_lds);
@@ -923,15 +928,15 @@ pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, co
                   const PtWork& wk, int bid, int nblk, double fx, double fy, double cx, double cy, double hub_c,
                   double lambda_arg, const double* __restrict__ lam_dev, double* __restrict__ Hpp, double* __restrict__ bp,
                   double2* __restrict__ p_w, int* __restrict__ p_camf, double* __restrict__ Hppinv, double* __restrict__ y0,
-                  double* __restrict__ partG, const long long* __restrict__ lam_flag = nullptr, long long lam_seq = 0) {
+                  double* __restrict__ partG, const double* __restrict__ lam_slot = nullptr, long long* __restrict__ err_flag = nullptr) {
   extern __shared__ __align__(16) double tab[];   // 16-byte aligned: the table is read and written with b128 LDS operations
   __shared__ double smg[PT_THREADS / 64];
   double gm = 0.0;                                 // max |bp| over this thread's points (the reference's gtol test, scipy trf.py:451-453)
   // lam_dev: the damping of a SPECULATED linearisation is decided on the device (k_scalars) -- by the kernel ahead of this
-  // launch (lam_flag == null), or by workgroup 0 of this very launch (the rider, lam_flag = the word it publishes
-  // lam_seq in when scal[] is written): then the damping is fetched as late as possible, before the first inverse
-  double lambda = (lam_dev && !lam_flag) ? lam_dev[0] : lambda_arg;
-  bool have_lambda = !(lam_dev && lam_flag);
+  // launch (lam_slot == null), or by workgroup 0 of this very launch (the rider, lam_slot = the word it stores the damping
+  // in, 0 until then): then the damping is fetched as late as possible, before the first inverse
+  double lambda = (lam_dev && !lam_slot) ? lam_dev[0] : lambda_arg;
+  bool have_lambda = !(lam_dev && lam_slot);
   const int rb = pt_range_of_block(bid, nblk, wk.xcd_ranges);
   const int2 win = blk_win[wk.blk_base + rb];
   const bool use_lds = ALL_LDS || (size_t)win.y * CM::TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
@@ -990,10 +995,23 @@ pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, co
     if (!have_lambda) {
       // workgroup 0 never waits for anybody and is dispatched first, so this wait ends; by now it has usually ended long ago
       // RELAXED device-scope loads (served at the coherence point, nothing invalidated): an ACQUIRE here would make every
-      // wave of the launch invalidate its XCD's L2 (measured: the pass went from 21 to 99 us).  The value is read by a
-      // second such load issued after the flag has been seen; the writer released the flag behind the value.
-      while (__hip_atomic_load(lam_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lam_seq) __builtin_amdgcn_s_sleep(8);
-      lambda = __hip_atomic_load(lam_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // wave of the launch invalidate its CU's L1 (measured: the pass went from 21 to 99 us).  The word is 0 until the rider
+      // stores the damping (always > 0) into it: the load that sees "ready" IS the value, no second word to order behind
+      // it.  Bounded by the wall clock: a rider that never comes leaves an error word for the host instead of a hang.
+      double lv = __hip_atomic_load(lam_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lv == 0.0) {
+        const long long t_start = (long long)wall_clock64();
+        int spins = 0;
+        while ((lv = __hip_atomic_load(lam_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0.0) {
+          __builtin_amdgcn_s_sleep(8);
+          if ((++spins & 255) == 0 && (long long)wall_clock64() - t_start > RIDER_WAIT_TICKS) {
+            if (err_flag) __hip_atomic_store(err_flag, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            lv = 1.0;                                    // (any finite damping: the host discards the solve)
+            break;
+          }
+        }
+      }
+      lambda = lv;
       have_lambda = true;
     }
     if (p >= 0 && sub == LANES - 1) {
@@ -1037,7 +1055,7 @@ k_pt_linearize(BA_LIN_PARAMS, PtWork wk, BA_LIN_TAIL) {
   if (sa.on && blockIdx.x < NPART) { if (blockIdx.x == 0) scalars_body(sa); return; }
   pt_linearize_body<CM, ROBUST, ALL_LDS, LANES>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wk, (int)blockIdx.x - sa.on * NPART, (int)gridDim.x - sa.on * NPART,
                                             fx, fy, cx, cy, hub_c, lambda, lam_dev, Hpp, bp, p_w, p_camf, Hppinv, y0, partG,
-                                            sa.on ? sa.dev_flag : (const long long*)nullptr, sa.seq);
+                                            sa.on ? sa.lam_slot : (const double*)nullptr, sa.err_flag);
 }
 // short and long tracks in one launch: workgroups [0, nblk_short) take the range list with LPP lanes
 // per point, the rest the long-track list with a DPP row per point (saves a launch per pass on data
@@ -1047,14 +1065,14 @@ __global__ void __launch_bounds__(PT_THREADS)
 k_pt_linearize_both(BA_LIN_PARAMS, PtWork wk, int nblk_short, PtWork wl, BA_LIN_TAIL) {
   if (sa.on && blockIdx.x < NPART) { if (blockIdx.x == 0) scalars_body(sa); return; }      // the rider: workgroup 0 (1 .. NPART-1 idle, see k_pt_linearize)
   const int bid = (int)blockIdx.x - sa.on * NPART, nblk = (int)gridDim.x - sa.on * NPART;
-  const long long* lf = sa.on ? sa.dev_flag : (const long long*)nullptr;
+  const double* lf = sa.on ? sa.lam_slot : (const double*)nullptr;
   if (bid < nblk_short)
     pt_linearize_body<CM, ROBUST, ALL_LDS, LPP>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wk, bid, nblk_short, fx, fy, cx, cy,
-                                            hub_c, lambda, lam_dev, Hpp, bp, p_w, p_camf, Hppinv, y0, partG, lf, sa.seq);
+                                            hub_c, lambda, lam_dev, Hpp, bp, p_w, p_camf, Hppinv, y0, partG, lf, sa.err_flag);
   else
     pt_linearize_body<CM, ROBUST, ALL_LDS, LPP_LONG>(camA, ptab, pt_off, p_cam, p_uv, blk_win, wl, bid - nblk_short,
                                                  nblk - nblk_short, fx, fy, cx, cy, hub_c, lambda, lam_dev, Hpp, bp, p_w,
-                                                 p_camf, Hppinv, y0, partG, lf, sa.seq);
+                                                 p_camf, Hppinv, y0, partG, lf, sa.err_flag);
 }
 #undef BA_LIN_PARAMS
 #undef BA_LIN_TAIL
@@ -1311,6 +1329,7 @@ template <class CM, bool ROBUST, int MODE, bool ALL_LDS, int LANES, typename JT>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_schur(BA_SCH_PARAMS, PtWork wk, BA_SCH_TAIL) {
   const int n_rider = (MODE == 1) ? cu.n_blocks : 0;           // the camera update's workgroups: the FIRST ones of the launch
+  if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0 && cu.lam_slot) cu.lam_slot[0] = 0.0;     // (see ScalarsArgs::lam_slot)
   if (MODE == 1 && (int)blockIdx.x < n_rider) {
     extern __shared__ __align__(16) double tab[];
     cam_update_rider<CM>(cu, blockIdx.x, tab);
@@ -1324,6 +1343,7 @@ template <class CM, bool ROBUST, int MODE, bool ALL_LDS, typename JT>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_schur_both(BA_SCH_PARAMS, PtWork wk, int nblk_short, PtWork wl, BA_SCH_TAIL) {
   const int n_rider = (MODE == 1) ? cu.n_blocks : 0;
+  if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0 && cu.lam_slot) cu.lam_slot[0] = 0.0;     // (see ScalarsArgs::lam_slot)
   if (MODE == 1 && (int)blockIdx.x < n_rider) {
     extern __shared__ __align__(16) double tab[];
     cam_update_rider<CM>(cu, blockIdx.x, tab);
@@ -1911,13 +1931,11 @@ __device__ void scalars_body(const ScalarsArgs& a) {
     a.scal[threadIdx.x] = res[threadIdx.x];
     if (a.scal_host) a.scal_host[threadIdx.x] = res[threadIdx.x];   // one wave: 24 consecutive host-mapped words
   }
-  // one wave wrote every device and host word: the same wave fences and its lane 0 publishes the sequence numbers
-  // behind them -- the device word first (rider mode: the point workgroups of this launch wait on it), then the host's
+  // rider mode: the point workgroups of this launch wait for the next damping and for nothing else of scal[] (what later
+  // kernels read of it crosses a kernel boundary) -- one device-scope store of the value itself into the word they poll
+  if (a.lam_slot && threadIdx.x == 0) __hip_atomic_store(a.lam_slot, res[S_LAM_NEXT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // one wave wrote every host word: the same wave fences and its lane 0 publishes the sequence number behind them
   if (threadIdx.x < 64) {
-    if (a.dev_flag) {
-      __threadfence();
-      if (threadIdx.x == 0) __hip_atomic_store(a.dev_flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
     if (a.host_flag) {
       __threadfence_system();
       if (threadIdx.x == 0) publish_flag(a.host_flag, a.seq, 0);

@@ -18,8 +18,17 @@
 //
 // Cross-workgroup data only moves through agent-scope atomic stores / loads (coherent whatever XCD a workgroup landed
 // on; measured ~1.8 doubles / ns per reading workgroup, tools/microbench/grid_barrier.hip -- hence the compact message)
-// and the barrier is one agent-scope counter (1.1 - 1.5 us).  Every spin is bounded: a workgroup that is not served
-// leaves with BA_ERR_HIP instead of hanging the device.  All sums keep a fixed order (lanes, waves, workgroups).
+// and the barrier is one agent-scope counter (1.1 - 1.5 us).  All sums keep a fixed order (lanes, waves, workgroups).
+//
+// Residency.  The workgroups meet at a counter barrier, so all G of them have to be resident together; an ordinary launch
+// does not promise that (another stream of the same process, a second handle or a profiler may hold compute units).
+// The host checks the occupancy query before it ever chooses this kernel (ba_set_problem), and the kernel never depends
+// on the answer: every spin is bounded by the 100 MHz wall clock (MW_SPIN_TICKS, 50 ms), a workgroup that is not
+// served reports BA_ERR_HIP in the summary and leaves, and the host then re-solves the SAME window with the
+// one-workgroup kernel (k_small_lm) in the same process (small_solve in ba_hip.hip).  The start point survives a failed
+// launch: the cameras in global memory are only written by the final block of a successful solve, and every workgroup
+// parks its landmarks' start positions in the (otherwise unused) y slots of the current point table before anything
+// else, from where the host side restores them.
 //
 // Limits (checked by the host, else k_small_lm runs): Nc <= 8 (instantiated for two, three and four 16-row tiles of [V; z]:
 // up to 5 / 7 / 8 cameras), 64 (G - 1) < Np <= 64 G with G <= 32, no landmark observed twice by one camera (so a track has at
@@ -52,14 +61,18 @@ constexpr int MW_SLABS = 3 * MW_PTS / 16;          // 12 slabs of 16 columns
 constexpr int MW_MSG = MwDim<4>::MSG + 3;          // stride of a workgroup's slot in the exchange buffer (any NT)
 constexpr int MW_SCAL = 8;
 constexpr int MW_MIN_PTS = 1;                     // (measured: no slower than k_small_lm even with one or two workgroups)
-constexpr int MW_SPIN_LIMIT = 1 << 24;         // (seconds: only a workgroup that is never scheduled gets there)
+// A barrier gives up after this many ticks of the 100 MHz wall clock (s_memrealtime): 50 ms.  At most three barriers can
+// time out one after the other in one launch (workgroups that were queued behind the ones that gave up arrive later and
+// wait in turn), far below the 20 s the host waits for the result word.
+constexpr long long MW_SPIN_TICKS = 5000000;
 
 struct MwArgs {
   SmallArgs A;
   const int* woff;                 // [(G + 1)][MW_MAX_CAMS]: camera c's observations of landmarks >= 64 g start here (index into c_pt / c_uv)
   int G;
-  double* slots;                   // [2][G][MW_MSG]   exchange 1, double-buffered by parity
-  double* sslots;                  // [2][G][MW_SCAL]  exchange 2
+  double* slots;                   // [2][G][MW_MSG]   exchange 1, double-buffered by its own parity
+  double* sslots;                  // [2][G][MW_SCAL]  exchange 2, double-buffered by its own parity
+  int G_barrier;                   // workgroups every barrier waits for: G (tests pass G + 1 to provoke the time-out path)
   unsigned long long* ctr;         // barrier counter; every launch counts from (its sequence number << 32): no clearing between launches
 };
 
@@ -103,7 +116,11 @@ k_small_mw(MwArgs M) {
   const int pl = tid / MW_LPP, sub = tid % MW_LPP;   // landmark of this thread inside the workgroup, lane inside the landmark
   const int p = g * MW_PTS + pl;
   const bool have_p = p < Np;
-  int xpar = 0;                                      // parity of the next exchange (both kinds share the counter)
+  // Each exchange buffer has a parity of its own: a workgroup that has passed the barrier of use u of a buffer may write
+  // its slot for use u + 1 (the other half) while a slower one still reads use u; it cannot reach use u + 2 (the same
+  // half again) before everybody has arrived at use u + 1, i.e. has finished reading use u.  No assumption about how the
+  // two kinds of exchange alternate.
+  int xpar1 = 0, xpar2 = 0;
   // the counter of this launch starts at (sequence number << 32): whichever workgroup comes first raises it there (an
   // idempotent maximum: later ones find it at or above), so no launch has to clear what the previous one left
   const unsigned long long ctr_base = (unsigned long long)A.seq << 32;
@@ -115,11 +132,16 @@ k_small_mw(MwArgs M) {
     __syncthreads();
     if (tid == 0) {
       __hip_atomic_fetch_add(M.ctr, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long target = ctr_base + (bar + 1) * (unsigned long long)G;
+      const unsigned long long target = ctr_base + (bar + 1) * (unsigned long long)M.G_barrier;
       int spins = 0, ok = 1;
+      long long t_start = 0;
       while (__hip_atomic_load(M.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > MW_SPIN_LIMIT) { ok = 0; break; }
+        if ((++spins & 63) == 0) {                       // the clock is read once per 64 polls
+          const long long now = (long long)wall_clock64();
+          if (t_start == 0) t_start = now;
+          else if (now - t_start > MW_SPIN_TICKS) { ok = 0; break; }
+        }
       }
       __atomic_thread_fence(__ATOMIC_ACQUIRE);
       s_ok = ok;
@@ -129,7 +151,7 @@ k_small_mw(MwArgs M) {
     return s_ok != 0;
   };
   // every workgroup's `len` words (src, LDS) summed in workgroup order into dst (LDS); word `max_at` (if >= 0): the maximum
-  auto exchange = [&](double* slots, int stride, const double* src, int len, double* dst, int max_at) -> bool {
+  auto exchange = [&](double* slots, int& xpar, int stride, const double* src, int len, double* dst, int max_at) -> bool {
     double* mine = slots + ((size_t)xpar * G + g) * stride;
     for (int i = tid; i < len; i += MW_THREADS) __hip_atomic_store(mine + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!barrier()) return false;
@@ -157,7 +179,7 @@ k_small_mw(MwArgs M) {
   };
   auto give_up = [&]() {                              // a barrier timed out: report, never hang
     if (g == 0 && tid == 0) {
-      A.summary->status = BA_ERR_HIP; A.summary->iterations = -1;
+      A.summary->status = BA_ERR_HIP; A.summary->iterations = -1; A.summary->accepted = s_acc;
       *A.cur_out = A.cur;
       publish_flag(A.host_flag, A.seq, 1);
     }
@@ -181,6 +203,14 @@ k_small_mw(MwArgs M) {
     l_ij[t] = (unsigned short)(i | (j << 8));
   }
   if (tid == 0) { s_cur = A.cur; s_lambda = A.lambda0; s_nu = 2.0; s_stop = 0; s_it = 0; s_acc = 0; s_status = 0; }
+  // the start positions of the own landmarks, parked in the y slots of the current point table (this kernel keeps y in
+  // registers and never reads or writes those slots otherwise): what the host restores the window from if a barrier
+  // times out after steps have already been taken (k_small_restore)
+  if (have_p && sub == 0) {
+    const double4 X = *(const double4*)(A.ptab[A.cur] + PT * (size_t)p);
+    double* o = A.ptab[A.cur] + PT * (size_t)p + 4;
+    o[0] = X.x; o[1] = X.y; o[2] = X.z;
+  }
   __syncthreads();
 
   // cost over this workgroup's slices at parameter set w: wave c < Nc walks camera c's slice -> l_sc[4] = sse, l_sc[5] = sum rho
@@ -214,7 +244,7 @@ k_small_mw(MwArgs M) {
   slice_cost(A.cur);
   if (tid < 4) l_sc[tid] = 0.0;
   __syncthreads();
-  if (!exchange(M.sslots, MW_SCAL, l_sc, 6, l_tot, -1)) { give_up(); return; }
+  if (!exchange(M.sslots, xpar2, MW_SCAL, l_sc, 6, l_tot, -1)) { give_up(); return; }
   if (tid == 0) {
     s_sse = l_tot[4]; s_cost = 0.5 * l_tot[5];
     if (g == 0) { A.summary->initial_sse = s_sse; A.summary->initial_cost = s_cost; }
@@ -400,7 +430,7 @@ k_small_mw(MwArgs M) {
     __syncthreads();
     MW_STAMP(3);
     // ---- exchange 1
-    if (!exchange(M.slots, MW_MSG, l_msg, msg_len, l_msg, msg_len - 1)) { give_up(); return; }
+    if (!exchange(M.slots, xpar1, MW_MSG, l_msg, msg_len, l_msg, msg_len - 1)) { give_up(); return; }
     MW_STAMP(4);
     // ---- S, g (every workgroup the same): damping from the summed diagonal; fixed camera: identity rows / columns
     for (int t = tid; t < nS; t += MW_THREADS) {         // both triangles from the message's upper one
@@ -529,7 +559,7 @@ k_small_mw(MwArgs M) {
     slice_cost(tr);                                      // l_sc[4], l_sc[5]
     MW_STAMP(8);
     // ---- exchange 2: the step's scalars; then the verdict, the same in every workgroup
-    if (!exchange(M.sslots, MW_SCAL, l_sc, 6, l_tot, -1)) { give_up(); return; }
+    if (!exchange(M.sslots, xpar2, MW_SCAL, l_sc, 6, l_tot, -1)) { give_up(); return; }
     MW_STAMP(9);
     if (tid == 0) {
       double gTd = l_tot[0], dDd = l_tot[1], step2 = l_tot[2], x2 = l_tot[3];
@@ -582,6 +612,15 @@ k_small_mw(MwArgs M) {
     *A.cur_out = fin;
     publish_flag(A.host_flag, A.seq, 1);
   }
+}
+
+// After a k_small_mw launch that gave up at a barrier: the start positions back from the y slots into the X slots of the
+// point table the solve started from (the cameras of that set were never written).
+__global__ void k_small_restore(double* __restrict__ ptab, int n_pts) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pts) return;
+  double* o = ptab + PT * (size_t)p;
+  o[0] = o[4]; o[1] = o[5]; o[2] = o[6];
 }
 
 }  // namespace ba

@@ -93,7 +93,11 @@ SYMBOLS = {
     "ba_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _DP]),
     "ba_triangulate": (C.c_int, [C.c_void_p, _DP, _DP, _DP, C.c_int64, _DP, _DP, _DP, C.POINTER(C.c_uint8)]),
     "ba_get_trace": (C.c_int, [C.c_void_p, C.POINTER(BAIterRecord), C.c_int32, C.POINTER(C.c_int32)]),
+    "ba_get_stat": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
+    "ba_debug_occupy": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double]),
 }
+# enum ba_stat (include/ba_hip.h)
+STATS = {"window_mw_launches": 0, "window_lm_launches": 1, "window_fallbacks": 2, "precond_builds": 3, "precond_reuses": 4}
 
 
 def load_library():
@@ -234,15 +238,7 @@ class Solver:
     def solve(self, **kw):
         """kw: loss ('linear'|'huber'), preconditioner ('jacobi'|'schur_jacobi') or any
         ba_options field.  Returns the summary as a dict."""
-        o = self.default_options()
-        for k, v in kw.items():
-            if k == "loss":
-                v = LOSS[v] if isinstance(v, str) else v
-            if k == "preconditioner":
-                v = PRECOND[v] if isinstance(v, str) else v
-            if not hasattr(o, k):
-                raise TypeError(f"unknown option {k}")
-            setattr(o, k, v)
+        o = self._options(kw)
         s = BASummary()
         _check(self._lib.ba_solve(self._h, C.byref(o), C.byref(s)))
         return s.as_dict()
@@ -289,6 +285,7 @@ class Solver:
         return s.as_dict()
 
     def _options(self, kw):
+        """ba_default_options overlaid with kw (loss / preconditioner by name or by value, any other ba_options field)."""
         o = self.default_options()
         for k, v in kw.items():
             if k == "loss":
@@ -304,15 +301,7 @@ class Solver:
         """ba_solve_bal on a bal.BALProblem (9-parameter cameras, f / k1 / k2 adjusted with the pose): returns
         (summary dict, cams (Nc,9), pts (Np,3)).  kw as for solve()."""
         intr = self._set_bal(bal, fixed_cam)
-        o = self.default_options()
-        for k, v in kw.items():
-            if k == "loss":
-                v = LOSS[v] if isinstance(v, str) else v
-            if k == "preconditioner":
-                v = PRECOND[v] if isinstance(v, str) else v
-            if not hasattr(o, k):
-                raise TypeError(f"unknown option {k}")
-            setattr(o, k, v)
+        o = self._options(kw)
         s = BASummary()
         _check(self._lib.ba_solve_bal(self._h, _dp(intr), C.byref(o), C.byref(s)))
         cams6, pts = self.get_params()
@@ -365,3 +354,16 @@ class Solver:
 
     def synchronize(self):
         _check(self._lib.ba_synchronize(self._h))
+
+    def stats(self):
+        """Event counters of the handle (ba_get_stat): dict name -> count since the handle was created."""
+        out = {}
+        for name, which in STATS.items():
+            v = C.c_int64(0)
+            _check(self._lib.ba_get_stat(self._h, which, C.byref(v)))
+            out[name] = v.value
+        return out
+
+    def debug_occupy(self, n_workgroups, lds_bytes, milliseconds):
+        """Test hook (ba_debug_occupy): idle workgroups on a second stream hold compute units' LDS for a bounded time."""
+        _check(self._lib.ba_debug_occupy(self._h, int(n_workgroups), int(lds_bytes), float(milliseconds)))

@@ -132,8 +132,26 @@ enum ba_kernel_slot {
   BA_K_PRECOND = 8, BA_K_BACKSUB = 9, BA_K_MISC = 10, BA_K_ALLREDUCE = 11
 };
 
+/* Event counters of a handle (ba_get_stat): which implementation served the window-sized solves, how often the
+ * multi-workgroup window solver had to be replaced by the one-workgroup kernel (its workgroups were not resident together:
+ * csrc/ba_small_mw.hpp), how often the multi-kernel loop built / kept the Schur-Jacobi preconditioner. */
+enum ba_stat {
+  BA_STAT_WINDOW_MW_LAUNCHES = 0,   /* launches of k_small_mw (several cooperating workgroups) */
+  BA_STAT_WINDOW_LM_LAUNCHES = 1,   /* launches of k_small_lm (one workgroup) */
+  BA_STAT_WINDOW_FALLBACKS = 2,     /* k_small_mw gave up at a barrier and the window was re-solved by k_small_lm */
+  BA_STAT_PRECOND_BUILDS = 3,       /* damped systems whose Schur-Jacobi blocks were rebuilt */
+  BA_STAT_PRECOND_REUSES = 4,       /* damped systems that kept the previous blocks (ba_options.precond_lag) */
+  BA_STAT_COUNT = 8
+};
+
 const char* ba_last_error(void);
 const char* ba_kernel_name(int slot);
+/* *value = counter `which` (ba_stat) of the handle since ba_create. */
+int ba_get_stat(ba_handle* h, int32_t which, int64_t* value);
+/* Test hook: occupies compute units from a SECOND stream of the handle -- n_workgroups workgroups of 256 threads with
+ * lds_bytes of LDS each idle for `milliseconds` (at most 2000) of the device's wall clock, then leave.  Returns at once.
+ * Lets a test hold the units the window solver's workgroups would need (tests/test_gpu_small.py). */
+int ba_debug_occupy(ba_handle* h, int32_t n_workgroups, int32_t lds_bytes, double milliseconds);
 /* Batched two-view triangulation + cheirality test: replaces VisualOdometryPipeline._triangulate_points,
  * src/pipeline.py:315-336 (cv2.triangulatePoints on P1 = K [I|0], P2 = K [R_rel|t_rel], division by (w + 1e-6),
  * z > 0 in both cameras).  K, R_rel row-major 3x3; pts1 / pts2 double[n][2] pixels in the two views; xyz double[n][3]
@@ -190,16 +208,21 @@ int ba_residuals_bal(ba_handle* h, const double* intr, int32_t loss, double f_sc
 /* K2 for the BAL camera (parity hook, like ba_linearize): block normal equations at the current parameters with the 2x9
  * camera block [d/d rvec (additive) | d/d t | d/d f | d/d k1 | d/d k2].  Outputs (any may be NULL):
  *   Hcc double[Nc][45]  upper triangle of Jc^T w Jc, row-major (00 01 .. 08 11 .. 88);  bc double[Nc][9]  Jc^T w r
- *   Hpp double[Np][6], bp double[Np][3] as ba_linearize.  The fixed camera's blocks are zero.  Single rank. */
+ *   Hpp double[Np][6], bp double[Np][3] as ba_linearize.  The fixed camera's blocks are zero.  In a multi-rank job Hcc | bc
+ *   are all-reduced like ba_linearize's, Hpp | bp are the calling rank's shard. */
 int ba_linearize_bal(ba_handle* h, const double* intr, int32_t loss, double f_scale, double* Hcc, double* bc, double* Hpp,
                      double* bp);
 
-/* The solve step for the BAL 9-parameter camera (csrc/ba_bal.hpp): LM + Schur complement + matrix-free PCG with 9x9 camera
- * blocks; preconditioner BA_PRECOND_JACOBI (damped 9x9 camera blocks) or Schur-Jacobi (their Schur complements: the
- * default; BA_PRECOND_TWO_LEVEL means Schur-Jacobi here); same damping / gain-ratio / stopping rules, options, summary
- * and trace as ba_solve (jacobian_precision and small_solver are ignored).  Cameras (rvec, t) and points are the
+/* The solve step for the BAL 9-parameter camera: the SAME kernels and host loop as ba_solve, instantiated for the second
+ * camera model of csrc/ba_models.hpp (BalCam; kernels in csrc/ba_kernels.hpp are templates over the model): LM + Schur
+ * complement + matrix-free PCG with 9x9 camera blocks, device-side PCG / LM verdicts, speculated linearisation;
+ * preconditioner BA_PRECOND_JACOBI (damped 9x9 camera blocks) or Schur-Jacobi (their Schur complements: the default;
+ * BA_PRECOND_TWO_LEVEL means Schur-Jacobi here).  Same damping / gain-ratio / stopping rules, options, summary and trace as
+ * ba_solve; jacobian_precision is honoured (1 = BASELINE config 5's "fp32 Jacobian + fp64 solve"); small_solver is ignored
+ * (the window solver is built for the reference's pinhole only).  Multi-rank jobs are supported exactly as in ba_solve
+ * (landmark shards, the same all-reduces; fold sizes follow the 9-parameter blocks).  Cameras (rvec, t) and points are the
  * handle's (ba_set_params before, ba_get_params after); intr double[Nc][3] = (f, k1, k2) per camera is read AND updated.
- * fixed_cam of ba_set_problem is honoured (-1: no camera held; the damping carries the gauge).  Single rank. */
+ * fixed_cam of ba_set_problem is honoured (-1: no camera held; the damping carries the gauge). */
 int ba_solve_bal(ba_handle* h, double* intr, const ba_options* opts, ba_summary* sum);
 
 /* K2/K3: linearise at the current parameters.  Outputs (any may be NULL):

@@ -517,7 +517,7 @@ def lm_solve(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam=-1, loss='linear',
     linear_solver='dense' solves the explicit reduced system (schur_dense) exactly instead, as the
     single-launch solver for window-sized problems does (csrc/ba_small.hpp).
     model='bal': the 9-parameter BAL camera [rvec | t | f k1 k2] (bal_residuals, bal_normal_equations; K4 is ignored) --
-    the mirror of ba_solve_bal (csrc/ba_bal.hpp); same loop, 9x9 camera blocks.
+    the mirror of ba_solve_bal (the BalCam instantiation of the loop, csrc/ba_models.hpp); same loop, 9x9 camera blocks.
     Returns dict(cams, pts, iterations, accepted, sse0, sse, cost0, cost, pcg_iters,
     history)."""
     nb = 9 if model == 'bal' else 6

@@ -2,6 +2,8 @@
 BundleAdjuster(window_size=5), src/pipeline.py:39,99).  Same options / summary / trace as the multi-kernel path; the
 reduced camera system is solved exactly (dense Cholesky) instead of by PCG, so the two paths walk different LM
 trajectories to the SAME minimiser."""
+import time
+
 import numpy as np
 import pytest
 
@@ -278,3 +280,59 @@ def test_multi_workgroup_window_solver_on_random_window_shapes(monkeypatch):
             # Gauss-Jordan sweeps and the Cholesky factorisation then differ by more than on the well-posed windows above)
             assert abs(o1["final_cost"] - o0["final_cost"]) <= 1e-7 * o0["final_cost"], what
 
+
+
+def test_window_solver_falls_back_when_a_barrier_is_not_served(monkeypatch):
+    """The workgroups of k_small_mw meet at a counter barrier and the launch is an ordinary one: nothing promises that they
+    are resident together.  BA_DEBUG_MW_EXTRA_WG makes every barrier wait for one workgroup more than the launch has, i.e.
+    the bounded spin (50 ms of the device clock) runs out at the first barrier in every workgroup.  ba_solve must then
+    return BA_OK with the result of the one-workgroup kernel on the SAME start point, in the same process, and count the
+    fall-back; the next solve on the handle (hook off) goes through k_small_mw again."""
+    p = make_problem(5, 500, 4, seed=77, outlier_frac=0.02)
+    kw = dict(loss="huber", max_iters=8, ftol=0.0, xtol=0.0, gtol=0.0)
+    with hip_backend.Solver(0) as s:
+        monkeypatch.setenv("BA_SMALL_MW", "0")
+        s.set_problem(p)
+        ref, ref_par = s.solve(**kw), s.get_params()
+        monkeypatch.delenv("BA_SMALL_MW")
+        st0 = s.stats()
+        monkeypatch.setenv("BA_DEBUG_MW_EXTRA_WG", "1")
+        s.set_problem(p)
+        out, par = s.solve(**kw), s.get_params()
+        st1 = s.stats()
+        assert st1["window_fallbacks"] == st0["window_fallbacks"] + 1
+        assert st1["window_mw_launches"] == st0["window_mw_launches"] + 1 and st1["window_lm_launches"] == st0["window_lm_launches"] + 1
+        # the very kernel, the very start point: identical bits
+        assert out["iterations"] == ref["iterations"] == 8 and out["final_cost"] == ref["final_cost"] and out["final_sse"] == ref["final_sse"]
+        assert np.array_equal(par[0], ref_par[0]) and np.array_equal(par[1], ref_par[1])
+        assert out["seconds_total"] < 2.0                      # a handful of 50 ms time-outs, not the host's 20 s limit
+        monkeypatch.delenv("BA_DEBUG_MW_EXTRA_WG")
+        s.set_problem(p)
+        again = s.solve(**kw)
+        st2 = s.stats()
+        assert st2["window_fallbacks"] == st1["window_fallbacks"] and st2["window_mw_launches"] == st1["window_mw_launches"] + 1
+        assert abs(again["final_cost"] - ref["final_cost"]) <= 1e-10 * ref["final_cost"]
+
+
+def test_window_solver_survives_a_chip_somebody_else_occupies():
+    """every compute unit but four holds a resident workgroup of ANOTHER stream with 100 KB of LDS
+    (ba_debug_occupy: idle workgroups that leave after 600 ms of the device clock), so at most four of the eight workgroups
+    of a 5-camera / 500-landmark window's k_small_mw launch (87 KB of LDS each) can be resident together.  The solve must
+    come back BA_OK with the oracle's cost; whether it needed the fall-back depends on where the runtime put the
+    occupying workgroups, so the counter is only reported -- the forced variant above asserts it."""
+    p = make_problem(5, 500, 4, seed=78, outlier_frac=0.02)
+    kw = dict(loss="huber", max_iters=30, ftol=1e-12, xtol=1e-12, gtol=0.0)
+    ref = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, 0, linear_solver="dense", **kw)
+    with hip_backend.Solver(0) as s, hip_backend.Solver(0) as hog:
+        s.set_problem(p)
+        n_cu = 256
+        hog.debug_occupy(n_cu - 4, 100 * 1024, 600.0)
+        time.sleep(0.02)                                         # the occupying workgroups are resident by now
+        t0 = time.perf_counter()
+        out = s.solve(**kw)
+        dt = time.perf_counter() - t0
+        st = s.stats()
+        hog.synchronize()
+    print(f"occupied chip: solve {dt * 1e3:.1f} ms, fall-backs {st['window_fallbacks']}, status {out['status_name']}")
+    assert abs(out["final_cost"] - ref["cost"]) <= 1e-8 * ref["cost"]
+    assert dt < 5.0

@@ -226,3 +226,24 @@ def test_two_rank_spmd_run_matches_single_rank_host_logic():
         assert abs(sse - ba.last_summary["final_sse"]) <= 1e-9 * sse
     np.testing.assert_array_equal(got[0][2], got[1][2])              # both ranks end with the same map
     np.testing.assert_array_equal(got[0][3], got[1][3])
+
+
+def test_bench_without_a_launcher_refuses_instead_of_timing_one_rank():
+    """CPU (no GPU in this container): `python bench.py --gpus 2` with no WORLD_SIZE starts its two ranks itself; they find
+    no device, so the command must end NON-ZERO and print no result line -- in particular not a line for one GPU, which
+    is what round 3's bench silently produced when it was run without a launcher.  A launcher environment that disagrees
+    with --gpus is refused as well."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--config", "C1",
+           "--repeats", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode != 0
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{"):
+            assert "value" not in json.loads(ln)
+    r = subprocess.run(cmd, env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120, cwd=root)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
