@@ -223,8 +223,12 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--pcg-tol", type=float, default=0.1)
     ap.add_argument("--pcg-max-iters", type=int, default=200)
-    ap.add_argument("--pcg-model-tol", type=float, default=0.0, help="Nash & Sofer model test of the PCG loop (ba_options.pcg_model_tol; 0 = off)")
+    ap.add_argument("--pcg-model-tol", type=float, default=-1.0,
+                    help="Nash & Sofer model test of the PCG loop (ba_options.pcg_model_tol; 0 = off; -1 = the library's default: "
+                         "0.5 on band-structured problems on one rank, else off)")
     ap.add_argument("--precond", default="schur_jacobi", choices=["schur_jacobi", "jacobi", "two_level"])
+    ap.add_argument("--precond-lag", type=int, default=None,
+                    help="ba_options.precond_lag: damped systems that may keep the Schur-Jacobi blocks of an earlier one (default: the library's)")
     ap.add_argument("--jacobian", default="f64", choices=["f64", "f32"], help="f32: config 5's fp32 Jacobian blocks in the PCG passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=11, help="timed repeats of the K-step solve; value = the median repeat")
@@ -339,6 +343,11 @@ def main():
     kw = dict(loss=args.loss, ftol=0.0, xtol=0.0, gtol=1e-300, pcg_tol=args.pcg_tol, pcg_max_iters=args.pcg_max_iters,
               pcg_model_tol=args.pcg_model_tol,
               preconditioner=args.precond, jacobian_precision=1 if args.jacobian == "f32" else 0)
+    if args.precond_lag is not None:
+        kw["precond_lag"] = args.precond_lag
+
+    # the PCG model test in effect (ba_options.pcg_model_tol = -1 resolves inside the library; mirrored here for the line)
+    model_tol_eff = args.pcg_model_tol if args.pcg_model_tol >= 0 else (0.5 if (solver.stats()["banded"] and world == 1 and not os.environ.get("BA_COMM_FORCE")) else 0.0)
 
     def run_solve(**k):
         if intr0 is not None:
@@ -472,7 +481,7 @@ def main():
             "dtype": "f64" if args.jacobian == "f64" else "f64 accumulation and solve, f32 Jacobian blocks in the PCG passes",
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {prob.n_cams} cams / {prob.n_pts} pts / {n_obs_total} obs, "
-                                   f"loss={args.loss}, LM+Schur+PCG(tol {args.pcg_tol}, model test {args.pcg_model_tol})"
+                                   f"loss={args.loss}, LM+Schur+PCG(tol {args.pcg_tol}, model test {model_tol_eff})"
                                    + (", BAL 9-parameter camera (f, k1, k2 per camera, adjusted)" if intr0 is not None else ""),
                        "camera": args.camera,
                        "parallelism": f"landmark-sharded x{world}" if world > 1 else "single GPU", "comm": comm_note,

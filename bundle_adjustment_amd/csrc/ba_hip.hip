@@ -203,6 +203,7 @@ struct ba_handle {
   int mw_resident[3] = {-1, -1, -1};   // workgroups of k_small_mw<2 / 3 / 4> the device holds at once (occupancy query, once per handle)
   long long stats[BA_STAT_COUNT] = {0};   // ba_get_stat
   // two-level preconditioner for band-structured problems (ba_coarse.hpp): structures built by ba_set_problem
+  bool banded = false;         // mean camera span of a track <= Nc / 8 (sequential captures): pcg_model_tol's automatic default
   bool two_level_ok = false;   // this problem has them
   bool two_level = false;      // the current solve uses them
   int n_agg = 0, n_runs = 0, n_pairs = 0, coarse_bw = 0;
@@ -244,7 +245,7 @@ struct ba_handle {
   bool profile = false;
   std::vector<hipEvent_t> ev;
   std::vector<int> ev_slot;
-  size_t ev_used = 0;
+  size_t ev_used = 0, n_flushes = 0;
   ba_profile prof = {};
   std::vector<float> prof_ms[BA_PROFILE_SLOTS];   // every measured duration, per slot
 };
@@ -475,6 +476,7 @@ static void flush_profile(ba_handle* h) {
   }
   h->ev_used = 0;
   h->ev_slot.clear();
+  h->n_flushes++;
 }
 extern "C" int ba_get_profile(ba_handle* h, ba_profile* out) {
   if (!h || !out) return fail(BA_ERR_INVALID, "null argument");
@@ -851,7 +853,9 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
       span_sum += hi - lo;
       ++tracks;
     }
-    bool want = tracks > 0 && span_sum / tracks <= Nc / 8.0 && !h->multi;
+    h->banded = tracks > 0 && span_sum / tracks <= Nc / 8.0;
+    h->stats[BA_STAT_BANDED] = h->banded ? 1 : 0;
+    bool want = h->banded && !h->multi;
     if (const char* e = getenv("BA_TWO_LEVEL")) want = atoi(e) != 0 && !h->multi;
     if (want && Nc >= 2 * VEC_CAMS && Np > 0 && No > 0) {
       std::vector<std::pair<int, int>> tmp;
@@ -1211,7 +1215,7 @@ static void launch_residual(ba_handle* h, int which, bool robust, double fscale,
 // results go straight to the host-mapped mirror (no copy kernel)
 // decide (single rank): the same kernel also computes the gain ratio and the next damping (lm_decide)
 static ScalarsArgs scalars_args(ba_handle* h, bool with_step, int k, double tol2, int min_iters, long long seq, double cost_cur,
-                                double lambda) {
+                                double lambda, double lam_floor = 0.0) {
   const bool direct = with_step && !h->multi;         // results straight into host-mapped memory + sequence word
   ScalarsArgs a;
   a.partR = h->partR.p; a.nR = NPART * h->Nc;
@@ -1223,14 +1227,14 @@ static ScalarsArgs scalars_args(ba_handle* h, bool with_step, int k, double tol2
   a.tol2 = tol2; a.min_iters = min_iters;
   a.scal = h->scal.p; a.scal_host = direct ? h->d_scal_host : (double*)nullptr;
   a.host_flag = direct ? h->d_flags + 2 : (long long*)nullptr; a.seq = seq;
-  a.decide = direct ? 1 : 0; a.cost_cur = cost_cur; a.lambda = lambda;
+  a.decide = direct ? 1 : 0; a.cost_cur = cost_cur; a.lambda = lambda; a.lam_floor = lam_floor;
   a.lam_slot = nullptr; a.err_flag = nullptr; a.on = 0;
   return a;
 }
 static void launch_scalars(ba_handle* h, bool with_step, int k = 0, double tol2 = 0.0, int min_iters = 0, long long seq = 0,
-                           double cost_cur = 0.0, double lambda = 0.0) {
+                           double cost_cur = 0.0, double lambda = 0.0, double lam_floor = 0.0) {
   Scope sc(h, BA_K_MISC);
-  BA_LAUNCH(k_scalars, dim3(1), dim3(1024), 0, h->stream, scalars_args(h, with_step, k, tol2, min_iters, seq, cost_cur, lambda));
+  BA_LAUNCH(k_scalars, dim3(1), dim3(1024), 0, h->stream, scalars_args(h, with_step, k, tol2, min_iters, seq, cost_cur, lambda, lam_floor));
 }
 // spin on a host-mapped sequence word until it reaches `target` (the device publishes with a
 // system-scope release); a wall-clock limit turns a wedged GPU into an error instead of a hang
@@ -1394,7 +1398,8 @@ template <class CM>
 static void launch_pt_schur_t(ba_handle* h, bool robust, int mode, int k, double tol2, int min_iters, long long flag_base,
                               double* gmax_out, const CamUpdateArgs& cu) {
   const int w = h->cur;
-  const int ride = (mode == 1) ? cu.n_blocks : 0;      // the camera update as extra workgroups of the back substitution
+  const int ride = (mode == 1 || cu.fuse) ? cu.n_blocks : 0;      // the camera update as extra workgroups of the back substitution
+                                                                  // (or of the PCG point pass that may turn into it: cu.fuse)
 #define PS_HEAD h->camA[w].p, h->ptab[w].p, h->pt_off.p, (robust ? h->p_camf[h->pb].p : h->p_cam.p), h->p_w[h->pb].p,                 \
                 h->Hppinv[h->pb].p, h->blk_win.p
 #define PS_TAIL h->K4[0], h->K4[1], h->fixed, h->partA.p, k, h->st.p, h->partV.p, nbv(h), tol2, min_iters, h->y0[h->pb].p,     \
@@ -1500,10 +1505,11 @@ static int exchange_system(ba_handle* h, bool with_diag) {
   return allreduce(h, h->sysmsg.p, 2 + n6 + nE + (size_t)h->world);
 }
 // finalize = true: fold the fresh camera-half partials into Hcc | bc inside the same kernel
-static void launch_pcg_setup(ba_handle* h, double lambda, bool schur_diag, bool finalize) {
+// precond: 0 = Jacobi blocks, 1 = Schur-Jacobi blocks from partE, 2 = keep the blocks already in Minv (k_pcg_setup)
+static void launch_pcg_setup(ba_handle* h, double lambda, int precond, bool finalize) {
   Scope sc(h, BA_K_PCG_UPDATE);
 #define SU_ARGS partL_of(h, h->lb), h->HccBc.p, bc_ptr(h), sys_p6(h), sys_E(h), nparts_of(h), h->cs[h->cur].p, lambda,           \
-                schur_diag ? 1 : 0, h->Nc, h->fixed, h->Hccd.p, h->Minv.p, h->gvec.p, h->x.p, h->r.p, h->p.p, h->s.p,     \
+                precond, h->Nc, h->fixed, h->Hccd.p, h->Minv.p, h->gvec.p, h->x.p, h->r.p, h->p.p, h->s.p,     \
                 h->z.p, h->camA[h->cur].p, h->partV.p, h->st.p, h->partGc.p, (h->two_level ? h->coarse_rc.p : (double*)nullptr), h->vx.p
 #define CALL_T(CM)                                                                                               \
   do {                                                                                                           \
@@ -1635,12 +1641,17 @@ static void coarse_build(ba_handle* h) {
 // invert: (re)compute the damped point inverses (not needed right after launch_lin_pt at the
 // same lambda); finalize: Hcc | bc still have to be folded from the camera-half partials
 static void coarse_build(ba_handle* h);
-static int damped_system(ba_handle* h, double lambda, bool schur_diag, bool invert = true, bool finalize = false) {
+// keep = true (Schur-Jacobi only, ba_options.precond_lag): the preconditioner blocks in Minv stay as they are -- the
+// right-hand side W y0 then comes from the 6-sum camera pass (k_cam_schur) instead of the 27-sum one that also builds
+// the blocks' Schur terms, and k_pcg_setup neither folds them nor inverts anything
+static int damped_system(ba_handle* h, double lambda, bool schur_diag, bool invert = true, bool finalize = false, bool keep = false) {
   if (invert) launch_point_invert(h, lambda);
-  launch_cam_schur(h, h->lin_robust, schur_diag, false, 0, 0.0, 0);
-  if (int rc = exchange_system(h, schur_diag)) return rc;
-  launch_pcg_setup(h, lambda, schur_diag, finalize);
+  const bool diag_pass = schur_diag && !keep;
+  launch_cam_schur(h, h->lin_robust, diag_pass, false, 0, 0.0, 0);
+  if (int rc = exchange_system(h, diag_pass)) return rc;
+  launch_pcg_setup(h, lambda, schur_diag ? (keep ? 2 : 1) : 0, finalize);
   if (h->two_level) coarse_build(h);
+  if (schur_diag) h->stats[keep ? BA_STAT_PRECOND_REUSES : BA_STAT_PRECOND_BUILDS]++;
   return BA_OK;
 }
 
@@ -1698,8 +1709,10 @@ extern "C" int ba_default_options(ba_options* o) {
   o->reserved0 = 0;
   o->profile = 0;
   o->verbose = 0;
-  o->pcg_model_tol = 0.0;           // Nash & Sofer's truncated-Newton test on the quadratic model: off (ba_hip.h; 0.5 is their value)
+  o->pcg_model_tol = -1.0;          // Nash & Sofer's truncated-Newton test on the quadratic model: automatic -- 0.5 (their value) on
+                                    // band-structured problems, off otherwise (ba_hip.h)
   o->pcg_model_min_iters = 5;
+  o->precond_lag = 3;
   return BA_OK;
 }
 
@@ -1947,7 +1960,9 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   if (opts->jacobian_precision != 0 && opts->jacobian_precision != 1)
     return fail(BA_ERR_INVALID, "jacobian_precision must be 0 (f64) or 1 (f32 blocks, f64 accumulation)");
   if (opts->preconditioner < BA_PRECOND_JACOBI || opts->preconditioner > BA_PRECOND_TWO_LEVEL) return fail(BA_ERR_INVALID, "unknown preconditioner");
-  if (!(opts->pcg_model_tol >= 0.0) || opts->pcg_model_min_iters < 0) return fail(BA_ERR_INVALID, "bad pcg_model_tol / pcg_model_min_iters");
+  if (!(opts->pcg_model_tol >= 0.0 || opts->pcg_model_tol == -1.0) || opts->pcg_model_min_iters < 0)
+    return fail(BA_ERR_INVALID, "bad pcg_model_tol (>= 0, or -1 = automatic) / pcg_model_min_iters");
+  if (opts->precond_lag < 0) return fail(BA_ERR_INVALID, "precond_lag must not be negative");
   if (set_device(h)) return BA_ERR_HIP;
   memset(sum, 0, sizeof *sum);
   h->trace.clear();
@@ -1970,6 +1985,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   const int Nc = h->Nc;
   h->profile = opts->profile != 0;
   const double tol2 = opts->pcg_tol * opts->pcg_tol;
+  const double model_tol = opts->pcg_model_tol >= 0.0 ? opts->pcg_model_tol : ((h->banded && !h->multi) ? 0.5 : 0.0);
 
   BA_SYNC(h);
   const double t_begin = now_s();
@@ -1988,10 +2004,21 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   }
   const bool debug_poison = getenv("BA_DEBUG_POISON_TRIAL") != nullptr;     // tests: every trial cost comes out NaN
   // BA_RIDERS: bit 0 = the camera update rides along the back substitution, bit 1 = the scalar fold + verdict rides along
-  // the speculated point half (ba_kernels.hpp, "riders"); BA_NO_RIDERS / BA_RIDERS=0: launches of their own (tuning, tests)
-  const int riders = getenv("BA_NO_RIDERS") ? 0 : (getenv("BA_RIDERS") ? atoi(getenv("BA_RIDERS")) : 3);
+  // the speculated point half (ba_kernels.hpp, "riders"), bit 2 = the PCG probe that finds PCG finished goes on as the back
+  // substitution in the same launch (needs bit 0); BA_NO_RIDERS / BA_RIDERS=0: launches of their own (tuning, tests)
+  const int riders = getenv("BA_NO_RIDERS") ? 0 : (getenv("BA_RIDERS") ? atoi(getenv("BA_RIDERS")) : 7);
   double lambda = opts->initial_lambda, nu = 2.0;
   int it = 0, status = 0;
+  // Schur-Jacobi blocks kept over consecutive damped systems (ba_options.precond_lag): when they were built, how often they
+  // have been kept since, and what the inner solves cost with them.  Host-side and deterministic: the rule reads options,
+  // dampings and PCG iteration counts only (identical on every rank of a multi-rank job).
+  const bool cap_floor = getenv("BA_NO_CAP_FLOOR") == nullptr;      // (switch for A / B measurements)
+  double lam_floor = 0.0;
+  bool have_precond = false;
+  double lam_built = 0.0;
+  double last_decrease = 1.0;      // relative cost decrease of the last accepted step
+  int kept = 0, pcg_at_build = -1, pcg_last = -1;
+  const int lag = (schur_diag && !h->two_level) ? opts->precond_lag : 0;
   bool need_linearize = true;      // a linearisation at the current parameters is needed before the next damped system
   bool have_lin = false;           // ... and buffer sets [lb] / [pb] already hold it (speculated at the trial point that was accepted)
   h->linearized = false;
@@ -2015,7 +2042,14 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       fresh = true;
     }
     // ---- damped system, right-hand side, preconditioner, first PCG vectors
-    { Range r_damp("damped_system"); if (int rc = damped_system(h, lambda, schur_diag, !fresh, fresh)) return rc; }
+    // (!fresh: the same linearisation damped again after a rejected step; else the point the blocks were built at has moved by
+    // a step that lowered the cost by no more than 1 % -- early, large steps always rebuild: there a stale preconditioner
+    // costs more PCG iterations, at three passes each, than the one 27-sum pass it saves)
+    const bool keep = lag > 0 && have_precond && kept < lag && lambda <= 10.0 * lam_built && lambda >= 0.1 * lam_built &&
+                      (pcg_at_build < 0 || pcg_last <= pcg_at_build + pcg_at_build / 2 + 2) && (!fresh || last_decrease <= 1e-2);
+    { Range r_damp("damped_system"); if (int rc = damped_system(h, lambda, schur_diag, !fresh, fresh, keep)) return rc; }
+    if (keep) ++kept;
+    else { have_precond = schur_diag; lam_built = lambda; kept = 0; pcg_at_build = -1; }
     bool gtol_pending = false;     // single rank: max |gradient| lands in host-mapped memory, read at the first PCG verdict
     if (fresh && opts->gtol > 0) {
       // max |gradient| = max(|bc|, |bp|): per-workgroup maxima come out of the point half (partG) and of
@@ -2035,9 +2069,30 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     bool gtol_stop = false;
     const long long base = h->flag_base;
     h->flag_base += opts->pcg_max_iters + 8;
+    // K7a + K6 arguments.  The camera update does not feed the back substitution except through the step's vt, which the point
+    // workgroups drop into the rows of their LDS windows themselves (vx): it rides along the same launch as extra
+    // workgroups (ba_kernels.hpp, "riders") whenever every window is staged in LDS; else it is a launch of its own.
+    CamUpdateArgs cu;
+    memset(&cu, 0, sizeof cu);
+    cu.cams = h->cams[h->cur].p; cu.intr = h->intr[h->cur].p; cu.dc = h->x.p; cu.rpcg = h->r.p; cu.Hcc = h->HccBc.p; cu.bc = bc_ptr(h);
+    cu.cs = h->cs[h->cur].p; cu.cams_trial = h->cams[1 - h->cur].p; cu.intr_trial = h->intr[1 - h->cur].p; cu.cs_trial = h->cs[1 - h->cur].p;
+    cu.vtil = h->camA[h->cur].p; cu.camA_trial = h->camA[1 - h->cur].p; cu.partC = h->partC.p;
+    cu.vx = h->vx.p;
+    cu.lam_slot = h->dev_lam.p;
+    // (riding workgroups: a multiple of NPART, so that the point workgroups behind them keep their XCD = index mod NPART)
+    cu.n_cams = Nc; cu.fixed_cam = h->fixed; cu.n_blocks = (((nbv(h) + CU_GROUPS - 1) / CU_GROUPS + NPART - 1) / NPART) * NPART;
+    const bool ride = (riders & 1) && all_lds_of(h) && h->Np > 0;
+    // The probe that finds PCG finished goes on as the back substitution (pt_schur_body, cu.fuse): riders in front of
+    // every PCG point pass, so only while everything is still resident at once; fp64 blocks only (the back substitution
+    // is never computed with the PCG passes' fp32 blocks)
+    const bool fuse = ride && (riders & 4) && !h->jac_f32 && h->nblkP + h->nblkL + cu.n_blocks <= h->n_cu;
+    cu.fuse = fuse ? 1 : 0;
+    bool backsub_done = false;
+    size_t probe_ev = (size_t)-1, probe_flushes = 0;
     auto launch_point_pass = [&](int kk) {
+      probe_ev = h->ev_slot.size(); probe_flushes = h->n_flushes;
       launch_pt_schur(h, robust, 0, kk, tol2, opts->pcg_min_iters, base,
-                      (kk == 0 && gtol_pending) ? h->d_scal_host + GMAX_HOST_SLOT : (double*)nullptr);
+                      (kk == 0 && gtol_pending) ? h->d_scal_host + GMAX_HOST_SLOT : (double*)nullptr, fuse ? &cu : nullptr);
     };
     auto launch_rest = [&](int kk) -> int {
       launch_cam_schur(h, robust, false, true, kk, tol2, opts->pcg_min_iters);
@@ -2046,7 +2101,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
 #define STEP_ARGS kk, p6_ptr(h), nparts_of(h), (const double*)uy_ptr(h), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc, h->fixed, tol2,       \
                   opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA[h->cur].p, h->partV.p, nbv(h), h->st.p, \
                   h->d_flags, base, (const double*)h->verdict.p
-#define STEP_TAIL h->vx.p, opts->pcg_model_tol, opts->pcg_model_min_iters
+#define STEP_TAIL h->vx.p, model_tol, opts->pcg_model_min_iters
       if (h->two_level) {
         BA_LAUNCH((k_pcg_step<Pinhole, true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, h->coarse_rc.p, STEP_TAIL);
         BA_LAUNCH(k_pcg_coarse, dim3(h->n_agg), dim3(VEC_BLOCK), 0, h->stream, kk, (const double*)h->coarseEinv.p,
@@ -2074,7 +2129,14 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
         if (gmax <= opts->gtol) { gtol_stop = true; break; }
       }
       const long long payload = h->h_flags[1];
-      if (payload > 0) { pcg_done_iters = (int)payload - 1; break; }
+      if (payload > 0) {
+        pcg_done_iters = (int)payload - 1;
+        if (fuse) {                   // the launch that published this verdict is doing the back substitution
+          backsub_done = true;
+          if (h->profile && probe_flushes == h->n_flushes && probe_ev < h->ev_slot.size()) h->ev_slot[probe_ev] = BA_K_BACKSUB;
+        }
+        break;
+      }
       if (int rc = launch_rest(k)) return rc;
       ++k;
       if (k >= opts->pcg_max_iters) break;
@@ -2082,27 +2144,23 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     }
     delete r_pcg; r_pcg = nullptr;
     if (gtol_stop) { status = 3; break; }      // converged by gradient: no step (the queued probe exits on its own)
+    // Cap-aware damping.  An inner solve that runs into pcg_max_iters says that at this damping the reduced system is
+    // beyond what the preconditioned iteration resolves within its budget (long camera chains at small damping: the drift
+    // modes; BASELINE config 5).  The step it leaves is still a descent step (truncated CG), but letting the damping fall
+    // further only buys more capped solves: from here on the damping stays at or above three times the value that
+    // hit the cap -- one Nielsen step back, where the solve still converged.  The floor travels with the step's verdict
+    // (lm_decide): the speculated point half reads the next damping on the device.
+    if (cap_floor && k >= opts->pcg_max_iters) { lam_floor = std::max(lam_floor, 3.0 * lambda); h->stats[BA_STAT_CAP_FLOOR_RAISES]++; }
     // ---- step, trial point, gain-ratio scalars
     Range r_step("step");
-    {
-      // K7a + K6.  The camera update does not feed the back substitution except through the step's vt, which the point
-      // workgroups compute themselves for the rows of their LDS windows: it rides along the same launch as extra
-      // workgroups (ba_kernels.hpp, "riders") whenever every window is staged in LDS; else it is a launch of its own.
-      CamUpdateArgs cu;
-      cu.cams = h->cams[h->cur].p; cu.intr = h->intr[h->cur].p; cu.dc = h->x.p; cu.rpcg = h->r.p; cu.Hcc = h->HccBc.p; cu.bc = bc_ptr(h);
-      cu.cs = h->cs[h->cur].p; cu.cams_trial = h->cams[1 - h->cur].p; cu.intr_trial = h->intr[1 - h->cur].p; cu.cs_trial = h->cs[1 - h->cur].p;
-      cu.vtil = h->camA[h->cur].p; cu.camA_trial = h->camA[1 - h->cur].p; cu.partC = h->partC.p;
-      cu.vx = h->vx.p;
-      cu.lam_slot = h->dev_lam.p;
-      // (riding workgroups: a multiple of NPART, so that the point workgroups behind them keep their XCD = index mod NPART)
-      cu.n_cams = Nc; cu.fixed_cam = h->fixed; cu.n_blocks = (((nbv(h) + CU_GROUPS - 1) / CU_GROUPS + NPART - 1) / NPART) * NPART;
-      const bool ride = (riders & 1) && all_lds_of(h) && h->Np > 0;
+    if (!backsub_done) {              // (PCG ran into its iteration cap, or the fused form is off)
+      cu.fuse = 0;
       if (!ride) {
         Scope sc(h, BA_K_MISC);
         if (h->model) BA_LAUNCH(k_cam_update<BalCam>, dim3(nbv(h)), dim3(VEC_BLOCK), 0, h->stream, cu);
         else          BA_LAUNCH(k_cam_update<Pinhole>, dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, cu);
+        cu.n_blocks = 0;              // (the arguments still travel: the launch clears the riding verdict's damping word)
       }
-      if (!ride) cu.n_blocks = 0;            // (the arguments still travel: the launch clears the riding verdict's damping word)
       launch_pt_schur(h, robust, 1, 0, 0.0, 0, 0, nullptr, &cu);
     }
     // Speculation: unless this is the last iteration, the cost at the trial point comes out of the camera half of
@@ -2118,7 +2176,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     // the step's scalar fold + verdict: single rank with a speculated point half behind it -> workgroup 0 of that launch
     // (the point workgroups pick the next damping up through a device word); else a launch of its own
     const bool ride_scalars = (riders & 2) && speculated && !h->multi && h->Np > 0;
-    if (!ride_scalars) launch_scalars(h, true, k, tol2, opts->pcg_min_iters, seq, cost, lambda);
+    if (!ride_scalars) launch_scalars(h, true, k, tol2, opts->pcg_min_iters, seq, cost, lambda, lam_floor);
     if (h->multi) {
       // the six sums over ranks, then the verdict on the all-reduced block (same host-mapped mirror + word).  A speculated
       // camera half has to be all-reduced anyway: the six words travel in the header of that message, one collective
@@ -2128,10 +2186,10 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
         reduced6 = h->linmsg[1 - h->lb].p;
       } else if (int rc = allreduce(h, h->scal.p, 6)) return rc;
       Scope sc(h, BA_K_MISC);
-      BA_LAUNCH(k_decide, dim3(1), dim3(64), 0, h->stream, h->scal.p, reduced6, cost, lambda, h->d_scal_host, h->d_flags + 2, seq);
+      BA_LAUNCH(k_decide, dim3(1), dim3(64), 0, h->stream, h->scal.p, reduced6, cost, lambda, lam_floor, h->d_scal_host, h->d_flags + 2, seq);
     }
     if (speculated) {
-      ScalarsArgs sa = scalars_args(h, true, k, tol2, opts->pcg_min_iters, seq, cost, lambda);
+      ScalarsArgs sa = scalars_args(h, true, k, tol2, opts->pcg_min_iters, seq, cost, lambda, lam_floor);
       sa.on = 1; sa.lam_slot = h->dev_lam.p; sa.err_flag = h->d_flags + 6;
       launch_lin_pt(h, 1 - h->cur, 1 - h->pb, robust, fs, 0.0, h->scal.p + S_LAM_NEXT, ride_scalars ? &sa : nullptr);
     }
@@ -2142,6 +2200,8 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     }
     if (pcg_done_iters < 0) pcg_done_iters = (h->h_scal[S_PCG_FIN] != 0.0) ? (int)h->h_scal[S_PCG_ITERS] : k;
     sum->pcg_iterations += pcg_done_iters;
+    pcg_last = pcg_done_iters;
+    if (pcg_at_build < 0) pcg_at_build = pcg_done_iters;      // the first inner solve with freshly built blocks
     double t2 = now_s();
     sum->seconds_pcg += t2 - t1;
     const double* S = h->h_scal;
@@ -2162,6 +2222,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     bool stop = false;
     if (rho > 0 && std::isfinite(cost_new)) {
       const double dcost = cost - cost_new;
+      last_decrease = cost_new > 0.0 ? dcost / cost_new : 1.0;
       h->cur = 1 - h->cur;
       if (speculated) { h->lb = 1 - h->lb; h->pb = 1 - h->pb; have_lin = true; }
       cost = cost_new;

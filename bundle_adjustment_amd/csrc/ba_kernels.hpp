@@ -864,6 +864,8 @@ struct CamUpdateArgs {
   const double* vx;              // (M x_r, x_t, ..) of the PCG iterate, NB per camera, kept current by k_pcg_setup / k_pcg_step
   double *cams_trial, *intr_trial, *cs_trial, *vtil, *camA_trial, *partC;
   int n_cams, fixed_cam, n_blocks;
+  int fuse;                      // a PCG point pass (MODE 0) that finds PCG finished goes on as the back substitution in the SAME launch
+                                 // (n_blocks camera-update workgroups ride in front, as in a MODE 1 launch): see pt_schur_body
 };
 struct ScalarsArgs {
   const double* partR; int nR;
@@ -875,7 +877,7 @@ struct ScalarsArgs {
   double tol2; int min_iters;
   double *scal, *scal_host;
   long long* host_flag; long long seq;
-  int decide; double cost_cur, lambda;
+  int decide; double cost_cur, lambda, lam_floor;
   double* lam_slot;              // rider mode: device word the point workgroups of the same launch wait on.  It holds 0 (cleared by
                                  // the back substitution of the same step, two kernels earlier) until the rider stores the next
                                  // damping (> 0) into it: ONE word carries "ready" and the value, one relaxed load reads both
@@ -1172,6 +1174,11 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
   }
   const bool use_lds = ALL_LDS || (size_t)win.y * CM::TA * sizeof(double) <= LDS_TAB_BYTES;   // ALL_LDS: every window fits
   bool table_ready = !use_lds;
+  // MODE 0 with cu.fuse: the launch that finds PCG finished (s_fin) does not leave -- it already holds the table (the copy
+  // started before the verdict was known), so it drops the ITERATE's vt (vx, kept current by the vector kernels) into the
+  // rows' vector slots and walks its observations as the back substitution (MODE 1's epilogue); the host, which reads the
+  // same verdict, does not launch one.  One launch and one table copy less per LM iteration.
+  bool back = MODE == 1;
   // The table copy starts BEFORE the PCG verdict is known: the copy does not depend on it (the previous kernel of the
   // stream wrote the table), and its round trips hide the probe's.  A launch that turns out to be past the end of PCG
   // pays for a copy it does not use -- one launch per LM iteration against a round trip saved in every working one.
@@ -1221,7 +1228,23 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
       }
     }
     if (!table_ready) {
-      if (MODE == 1 && cu.n_blocks > 0) {
+      if (MODE == 0 && cu.fuse) {
+        fill_cam_table_wait();                           // (its barrier also makes s_fin visible)
+        if (s_fin) {
+          back = true;
+          constexpr int NBm = CM::NB;
+          const int nw = win.y * NBm;
+          const double* __restrict__ src = cu.vx + NBm * (size_t)win.x;
+          for (int e0 = threadIdx.x; e0 < nw; e0 += 4 * PT_THREADS) {      // four loads in flight per thread
+            double v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int e = e0 + q * PT_THREADS; v[q] = e < nw ? src[e] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int e = e0 + q * PT_THREADS; if (e < nw) tab[CM::TA * (e / NBm) + CM::VOFF + e % NBm] = v[q]; }
+          }
+          __syncthreads();
+        }
+      } else if (MODE == 1 && cu.n_blocks > 0) {
         // the camera update rides along this launch (extra workgroups), so nobody has put the step's vt = (M dc_r, dc_t, ..)
         // into the table rows: the PCG vector kernels keep that form of their iterate in vx (NB doubles per camera, dense),
         // and the window's slice of it is dropped into the LDS rows here -- fetched while the table copy is in flight
@@ -1242,7 +1265,7 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
         fill_cam_table_wait();
       }
       table_ready = true;
-      if (MODE == 0 && s_fin) return;
+      if (MODE == 0 && s_fin && !back) return;
     }
     if (MODE == 0 && sb == sb0) BA_STAMP(0, 3);
     if (p >= 0) {
@@ -1279,7 +1302,7 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
     if (p >= 0 && sub == LANES - 1) {
       double yy[3];
       sym3_mul(hi, u, yy);
-      if (MODE == 0) {
+      if (!back) {
         double* o = ptab + PT * (size_t)p + 4;
         o[0] = yy[0]; o[1] = yy[1]; o[2] = yy[2];
         acc[0] += u[0] * yy[0] + u[1] * yy[1] + u[2] * yy[2];
@@ -1300,16 +1323,19 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
   }
   if (!table_ready) {                      // a workgroup without a single slot: the copy must still land before it leaves
     fill_cam_table_wait();
-    if (MODE == 0 && s_fin) return;
+    if (MODE == 0 && s_fin) { if (!cu.fuse) return; back = true; }       // (fused: its four zero sums are still owed)
   }
   if (MODE == 0) BA_STAMP(0, 5);
-  constexpr int NACC = MODE == 0 ? 1 : 4;          // the PCG pass carries one sum (u . y), the back substitution four
+  // the PCG pass carries one sum (u . y), the back substitution four
+  if (back) {
 #pragma unroll
-  for (int q = 0; q < NACC; ++q) acc[q] = wave_total_dpp(acc[q]);
-  block_combine<NACC, PT_THREADS, 4>(acc, sm);
-  if (threadIdx.x == 0) {
-    if (MODE == 0) partA[wk.blk_base + rb] = acc[0];
-    else { for (int q = 0; q < 4; ++q) partB[4 * (wk.blk_base + rb) + q] = acc[q]; }
+    for (int q = 0; q < 4; ++q) acc[q] = wave_total_dpp(acc[q]);
+    block_combine<4, PT_THREADS, 4>(acc, sm);
+    if (threadIdx.x == 0) { for (int q = 0; q < 4; ++q) partB[4 * (wk.blk_base + rb) + q] = acc[q]; }
+  } else {
+    acc[0] = wave_total_dpp(acc[0]);
+    block_combine<1, PT_THREADS, 4>(acc, sm);
+    if (threadIdx.x == 0) partA[wk.blk_base + rb] = acc[0];
   }
   if (MODE == 0) { BA_STAMP(0, 6); BA_STAMP(0, 7); }
 }
@@ -1325,16 +1351,39 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
                     int nGc, double* __restrict__ gmax_out, CamUpdateArgs cu
 #define BA_SCH_TAIL_ARGS fx, fy, fixed_cam, partA, kit, st, partV, nblkV, tol2, min_iters, y0, Hpp, bp, ptab_trial, partB,       \
                          host_flag, flag_base, verdict, partG, nG, partGc, nGc, gmax_out, cu
+#define BA_SCH_RIDER_ARGS kit, st, partV, nblkV, tol2, min_iters, host_flag, flag_base, verdict, partG, nG, partGc, nGc, gmax_out, cu
+// The workgroups in front of the point workgroups of a back-substitution launch (MODE 1), or of a PCG point pass that may
+// turn into one (MODE 0, cu.fuse): the camera update (riders).  True: this workgroup was a rider and is done.
+//   MODE 1: workgroup 0 also clears the riding verdict's damping word (ScalarsArgs::lam_slot).
+//   MODE 0: wave 0 runs the PCG probe like every point workgroup (workgroup 0, now a rider, is the one that publishes the
+//           verdict); the camera update runs only in the launch that finds PCG finished -- together with the cleared word.
+template <class CM, int MODE>
+__device__ __forceinline__ bool
+pt_schur_rider(int n_rider, int kit, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2,
+               int min_iters, long long* __restrict__ host_flag, long long flag_base, double* __restrict__ verdict,
+               const double* __restrict__ partG, int nG, const double* __restrict__ partGc, int nGc, double* __restrict__ gmax_out,
+               const CamUpdateArgs& cu) {
+  if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0 && cu.lam_slot) cu.lam_slot[0] = 0.0;
+  if ((int)blockIdx.x >= n_rider) return false;
+  extern __shared__ __align__(16) double tab[];
+  if (MODE == 0) {
+    __shared__ int r_fin;
+    if (threadIdx.x < 64) {
+      const bool fin = pcg_probe(kit, st, partV, nblkV, tol2, min_iters, host_flag, flag_base, verdict, partG, nG, partGc, nGc, gmax_out);
+      if (threadIdx.x == 0) r_fin = fin ? 1 : 0;
+    }
+    __syncthreads();
+    if (!r_fin) return true;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && cu.lam_slot) cu.lam_slot[0] = 0.0;
+  }
+  cam_update_rider<CM>(cu, blockIdx.x, tab);
+  return true;
+}
 template <class CM, bool ROBUST, int MODE, bool ALL_LDS, int LANES, typename JT>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_schur(BA_SCH_PARAMS, PtWork wk, BA_SCH_TAIL) {
-  const int n_rider = (MODE == 1) ? cu.n_blocks : 0;           // the camera update's workgroups: the FIRST ones of the launch
-  if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0 && cu.lam_slot) cu.lam_slot[0] = 0.0;     // (see ScalarsArgs::lam_slot)
-  if (MODE == 1 && (int)blockIdx.x < n_rider) {
-    extern __shared__ __align__(16) double tab[];
-    cam_update_rider<CM>(cu, blockIdx.x, tab);
-    return;
-  }
+  const int n_rider = (MODE == 1 || cu.fuse) ? cu.n_blocks : 0;           // the camera update's workgroups: the FIRST ones of the launch
+  if (pt_schur_rider<CM, MODE>(n_rider, BA_SCH_RIDER_ARGS)) return;
   pt_schur_body<CM, ROBUST, MODE, ALL_LDS, LANES, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk, (int)blockIdx.x - n_rider,
                                                   (int)gridDim.x - n_rider, BA_SCH_TAIL_ARGS);
 }
@@ -1342,13 +1391,8 @@ k_pt_schur(BA_SCH_PARAMS, PtWork wk, BA_SCH_TAIL) {
 template <class CM, bool ROBUST, int MODE, bool ALL_LDS, typename JT>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_schur_both(BA_SCH_PARAMS, PtWork wk, int nblk_short, PtWork wl, BA_SCH_TAIL) {
-  const int n_rider = (MODE == 1) ? cu.n_blocks : 0;
-  if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0 && cu.lam_slot) cu.lam_slot[0] = 0.0;     // (see ScalarsArgs::lam_slot)
-  if (MODE == 1 && (int)blockIdx.x < n_rider) {
-    extern __shared__ __align__(16) double tab[];
-    cam_update_rider<CM>(cu, blockIdx.x, tab);
-    return;
-  }
+  const int n_rider = (MODE == 1 || cu.fuse) ? cu.n_blocks : 0;
+  if (pt_schur_rider<CM, MODE>(n_rider, BA_SCH_RIDER_ARGS)) return;
   const int bid = (int)blockIdx.x - n_rider;
   if (bid < nblk_short)
     pt_schur_body<CM, ROBUST, MODE, ALL_LDS, LPP, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk, bid, nblk_short,
@@ -1360,6 +1404,7 @@ k_pt_schur_both(BA_SCH_PARAMS, PtWork wk, int nblk_short, PtWork wl, BA_SCH_TAIL
 #undef BA_SCH_PARAMS
 #undef BA_SCH_TAIL
 #undef BA_SCH_TAIL_ARGS
+#undef BA_SCH_RIDER_ARGS
 
 // -------------------------------------------------------------------------------------
 // reduced-camera-system vector kernels (one thread per camera)
@@ -1407,6 +1452,8 @@ constexpr int slice_chunks(int doubles) { return (doubles + 127) / 128; }      /
 // or Jacobi preconditioner Minv = (Hccd - E)^-1, right-hand side g = -(bc - W y0), and the
 // (FINALIZE: first folds the fresh linearisation partials into Hcc | bc, single rank)
 // first PCG vectors: x = 0, r = g, z = Minv r, p = s = 0, vtil, gamma/zeta partials.
+// use_schur_diag: 0 = Jacobi blocks, 1 = Schur-Jacobi blocks from partE, 2 = KEEP the blocks in Minv (built for an earlier
+// damped system, ba_options.precond_lag): partE is not read, nothing is inverted, Minv is not written.
 // The partial sums (linearisation, E, Wy0) come either as NPART partitions (nparts = NPART) or already folded and
 // all-reduced in partition 0 (nparts = 1; the other partitions are stale then).  CM: the camera model (block size NB = 6 or 9, table row layout).
 template <class CM, bool FINALIZE>
@@ -1435,6 +1482,11 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
   {
     double2 vc[slice_chunks(CS * VC)], vh[slice_chunks(NH * VC)], vb[slice_chunks(NB * VC)];
     slice_load(VecSlice{cs + CS * (size_t)c0, CS * nc}, vc);
+    if (use_schur_diag == 2) {                       // kept preconditioner blocks: straight into their LDS image
+      double2 vm[slice_chunks(NH * VC)];
+      slice_load(VecSlice{Minv + NH * (size_t)c0, NH * nc}, vm);
+      slice_store_lds(l_mi, NH * VC, vm);
+    }
     if (!FINALIZE) {
       slice_load(VecSlice{Hcc + NH * (size_t)c0, NH * nc}, vh);
       slice_load(VecSlice{bc + NB * (size_t)c0, NB * nc}, vb);
@@ -1457,7 +1509,7 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
 #pragma unroll
       for (int j = 0; j < NA; ++j) { const int i = j * 64 + lane; ta[j] = (FINALIZE && k < nparts && i < la) ? pa[i] : 0.0; }
 #pragma unroll
-      for (int j = 0; j < NE; ++j) { const int i = j * 64 + lane; te[j] = (use_schur_diag && k < nparts && i < le) ? pe[i] : 0.0; }
+      for (int j = 0; j < NE; ++j) { const int i = j * 64 + lane; te[j] = (use_schur_diag == 1 && k < nparts && i < le) ? pe[i] : 0.0; }
 #pragma unroll
       for (int j = 0; j < NW; ++j) { const int i = j * 64 + lane; tw[j] = (k < nparts && i < lw) ? pw[i] : 0.0; }
 #pragma unroll
@@ -1499,14 +1551,18 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
       for (int i = 0; i < NB; ++i) h[UT(NB, i, i)] += lambda * fmax(h[UT(NB, i, i)], DIAG_FLOOR);
     }
     for (int q = 0; q < NH; ++q) { l_hd[NH * t + q] = h[q]; m[q] = h[q]; }
-    if (use_schur_diag && !fixed) {
-      double A[NB][NB];
-      for (int i = 0; i < NB; ++i) for (int j = 0; j < NB; ++j) A[i][j] = l_e[NH * t + ST(NB, i, j)];
-      m_congruence<NB>(M, A);
-      for (int i = 0; i < NB; ++i) for (int j = i; j < NB; ++j) m[UT(NB, i, j)] -= A[i][j];
+    if (use_schur_diag == 2) {
+      for (int q = 0; q < NH; ++q) inv[q] = l_mi[NH * t + q];
+    } else {
+      if (use_schur_diag && !fixed) {
+        double A[NB][NB];
+        for (int i = 0; i < NB; ++i) for (int j = 0; j < NB; ++j) A[i][j] = l_e[NH * t + ST(NB, i, j)];
+        m_congruence<NB>(M, A);
+        for (int i = 0; i < NB; ++i) for (int j = i; j < NB; ++j) m[UT(NB, i, j)] -= A[i][j];
+      }
+      spdN_inverse<NB>(m, inv);
+      for (int q = 0; q < NH; ++q) l_mi[NH * t + q] = inv[q];
     }
-    spdN_inverse<NB>(m, inv);
-    for (int q = 0; q < NH; ++q) l_mi[NH * t + q] = inv[q];
     double wy[NB], g[NB], zz[NB], hz[NB];
     {
       const double* a = l_w6 + NB * t;
@@ -1543,7 +1599,7 @@ k_pcg_setup(const double* __restrict__ partL, double* __restrict__ Hcc, double* 
     slice_write_back(bc + NB * (size_t)c0, l_bc, NB * nc);
   }
   slice_write_back(Hccd + NH * (size_t)c0, l_hd, NH * nc);
-  slice_write_back(Minv + NH * (size_t)c0, l_mi, NH * nc);
+  if (use_schur_diag != 2) slice_write_back(Minv + NH * (size_t)c0, l_mi, NH * nc);
   slice_write_back(gvec + NB * (size_t)c0, l_g, NB * nc);
   slice_write_back(r + NB * (size_t)c0, l_g, NB * nc);
   slice_write_back(z + NB * (size_t)c0, l_z, NB * nc);
@@ -1845,25 +1901,27 @@ __device__ __forceinline__ void cam_update_rider(const CamUpdateArgs& a, int rb,
 // 0.5 (lambda d^T D d - g^T d + dc.r_pcg), and the damping an ACCEPTED step continues with (Nielsen's update).
 // The host takes both from here; a speculated point-half linearisation at the trial point reads res[S_LAM_NEXT]
 // from device memory before the host has decided anything.
-__device__ inline void lm_decide(double* __restrict__ res, double cost_cur, double lambda) {
+// lam_floor: the damping is not allowed below it (cap-aware damping, ba_solve: three times the damping at which an inner
+// solve last ran into pcg_max_iters; 0 = no floor)
+__device__ inline void lm_decide(double* __restrict__ res, double cost_cur, double lambda, double lam_floor) {
   const double cost_new = 0.5 * res[S_RHO];
   const double gTd = res[S_PT_GD] + res[S_CAM_GD], dDd = res[S_PT_DDD] + res[S_CAM_DDD], dcr = res[S_DC_R];
   const double model = 0.5 * (lambda * dDd - gTd + dcr);
   const double rho = (model > 0.0 && isfinite(cost_new)) ? (cost_cur - cost_new) / model : -1.0;
   const double t = 2.0 * rho - 1.0;
   res[S_GAIN] = rho;
-  res[S_LAM_NEXT] = fmax(lambda * fmax(1.0 / 3.0, 1.0 - t * t * t), 1e-12);
+  res[S_LAM_NEXT] = fmax(fmax(lambda * fmax(1.0 / 3.0, 1.0 - t * t * t), 1e-12), lam_floor);
 }
 // multi-rank form: the scalars are all-reduced between k_scalars and the decision; like k_scalars on a single rank,
 // the kernel mirrors the block into host-mapped memory and publishes the step's sequence word (one wave)
 __global__ void __launch_bounds__(64)
-k_decide(double* __restrict__ scal, const double* __restrict__ reduced6, double cost_cur, double lambda,
+k_decide(double* __restrict__ scal, const double* __restrict__ reduced6, double cost_cur, double lambda, double lam_floor,
          double* __restrict__ scal_host, long long* __restrict__ host_flag, long long seq) {
   __shared__ double res[S_COUNT];
   // (reduced6: the six all-reduced sums arrived in the header of another message, k_fold_lin)
   if (threadIdx.x < S_COUNT) res[threadIdx.x] = (reduced6 && threadIdx.x < 6) ? reduced6[threadIdx.x] : scal[threadIdx.x];
   __syncthreads();
-  if (threadIdx.x == 0) lm_decide(res, cost_cur, lambda);
+  if (threadIdx.x == 0) lm_decide(res, cost_cur, lambda, lam_floor);
   __syncthreads();
   if (threadIdx.x < S_COUNT) {
     scal[threadIdx.x] = res[threadIdx.x];
@@ -1924,7 +1982,7 @@ __device__ void scalars_body(const ScalarsArgs& a) {
   }
   __syncthreads();
   if (a.decide) {
-    if (threadIdx.x == 0) lm_decide(res, a.cost_cur, a.lambda);
+    if (threadIdx.x == 0) lm_decide(res, a.cost_cur, a.lambda, a.lam_floor);
     __syncthreads();
   }
   if (threadIdx.x < S_COUNT) {

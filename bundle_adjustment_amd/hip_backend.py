@@ -33,7 +33,7 @@ class BAOptions(C.Structure):
                 ("pcg_max_iters", C.c_int32), ("pcg_min_iters", C.c_int32), ("preconditioner", C.c_int32),
                 ("jacobian_precision", C.c_int32), ("reserved0", C.c_int32), ("profile", C.c_int32),
                 ("verbose", C.c_int32), ("small_solver", C.c_int32), ("pcg_model_tol", C.c_double),
-                ("pcg_model_min_iters", C.c_int32), ("reserved1", C.c_int32)]
+                ("pcg_model_min_iters", C.c_int32), ("precond_lag", C.c_int32)]
 
 
 class BASummary(C.Structure):
@@ -97,7 +97,8 @@ SYMBOLS = {
     "ba_debug_occupy": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double]),
 }
 # enum ba_stat (include/ba_hip.h)
-STATS = {"window_mw_launches": 0, "window_lm_launches": 1, "window_fallbacks": 2, "precond_builds": 3, "precond_reuses": 4}
+STATS = {"window_mw_launches": 0, "window_lm_launches": 1, "window_fallbacks": 2, "precond_builds": 3, "precond_reuses": 4, "banded": 5,
+         "cap_floor_raises": 6}
 
 
 def load_library():

@@ -74,14 +74,26 @@ typedef struct ba_options {
                               factorised exactly); 1 = always the multi-kernel LM / Schur / PCG path */
   double pcg_model_tol;    /* second PCG stopping test, on the quadratic model q(x) = 1/2 x^T S x - g^T x the iteration
                               minimises: stop after iteration i >= pcg_model_min_iters when i (q_{i-1} - q_i) <= pcg_model_tol |q_i|
-                              (Nash & Sofer's truncated-Newton test; 0.5 is their value; 0 = off, the default).  On
-                              ill-conditioned reduced systems (long camera chains at small damping) the residual test
-                              of pcg_tol keeps iterating long after the step has stopped improving the model: measured
-                              on config 5 at the reference's tolerances 715 -> 554 PCG iterations; on the
+                              (Nash & Sofer's truncated-Newton test; 0.5 is their value; 0 = off).  On ill-conditioned
+                              reduced systems (long camera chains at small damping) the residual test of pcg_tol keeps
+                              iterating long after the step has stopped improving the model: BASELINE config 5 on the
+                              BAL camera at the reference's tolerances 1148 -> 557 PCG iterations, 39 -> 20 ms; on the
                               well-conditioned C3 it truncates useful iterations (a run to convergence needs 54 LM
-                              iterations instead of 22), hence opt-in */
+                              iterations instead of 22).  Hence the default -1 = AUTOMATIC: 0.5 when ba_set_problem found
+                              the problem band-structured (mean camera span of a track <= Nc / 8: sequential captures;
+                              BA_STAT_BANDED) on a single rank, off otherwise (every rank of a multi-rank job must run
+                              the same test, and a rank only sees its shard: pass an explicit value there). */
   int32_t pcg_model_min_iters; /* default 5 */
-  int32_t reserved1;       /* must be 0 */
+  int32_t precond_lag;     /* Schur-Jacobi only: how many consecutive damped systems may KEEP the preconditioner blocks
+                              (M^-1 = blockdiag(S)^-1) built for an earlier one instead of rebuilding them (a preconditioner
+                              need not be current: PCG solves the same system, only its iteration count can change).  A
+                              kept system gets its right-hand side from the 6-sum camera pass instead of the 27-sum
+                              one and skips the per-camera inversions.  The blocks are rebuilt anyway when the damping
+                              has moved by more than 10x since they were built, when the last inner solve needed more
+                              than 1.5x + 2 the iterations of the first solve after the build, or when the last accepted
+                              step lowered the cost by more than 1 % (early, large steps: there a stale preconditioner
+                              costs more PCG iterations than the pass it saves; measured at C3).  0 = rebuild for every
+                              damped system.  Default 3 (ba_default_options).  Counted in BA_STAT_PRECOND_BUILDS / _REUSES. */
 } ba_options;
 
 typedef struct ba_summary {
@@ -141,6 +153,8 @@ enum ba_stat {
   BA_STAT_WINDOW_FALLBACKS = 2,     /* k_small_mw gave up at a barrier and the window was re-solved by k_small_lm */
   BA_STAT_PRECOND_BUILDS = 3,       /* damped systems whose Schur-Jacobi blocks were rebuilt */
   BA_STAT_PRECOND_REUSES = 4,       /* damped systems that kept the previous blocks (ba_options.precond_lag) */
+  BA_STAT_BANDED = 5,               /* 1: ba_set_problem found the current problem band-structured (pcg_model_tol's automatic default) */
+  BA_STAT_CAP_FLOOR_RAISES = 6,     /* LM iterations whose inner solve ran into pcg_max_iters and raised the damping floor */
   BA_STAT_COUNT = 8
 };
 

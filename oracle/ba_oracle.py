@@ -508,12 +508,31 @@ def pcg(op, rhs, Minv, tol, max_iters, min_iters=0, model_tol=0.0, model_min_ite
     return x, it, r
 
 
+def band_structured(cam_idx, pt_idx, n_cams):
+    """ba_set_problem's band statistic: the mean camera span (largest minus smallest camera index) of a track is at most
+    n_cams / 8 -- sequential captures, where a landmark is seen from a few neighbouring cameras."""
+    cam_idx, pt_idx = np.asarray(cam_idx), np.asarray(pt_idx)
+    if cam_idx.size == 0:
+        return False
+    npts = int(pt_idx.max()) + 1
+    lo = np.full(npts, n_cams, dtype=np.int64)
+    hi = np.full(npts, -1, dtype=np.int64)
+    np.minimum.at(lo, pt_idx, cam_idx)
+    np.maximum.at(hi, pt_idx, cam_idx)
+    seen = hi >= 0
+    return bool(seen.any() and float((hi[seen] - lo[seen]).sum()) / int(seen.sum()) <= n_cams / 8.0)
+
+
 def lm_solve(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam=-1, loss='linear',
              max_iters=50, ftol=1e-10, xtol=1e-10, gtol=1e-10, lam0=1e-4,
              pcg_tol=1e-1, pcg_max_iters=200, precond='schur_jacobi', verbose=False, linear_solver='pcg', model='pinhole',
-             pcg_model_tol=0.0, pcg_model_min_iters=5):
+             pcg_model_tol=-1.0, pcg_model_min_iters=5, precond_lag=3, cap_floor=True):
     """CPU mirror of the device LM / Schur / PCG loop (same formulas, same update
     rules, same stopping tests) -- see ba_solve in bundle_adjustment_amd/csrc/ba_hip.hip.
+    precond_lag (Schur-Jacobi only; the device's ba_options.precond_lag, same default and same rule): up to that many
+    consecutive damped systems keep the preconditioner blocks built for an earlier one, unless the damping has moved by more
+    than 10x since the build, the last inner solve needed more than 1.5x + 2 the iterations of the first one after it, or the
+    last accepted step lowered the cost by more than 1 % (a re-damped system after a rejected step may always keep them).
     linear_solver='dense' solves the explicit reduced system (schur_dense) exactly instead, as the
     single-launch solver for window-sized problems does (csrc/ba_small.hpp).
     model='bal': the 9-parameter BAL camera [rvec | t | f k1 k2] (bal_residuals, bal_normal_equations; K4 is ignored) --
@@ -521,6 +540,8 @@ def lm_solve(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam=-1, loss='linear',
     Returns dict(cams, pts, iterations, accepted, sse0, sse, cost0, cost, pcg_iters,
     history)."""
     nb = 9 if model == 'bal' else 6
+    if pcg_model_tol < 0:           # the device's automatic default (ba_options.pcg_model_tol = -1): on for band-structured problems
+        pcg_model_tol = 0.5 if band_structured(cam_idx, pt_idx, np.asarray(cams).reshape(-1, nb).shape[0]) else 0.0
     cams = np.array(cams, dtype=np.float64).reshape(-1, nb)
     pts = np.array(pts, dtype=np.float64).reshape(-1, 3)
     lam, nu = lam0, 2.0
@@ -539,6 +560,10 @@ def lm_solve(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam=-1, loss='linear',
     hist = []
     it = acc = pcg_total = 0
     status = 'max_iters'
+    lag = precond_lag if (precond == 'schur_jacobi' and linear_solver != 'dense') else 0
+    Minv_kept, lam_built, kept, pcg_at_build, pcg_last = None, 0.0, 0, -1, -1
+    last_decrease, fresh = 1.0, True
+    lam_floor = 0.0                     # cap-aware damping (ba_solve): 3 x the damping at which an inner solve last hit pcg_max_iters
     while it < max_iters:
         ne = normal_equations(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam, loss)
         gmax = max(np.abs(ne['bc']).max(), np.abs(ne['bp']).max())
@@ -547,10 +572,18 @@ def lm_solve(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam=-1, loss='linear',
             break
         op = SchurOperator(ne, cam_idx, pt_idx, lam, fixed_cam)
         rhs = op.rhs()
-        D = op.Hccd.copy() if precond == 'jacobi' else op.schur_diag_blocks()
-        if fixed_cam >= 0:
-            D[fixed_cam] = np.eye(nb)
-        Minv = np.linalg.inv(D)
+        keep = (lag > 0 and Minv_kept is not None and kept < lag and lam <= 10.0 * lam_built and lam >= 0.1 * lam_built
+                and (pcg_at_build < 0 or pcg_last <= pcg_at_build + pcg_at_build // 2 + 2)
+                and (not fresh or last_decrease <= 1e-2))
+        if keep:
+            Minv = Minv_kept
+            kept += 1
+        else:
+            D = op.Hccd.copy() if precond == 'jacobi' else op.schur_diag_blocks()
+            if fixed_cam >= 0:
+                D[fixed_cam] = np.eye(nb)
+            Minv = np.linalg.inv(D)
+            Minv_kept, lam_built, kept, pcg_at_build = (Minv if precond == 'schur_jacobi' else None), lam, 0, -1
         if precond == 'two_level':
             Minv = two_level_apply(Minv, np.linalg.inv(coarse_matrix(op, fixed_cam)), fixed_cam)
         if linear_solver == 'dense':
@@ -559,6 +592,11 @@ def lm_solve(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam=-1, loss='linear',
         else:
             dc, k, rfin = pcg(op, rhs, Minv, pcg_tol, pcg_max_iters, model_tol=pcg_model_tol, model_min_iters=pcg_model_min_iters)
         pcg_total += k
+        if cap_floor and linear_solver != 'dense' and k >= pcg_max_iters:
+            lam_floor = max(lam_floor, 3.0 * lam)
+        pcg_last = k
+        if pcg_at_build < 0:
+            pcg_at_build = k
         dp = op.back_substitute(dc)
         # model decrease of the damped, inexactly solved system (LM section)
         dcd = np.maximum(ne['Hcc'][:, np.arange(nb), np.arange(nb)], 1e-12)
@@ -580,10 +618,12 @@ def lm_solve(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam=-1, loss='linear',
             print(hist[-1])
         if rho > 0 and np.isfinite(cost_new):
             dcost = cost - cost_new
+            last_decrease = dcost / cost_new if cost_new > 0 else 1.0
+            fresh = True
             cams, pts, cost = cams_new, pts_new, cost_new
             acc += 1
             lam = lam * max(1.0 / 3.0, 1.0 - (2.0 * rho - 1.0) ** 3)
-            lam = max(lam, 1e-12)
+            lam = max(lam, 1e-12, lam_floor)
             nu = 2.0
             if dcost <= ftol * cost:
                 status = 'ftol'
@@ -591,6 +631,7 @@ def lm_solve(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam=-1, loss='linear',
         else:
             lam = min(lam * nu, 1e12)
             nu *= 2.0
+            fresh = False                  # the same linearisation, damped again
         if step <= xtol * (xtol + xnorm):
             status = 'xtol'
             break

@@ -272,13 +272,19 @@ def test_config5_bal_solve_reaches_the_noise_floor_at_full_size():
     oracle's BAL residual of the returned parameters; the held camera did not move; a second solve gives the same bits."""
     from bundle_adjustment_amd import hip_backend
     p = _config5()
-    kw = dict(fixed_cam=0, loss="huber", max_iters=40, ftol=1e-6, xtol=1e-10, gtol=1e-10, pcg_tol=0.1, pcg_max_iters=300)
+    kw = dict(fixed_cam=0, loss="huber", max_iters=30, ftol=1e-7, xtol=1e-10, gtol=1e-10, pcg_tol=0.1, pcg_max_iters=300)
     with hip_backend.Solver(0) as s:
         out, cams, pts = s.solve_bal(p, **kw)
         tr = s.trace()
+        st = s.stats()
         again, cams2, pts2 = s.solve_bal(p, **kw)
     assert np.sqrt(out["initial_sse"] / p.n_obs) > 5.0 and np.sqrt(out["final_sse"] / p.n_obs) < 0.60
-    assert out["accepted"] >= 5 and out["iterations"] <= 40, out
+    # The solve has to STOP ON A CONVERGENCE TEST within its budget.  (Round 3 could not: the late inner solves of this chain
+    # ran into the PCG cap at ever smaller dampings and the run ended on max_iters; what stops it now is the library's default
+    # behaviour on such problems -- the PCG model test, switched on where ba_set_problem finds band structure, and the
+    # cap-aware damping floor.)
+    assert out["status_name"] in ("ftol", "xtol", "gtol") and out["accepted"] >= 5, (out, [t["pcg_iterations"] for t in tr])
+    assert st["banded"] == 1
     assert len(tr) == out["iterations"] and all(t["pcg_iterations"] >= 1 for t in tr)
     r = o.bal_residuals(cams, pts, p.cam_idx, p.pt_idx, p.uv)
     assert abs(float((r * r).sum()) - out["final_sse"]) <= 1e-9 * out["final_sse"]
@@ -299,8 +305,17 @@ def test_config5_bal_fp32_jacobian_mode_follows_the_fp64_descent():
     kw = dict(fixed_cam=0, loss="huber", max_iters=10, ftol=1e-9, xtol=1e-12, gtol=0.0, pcg_tol=0.1, pcg_max_iters=400)
     with hip_backend.Solver(0) as s:
         ref, _, _ = s.solve_bal(p, **kw)
+        tr_ref = s.trace()
         out, cams, pts = s.solve_bal(p, jacobian_precision=1, **kw)
-    assert out["accepted"] == out["iterations"] and ref["accepted"] == ref["iterations"]
+        tr_out = s.trace()
+    # same verdicts while the steps still matter (past the noise floor accept / reject is decided by round-off)
+    compared = 0
+    for a, b in zip(tr_out, tr_ref):
+        if abs(b["cost"] - b["cost_trial"]) <= 1e-6 * b["cost"]:
+            break
+        assert a["accepted"] == b["accepted"], (a, b)
+        compared += 1
+    assert compared >= 5
     assert out["final_cost"] < 0.05 * out["initial_cost"]
     assert abs(out["final_cost"] - ref["final_cost"]) <= 2e-3 * ref["final_cost"], (out["final_cost"], ref["final_cost"])
     assert np.sqrt(out["final_sse"] / p.n_obs) < 0.75

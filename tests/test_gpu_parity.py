@@ -191,6 +191,41 @@ def test_solve_matches_cpu_mirror(solver, loss, precond):
     np.testing.assert_allclose(solver.get_rotations(), o.rodrigues_batch(cams[:, :3]), atol=1e-14)
 
 
+@pytest.mark.parametrize("loss", ["linear", "huber"])
+def test_kept_preconditioner_blocks_follow_the_oracle_and_reach_the_same_minimiser(loss):
+    """ba_options.precond_lag: near convergence (steps that lower the cost by less than 1 %) up to `lag` consecutive damped
+    systems keep the Schur-Jacobi blocks built for an earlier one (right-hand side from the 6-sum camera pass, no
+    inversions).  The oracle's LM mirror applies the same rule: with a tight PCG tolerance the device follows it step by
+    step -- same PCG iteration counts (within one: the kept systems' right-hand side comes out of another kernel, i.e.
+    another summation order), same verdicts, same minimiser -- and the counters say how often blocks were built / kept.
+    precond_lag = 0 never keeps anything and lands on the same minimiser."""
+    p = make_problem(12, 800, 5, seed=4, outlier_frac=0.02 if loss == "huber" else 0.0)
+    kw = dict(max_iters=25, ftol=0.0, xtol=0.0, gtol=0.0, pcg_tol=1e-4, pcg_max_iters=400)
+    res = {}
+    with hip_backend.Solver(0) as s:
+        for lag in (3, 0):
+            s.set_problem(p)
+            st0 = s.stats()
+            out = s.solve(loss=loss, precond_lag=lag, **kw)
+            st1 = s.stats()
+            res[lag] = (out, s.trace(), s.get_params(), {k: st1[k] - st0[k] for k in st1})
+    out, tr, (cams, pts), st = res[3]
+    ref = o.lm_solve(p.cams, p.pts, p.cam_idx, p.pt_idx, p.uv, p.K4, 0, loss, precond_lag=3, **kw)
+    assert st["precond_reuses"] >= 5 and st["precond_builds"] + st["precond_reuses"] == out["iterations"] == 25
+    assert res[0][3]["precond_reuses"] == 0 and res[0][3]["precond_builds"] == 25
+    compared = 0
+    for t, h in zip(tr, ref["history"]):
+        if abs(h["cost"] - h["cost_new"]) <= 1e-11 * h["cost"]:
+            break                          # at the minimiser: accept / reject is decided by round-off from here on
+        assert abs(t["pcg_iterations"] - h["pcg"]) <= 1, (t, h)
+        assert abs(t["cost_trial"] - h["cost_new"]) <= 1e-9 * h["cost_new"], (t, h)
+        assert bool(t["accepted"]) == bool(h["rho"] > 0)
+        compared += 1
+    assert compared >= 6
+    assert abs(out["final_cost"] - ref["cost"]) <= 1e-9 * ref["cost"]
+    assert abs(out["final_cost"] - res[0][0]["final_cost"]) <= 1e-9 * ref["cost"]
+
+
 def test_reference_default_settings_never_worse_than_reference(solver):
     """At the reference's literals (huber, xtol = ftol = 1e-5, 50 evaluations) the final SSE
     must not exceed what the reference's own run() reached (golden run_seed0)."""
