@@ -35,6 +35,7 @@
 #include "ba_coarse.hpp"
 #include "ba_small.hpp"
 #include "ba_small_mw.hpp"
+#include "ba_setup.hpp"
 
 using namespace ba;
 
@@ -202,6 +203,9 @@ struct ba_handle {
   DBuf<int> mw_woff; DBuf<double> mw_buf; bool mw_ok = false; int mw_G = 0;
   int mw_resident[3] = {-1, -1, -1};   // workgroups of k_small_mw<2 / 3 / 4> the device holds at once (occupancy query, once per handle)
   long long stats[BA_STAT_COUNT] = {0};   // ba_get_stat
+  DBuf<int> setup_i;                      // scratch of the device build of ba_set_problem (ba_setup.hpp)
+  char* h_setup = nullptr;                // pinned: what that build reads back (track-length histogram, statistics, windows)
+  int setup_path = 0;                     // how the current problem's layout was built: 0 host, 1 device
   // two-level preconditioner for band-structured problems (ba_coarse.hpp): structures built by ba_set_problem
   bool banded = false;         // mean camera span of a track <= Nc / 8 (sequential captures): pcg_model_tol's automatic default
   bool two_level_ok = false;   // this problem has them
@@ -389,6 +393,8 @@ extern "C" int ba_destroy(ba_handle* h) {
   if (h->h_flags) (void)hipHostFree(h->h_flags);
   if (h->h_small) (void)hipHostFree(h->h_small);
   if (h->h_up) (void)hipHostFree(h->h_up);
+  if (h->h_setup) (void)hipHostFree(h->h_setup);
+  h->setup_i.release();
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -592,6 +598,268 @@ static int allreduce(ba_handle* h, double* buf, size_t count, bool is_max = fals
 }
 
 // ---------------------------------------------------------------------------- problem
+// Point-pass grid, part 1 (needs the problem's dimensions only): lanes per point, number and length of the point ranges,
+// lanes per segment of the PCG camera pass.  Shared by the host and the device build of ba_set_problem.
+struct PtGrid { bool table_fits; int per_cu, pts_per_pass, want; };
+static PtGrid config_point_grid(ba_handle* h, int Nc, int Np, int No) {
+  const size_t full_table = (size_t)Nc * TA * sizeof(double);
+  const bool table_fits = full_table <= (size_t)LDS_TAB_BYTES;
+  const int per_cu = !table_fits ? 1 : (int)std::max<size_t>(1, std::min<size_t>(2048 / PT_THREADS, (size_t)(160 * 1024) / (full_table + 1024)));
+  h->lanes = LPP;
+  for (int ln = 16; ln > LPP; ln >>= 1)
+    if ((Np + PT_THREADS / ln - 1) / (PT_THREADS / ln) <= h->n_cu * per_cu) { h->lanes = ln; break; }
+  if (const char* e = getenv("BA_PT_LANES")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) h->lanes = v; }
+  const int pts_per_pass = PT_THREADS / h->lanes;
+  const int want = std::max(1, (Np + pts_per_pass - 1) / pts_per_pass);
+  h->nblkP = std::min(want, 4096);
+  if (table_fits) h->nblkP = std::min(h->nblkP, h->n_cu * per_cu);
+  if (const char* e = getenv("BA_PT_BLOCKS")) h->nblkP = std::max(1, std::min(want, atoi(e)));
+  if (const char* e = getenv("BA_XCD_RANGES")) h->xcd_ranges = atoi(e) != 0;
+  // lanes per (camera, partition) segment in the PCG camera pass: a wave, or a 16-lane row when segments are short
+  // (config 5: ~48 observations per segment -- a wave would walk it in one step with a quarter of its lanes idle and
+  // pay the 64-lane reduction of every sum for it; measured 13.4 -> 12.1 us, C3's ~125-observation segments keep the wave)
+  h->cam_segl = (Nc > 0 && (long long)No / Nc / NPART < 64) ? 16 : 64;
+  if (const char* e = getenv("BA_CAM_SEGL")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) h->cam_segl = v; }
+  h->ppb = std::max(1, (Np + h->nblkP - 1) / h->nblkP);
+  return PtGrid{table_fits, per_cu, pts_per_pass, want};
+}
+// part 2a: the track length above which a point gets a 16-lane row of its own (med = element Np / 2 of the sorted lengths)
+static void config_long_threshold(ba_handle* h, int med) {
+  const char* e = getenv("BA_LONG_TRACK");
+  h->long_thr = e ? std::max(1, atoi(e)) : std::max(8, 2 * med);
+  if (h->lanes != LPP) h->long_thr = 0x7fffffff;           // more lanes per point already: no separate long-track rows
+}
+// part 2b: how the long tracks are dealt to workgroups, and -- when ranges plus long-track workgroups would not all be
+// resident at once -- the grid with the fewest rounds per workgroup
+static void config_long_grid(ba_handle* h, const PtGrid& g, int Np, int n_long) {
+  h->n_long = n_long;
+  h->long_spb = PT_THREADS / LPP_LONG;
+  if (const char* e = getenv("BA_LONG_SLOTS")) h->long_spb = std::max(1, atoi(e)) * (PT_THREADS / LPP_LONG);
+  h->nblkL = (h->n_long + h->long_spb - 1) / h->long_spb;
+  // A point-pass workgroup is 1024 threads at 128 VGPRs: ONE per compute unit.  When one-round ranges plus one-round
+  // long-track workgroups need somewhat more workgroups than the chip has units (config 5: 306 + 175 on 256), the
+  // second wave of workgroups runs on part of the chip while the rest idles, and every workgroup pays its launch and its
+  // window copy for one round of work.  A round (512 points at 2 lanes, 64 long tracks at 16) is latency-bound and costs
+  // about the same whatever it holds, so the cost of a launch is the largest number of ROUNDS any workgroup walks:
+  // choose the long-track workgroups' size (m rounds) and the ranges' length such that everything is resident at once and
+  // that number is smallest (config 5: 168 ranges of 932 points + 88 x 128 long tracks, two rounds each; Schur point
+  // pass 17.0 -> 15.2 us pinhole, 20.0 -> 18.0 us BAL camera).  Much larger WINDOWED problems (more than two rounds per
+  // unit) keep one-round ranges: narrow windows matter more there.
+  if (!getenv("BA_PT_BLOCKS") && (!g.table_fits || h->n_long > 0)) {
+    int best_m = 0, best_cost = g.table_fits ? 0x7fffffff : 3, best_nb = 0;   // (table in LDS: ranges of any length share one fill)
+    const bool pick_m = !getenv("BA_LONG_SLOTS") && h->n_long > 0;
+    for (int m = 1; m <= (pick_m ? 4 : 1); ++m) {
+      const int spb = pick_m ? m * (PT_THREADS / LPP_LONG) : h->long_spb;
+      const int nl = (h->n_long + spb - 1) / spb;
+      const int avail = h->n_cu - nl;
+      if (avail < 1) continue;
+      const int nb = std::min(g.want, avail);
+      const int rounds = ((Np + nb - 1) / nb + g.pts_per_pass - 1) / g.pts_per_pass;
+      const int cost = std::max(rounds, h->n_long > 0 ? spb / (PT_THREADS / LPP_LONG) : 0);
+      if (cost < best_cost) { best_cost = cost; best_m = m; best_nb = nb; }
+    }
+    if (best_m && g.want + h->nblkL > h->n_cu) {
+      if (pick_m) { h->long_spb = best_m * (PT_THREADS / LPP_LONG); h->nblkL = (h->n_long + h->long_spb - 1) / h->long_spb; }
+      h->nblkP = best_nb;
+      h->ppb = (Np + best_nb - 1) / best_nb;
+    }
+  }
+}
+// Every device buffer of a problem whose size follows from the problem's dimensions and the point-pass grid alone (h->Nc,
+// Np, Nobs, nblkP, nblkL, multi, world are set).  Idempotent: a buffer that is large enough is kept.
+static int alloc_solver_buffers(ba_handle* h) {
+  const int Nc = h->Nc, Np = h->Np, No = h->Nobs;
+  const size_t nobs1 = std::max(No, 1), np1 = std::max(Np, 1);
+  const size_t nbv_max = (size_t)std::max(h->nblkVm[0], h->nblkVm[1]);
+  HIPCHECK(h->c_pt.alloc(nobs1)); HIPCHECK(h->c_orig.alloc(nobs1)); HIPCHECK(h->p_cam.alloc(nobs1));
+  HIPCHECK(h->c_uv.alloc(nobs1)); HIPCHECK(h->p_uv.alloc(nobs1));
+  HIPCHECK(h->c_w[0].alloc(nobs1)); HIPCHECK(h->c_w[1].alloc(nobs1)); HIPCHECK(h->p_w[0].alloc(nobs1)); HIPCHECK(h->p_w[1].alloc(nobs1));
+  HIPCHECK(h->c_ptf[0].alloc(nobs1)); HIPCHECK(h->c_ptf[1].alloc(nobs1)); HIPCHECK(h->p_camf[0].alloc(nobs1)); HIPCHECK(h->p_camf[1].alloc(nobs1));
+  for (int k = 0; k < 2; ++k) {
+    HIPCHECK(h->cams[k].alloc(6 * (size_t)Nc)); HIPCHECK(h->cs[k].alloc(CS * (size_t)Nc));
+    HIPCHECK(h->ptab[k].alloc(PT * np1));     // (k_pack_points writes whole records of set 0; set 1 gets X from the back
+  }                                           //  substitution and y from the point half before either is read)
+  HIPCHECK(h->stage.alloc(3 * np1));
+  // per-camera buffers are sized for the larger camera model (BAL: 9 parameters, 45 + 9 sums, 26-double table rows)
+  constexpr size_t NBX = BalCam::NB, NHX = BalCam::NH, NLX = BalCam::NL;
+  HIPCHECK(h->camA[0].alloc(TA_MAX * (size_t)Nc)); HIPCHECK(h->camA[1].alloc(TA_MAX * (size_t)Nc));
+  HIPCHECK(h->intr[0].alloc(3 * (size_t)Nc)); HIPCHECK(h->intr[1].alloc(3 * (size_t)Nc));
+  HIPCHECK(h->HccBc.alloc(NLX * (size_t)Nc + 8));   // Hcc (NH Nc) | bc (NB Nc): one all-reduce
+  for (int k = 0; k < 2; ++k) {
+    HIPCHECK(h->Hpp[k].alloc(6 * np1)); HIPCHECK(h->bp[k].alloc(3 * np1)); HIPCHECK(h->Hppinv[k].alloc(6 * np1));
+    HIPCHECK(h->y0[k].alloc(3 * np1));
+  }
+  h->pb = 0;
+  HIPCHECK(h->Hccd.alloc(NHX * (size_t)Nc)); HIPCHECK(h->Minv.alloc(NHX * (size_t)Nc));
+  HIPCHECK(h->partR.alloc(2 * (size_t)NPART * Nc));
+  HIPCHECK(h->partL[0].alloc(NLX * (size_t)NPART * Nc)); HIPCHECK(h->partL[1].alloc(NLX * (size_t)NPART * Nc));
+  HIPCHECK(h->part6.alloc(NBX * (size_t)NPART * Nc + 8));   // + the u.y word: one all-reduce carries both
+  HIPCHECK(h->partE.alloc(NHX * (size_t)NPART * Nc));
+  if (h->multi) { HIPCHECK(h->linmsg[0].alloc(8 + NLX * (size_t)Nc)); HIPCHECK(h->linmsg[1].alloc(8 + NLX * (size_t)Nc)); }
+  if (h->multi) HIPCHECK(h->sysmsg.alloc(2 + (size_t)(NBX + NHX) * Nc + (size_t)h->world + 8));
+  HIPCHECK(h->partA.alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partB.alloc(4 * (size_t)(h->nblkP + h->nblkL)));
+  HIPCHECK(h->partC.alloc(5 * nbv_max)); HIPCHECK(h->partV.alloc(4 * nbv_max));
+  HIPCHECK(h->partG[0].alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partG[1].alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partGc.alloc(nbv_max));
+  DBuf<double>* v6[] = {&h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin, &h->vx};
+  for (auto b : v6) HIPCHECK(b->alloc(NBX * (size_t)Nc));
+  HIPCHECK(h->scal.alloc(64));
+  HIPCHECK(h->st.alloc(2));
+  HIPCHECK(h->verdict.alloc(8));
+  HIPCHECK(hipMemsetAsync(h->verdict.p, 0, 8 * sizeof(double), h->stream));
+  HIPCHECK(h->dev_lam.alloc(2));
+  // (dev_lam is cleared by every back substitution; camA rows: geometry by k_cam_prepare / k_cam_update, vt by the
+  //  PCG setup before any pass reads it)
+  return BA_OK;
+}
+
+// ---- ba_set_problem, device build (ba_setup.hpp): one upload of the caller's arrays, every ordering derived by kernels.
+// Returns BA_OK, a negative ba_status, or 1 = "not for this problem" (the caller then runs the host build; nothing the
+// host build relies on has been touched).  Chosen for large problems whose whole camera table fits in LDS (the caller's
+// point numbering is kept then); bit-equal to the host build (tests/test_gpu_setup.py).
+constexpr int SETUP_HIST_BINS = 4096;
+constexpr size_t SETUP_PINNED_BYTES = 128 * 1024;
+static int dev_scan(ba_handle* h, const int* in, int n, int* bsum, int* out) {
+  const int nb = (n + SETUP_SCAN_BLOCK - 1) / SETUP_SCAN_BLOCK;
+  BA_LAUNCH(k_scan_block_sums, dim3(nb), dim3(1024), 0, h->stream, in, n, bsum);
+  BA_LAUNCH(k_scan_top, dim3(1), dim3(1024), 0, h->stream, bsum, nb);
+  BA_LAUNCH(k_scan_final, dim3(nb), dim3(1024), 0, h->stream, in, n, (const int*)bsum, out);
+  return BA_OK;
+}
+static int set_problem_device(ba_handle* h, int Nc, int Np, int No, const int32_t* cam_idx, const int32_t* pt_idx, const double* uv,
+                              const double K4[4], int fixed_cam, bool timed) {
+  auto t_prev = std::chrono::steady_clock::now();
+  auto stage = [&](const char* name) {
+    if (!timed) return;
+    (void)hipStreamSynchronize(h->stream);
+    const auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "ba_set_problem [device] %-24s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(t - t_prev).count());
+    t_prev = t;
+  };
+  if ((size_t)Np + 1 > (size_t)1024 * SETUP_SCAN_BLOCK) return 1;
+  h->Nc = Nc; h->Np = Np; h->Nobs = No; h->fixed = fixed_cam;
+  memcpy(h->K4, K4, sizeof h->K4);
+  h->nblkV = (Nc + VEC_CAMS - 1) / VEC_CAMS;
+  h->nblkVm[0] = (Nc + Pinhole::VC - 1) / Pinhole::VC; h->nblkVm[1] = (Nc + BalCam::VC - 1) / BalCam::VC;
+  const PtGrid grid = config_point_grid(h, Nc, Np, No);
+  if (!grid.table_fits) return 1;
+  if (!h->h_setup) HIPCHECK(hipHostMalloc((void**)&h->h_setup, SETUP_PINNED_BYTES, hipHostMallocDefault));
+  // observation-sized buffers the build works in; the flagged index copies serve as scratch until k_init_flagged fills them
+  HIPCHECK(h->p_camf[0].alloc(No)); HIPCHECK(h->p_camf[1].alloc(No)); HIPCHECK(h->c_ptf[0].alloc(No)); HIPCHECK(h->c_ptf[1].alloc(No));
+  HIPCHECK(h->p_cam.alloc(No)); HIPCHECK(h->c_pt.alloc(No)); HIPCHECK(h->c_orig.alloc(No));
+  HIPCHECK(h->c_uv.alloc(No)); HIPCHECK(h->p_uv.alloc(No)); HIPCHECK(h->rbuf.alloc(2 * (size_t)No));
+  HIPCHECK(h->pt_off.alloc(Np + 1)); HIPCHECK(h->offk.alloc((size_t)Nc * (NPART + 1))); HIPCHECK(h->slot.alloc(Np));
+  // scratch: p_src[No] | cnt[Np+1] fill[Np] big[Np] flag[Np+1] pos[Np+1] | cam_cnt[Nc+1] cam_fill[Nc] cam_off[Nc+1] | bsum[1032] |
+  //          hist[SETUP_HIST_BINS] | words[16] (0 bad, 1 n_tracks, 2 n_big) | u64[4] (0 span_sum, 1 in_partition, 2 in_band)
+  const size_t o_cnt = (size_t)No, o_fill = o_cnt + Np + 1, o_big = o_fill + Np, o_flag = o_big + Np, o_pos = o_flag + Np + 1;
+  const size_t o_ccnt = o_pos + Np + 1, o_cfill = o_ccnt + Nc + 1, o_coff = o_cfill + Nc, o_bsum = o_coff + Nc + 1;
+  const size_t o_hist = o_bsum + 1032, o_words = o_hist + SETUP_HIST_BINS, o_u64 = (o_words + 16 + 1) & ~(size_t)1, o_end = o_u64 + 8;
+  HIPCHECK(h->setup_i.alloc(o_end));
+  int* const S = h->setup_i.p;
+  int *d_cam = h->p_camf[0].p, *d_pt = h->p_camf[1].p, *seg = h->c_ptf[0].p, *p_pt = h->c_ptf[1].p, *p_src = S;
+  unsigned long long* u64 = (unsigned long long*)(S + o_u64);
+  HIPCHECK(hipMemcpyAsync(d_cam, cam_idx, (size_t)No * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(hipMemcpyAsync(d_pt, pt_idx, (size_t)No * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(hipMemcpyAsync(h->rbuf.p, uv, 2 * (size_t)No * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(hipMemsetAsync(S + o_cnt, 0, (o_end - o_cnt) * sizeof(int), h->stream));
+  HIPCHECK(hipMemsetAsync(S + o_words, 0x7f, sizeof(int), h->stream));                   // bad = 0x7f7f7f7f: "none"
+  stage("upload");
+  const dim3 go((No + 255) / 256), gp((Np + 255) / 256), b256(256);
+  BA_LAUNCH(k_setup_hist, go, b256, 0, h->stream, (const int*)d_cam, (const int*)d_pt, No, Nc, Np, S + o_cnt, S + o_words);
+  dev_scan(h, S + o_cnt, Np, S + o_bsum, h->pt_off.p);
+  BA_LAUNCH(k_setup_scatter_pt, go, b256, 0, h->stream, (const int*)d_pt, No, (const int*)h->pt_off.p, S + o_fill, seg);
+  BA_LAUNCH(k_setup_sort_pt, gp, b256, 0, h->stream, (const int*)h->pt_off.p, Np, (const int*)seg, (const int*)d_cam, p_src, h->p_cam.p, p_pt,
+            S + o_hist, SETUP_HIST_BINS, u64, S + o_words + 1, S + o_big, S + o_words + 2);
+  BA_LAUNCH(k_setup_sort_big, dim3(std::min(Np, 2048)), b256, 0, h->stream, (const int*)(S + o_big), (const int*)(S + o_words + 2),
+            (const int*)h->pt_off.p, (const int*)seg, (const int*)d_cam, p_src, h->p_cam.p, p_pt, u64, S + o_words + 1);
+  // read back: histogram of track lengths, words, span sum
+  int* hh = (int*)h->h_setup;
+  HIPCHECK(hipMemcpyAsync(hh, S + o_hist, (SETUP_HIST_BINS + 16) * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipMemcpyAsync(hh + SETUP_HIST_BINS + 16, u64, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  BA_SYNC(h);
+  stage("point order");
+  const int bad = hh[SETUP_HIST_BINS + 0], n_tracks = hh[SETUP_HIST_BINS + 1];
+  if (bad >= 0 && bad < No) {
+    if (cam_idx[bad] < 0 || cam_idx[bad] >= Nc) return fail(BA_ERR_INVALID, "cam_idx[%lld]=%d out of range", (long long)bad, cam_idx[bad]);
+    return fail(BA_ERR_INVALID, "pt_idx[%lld]=%d out of range", (long long)bad, pt_idx[bad]);
+  }
+  unsigned long long span_sum;
+  memcpy(&span_sum, hh + SETUP_HIST_BINS + 16, sizeof span_sum);
+  // median track length = element Np / 2 of the sorted lengths
+  int med = 0;
+  { long long cum = 0; for (int L = 0; L < SETUP_HIST_BINS; ++L) { cum += hh[L]; if (cum > Np / 2) { med = L; break; } } }
+  config_long_threshold(h, med);
+  if (h->long_thr != 0x7fffffff && h->long_thr >= SETUP_HIST_BINS - 1) return 1;       // (the capped histogram cannot count those)
+  int n_long = 0;
+  if (h->long_thr != 0x7fffffff) for (int L = h->long_thr + 1; L < SETUP_HIST_BINS; ++L) n_long += hh[L];
+  config_long_grid(h, grid, Np, n_long);
+  h->banded = n_tracks > 0 && (double)span_sum / n_tracks <= Nc / 8.0;
+  h->stats[BA_STAT_BANDED] = h->banded ? 1 : 0;
+  {   // problems the two-level preconditioner's structures would be built for: the host build (it also re-sorts every track by camera)
+    bool want = h->banded && !h->multi;
+    if (const char* e = getenv("BA_TWO_LEVEL")) want = atoi(e) != 0 && !h->multi;
+    if (want && Nc >= 2 * VEC_CAMS) return 1;
+  }
+  h->two_level_ok = false;
+  h->mw_ok = false;
+  h->one_part = false;
+  HIPCHECK(h->long_pts.alloc(std::max(h->n_long, 1)));
+  if (h->n_long > 0) {
+    BA_LAUNCH(k_setup_long_flags, gp, b256, 0, h->stream, (const int*)h->pt_off.p, Np, h->long_thr, S + o_flag);
+    dev_scan(h, S + o_flag, Np, S + o_bsum, S + o_pos);
+    BA_LAUNCH(k_setup_long_list, gp, b256, 0, h->stream, (const int*)h->pt_off.p, Np, h->long_thr, (const int*)(S + o_pos), h->long_pts.p);
+  }
+  if (h->lanes == LPP && !getenv("BA_NO_BANK_ORDER")) {
+    const long long nthreads = (long long)h->nblkP * ((h->ppb + 15) / 16) * 2;
+    BA_LAUNCH(k_setup_bank_order, dim3((unsigned)((nthreads + 255) / 256)), b256, 0, h->stream, (const int*)h->pt_off.p, Np, h->nblkP, h->ppb,
+              h->p_cam.p, p_src);
+  }
+  stage("long tracks + visiting order");
+  // camera order (keys: positions of the point-ordered list)
+  BA_LAUNCH(k_setup_hist_cam, go, b256, 0, h->stream, (const int*)h->p_cam.p, No, S + o_ccnt);
+  dev_scan(h, S + o_ccnt, Nc, S + o_bsum, S + o_coff);
+  BA_LAUNCH(k_setup_scatter_cam, go, b256, 0, h->stream, (const int*)h->p_cam.p, No, (const int*)(S + o_coff), S + o_cfill, seg);
+  BA_LAUNCH(k_setup_sort_cam, dim3(Nc), b256, 0, h->stream, (const int*)(S + o_coff), (const int*)seg, (const int*)p_pt, (const int*)p_src,
+            h->c_pt.p, h->c_orig.p);
+  BA_LAUNCH(k_setup_offk, dim3((Nc * (NPART + 1) + 255) / 256), b256, 0, h->stream, (const int*)(S + o_coff), Nc, h->offk.p);
+  BA_LAUNCH(k_setup_xcd_stat, dim3((Nc * NPART + 3) / 4), b256, 0, h->stream, (const int*)h->offk.p, (const int*)h->c_pt.p, Nc, Np, u64 + 1);
+  const int nwin = h->nblkP + h->nblkL;
+  if ((size_t)nwin * sizeof(int2) + 64 > SETUP_PINNED_BYTES) return 1;
+  HIPCHECK(h->blk_win.alloc(nwin));
+  BA_LAUNCH(k_setup_windows, dim3(nwin), b256, 0, h->stream, (const int*)h->pt_off.p, (const int*)h->p_cam.p, Np, Nc, h->nblkP, h->ppb,
+            (const int*)h->long_pts.p, h->n_long, h->long_spb, h->blk_win.p);
+  HIPCHECK(hipMemcpyAsync(h->h_setup, u64 + 1, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipMemcpyAsync(h->h_setup + 64, h->blk_win.p, (size_t)nwin * sizeof(int2), hipMemcpyDeviceToHost, h->stream));
+  // pixels into both orderings, flagged index copies, identity point numbering
+  BA_LAUNCH(k_gather_uv, go, b256, 0, h->stream, (const double2*)h->rbuf.p, (const int*)p_src, No, h->p_uv.p);
+  BA_LAUNCH(k_gather_uv, go, b256, 0, h->stream, (const double2*)h->rbuf.p, (const int*)h->c_orig.p, No, h->c_uv.p);
+  BA_LAUNCH(k_init_flagged, go, b256, 0, h->stream, (const int*)h->c_pt.p, (const int*)h->p_cam.p, No, h->c_ptf[0].p, h->c_ptf[1].p,
+            h->p_camf[0].p, h->p_camf[1].p);
+  BA_LAUNCH(k_setup_iota, gp, b256, 0, h->stream, h->slot.p, Np);
+  if (int rc = alloc_solver_buffers(h)) return rc;
+  h->lb = 0;
+  BA_SYNC(h);
+  stage("camera order, windows, pixels");
+  unsigned long long st2[2];
+  memcpy(st2, h->h_setup, sizeof st2);
+  h->cam_band = st2[1] > st2[0];
+  if (const char* e = getenv("BA_CAM_BAND")) h->cam_band = atoi(e) != 0;
+  {
+    const int2* win = (const int2*)(h->h_setup + 64);
+    size_t max_win[2] = {0, 0};
+    const size_t row_bytes[2] = {Pinhole::TA * sizeof(double), BalCam::TA * sizeof(double)};
+    h->all_lds_m[0] = h->all_lds_m[1] = true;
+    for (int b = 0; b < nwin; ++b)
+      for (int m = 0; m < 2; ++m) {
+        const size_t bytes = (size_t)win[b].y * row_bytes[m];
+        if (bytes <= (size_t)LDS_TAB_BYTES) max_win[m] = std::max(max_win[m], bytes);
+        else h->all_lds_m[m] = false;
+      }
+    h->lds_bytes_m[0] = max_win[0]; h->lds_bytes_m[1] = max_win[1];
+  }
+  h->setup_path = 1;
+  return BA_OK;
+}
+
 extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64_t n_obs, const int32_t* cam_idx,
                               const int32_t* pt_idx_in, const double* uv, const double K4[4], int32_t fixed_cam) {
   const int32_t* pt_idx = pt_idx_in;
@@ -609,9 +877,15 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   if (n_obs > 0 && (!cam_idx || !pt_idx || !uv)) return fail(BA_ERR_INVALID, "null observation arrays");
   if (!K4) return fail(BA_ERR_INVALID, "null intrinsics");
   if (fixed_cam < -1 || fixed_cam >= n_cams) return fail(BA_ERR_INVALID, "fixed_cam %d out of range", fixed_cam);
-  for (int64_t i = 0; i < n_obs; ++i) {
-    if (cam_idx[i] < 0 || cam_idx[i] >= n_cams) return fail(BA_ERR_INVALID, "cam_idx[%lld]=%d out of range", (long long)i, cam_idx[i]);
-    if (pt_idx[i] < 0 || pt_idx[i] >= n_pts) return fail(BA_ERR_INVALID, "pt_idx[%lld]=%d out of range", (long long)i, pt_idx[i]);
+  {   // index ranges, before anything is touched (a rejected call keeps the previous problem): branch-free sweep first
+    int ok = 1;
+    for (int64_t i = 0; i < n_obs; ++i)
+      ok &= (int)((unsigned)cam_idx[i] < (unsigned)n_cams) & (int)((unsigned)pt_idx[i] < (unsigned)n_pts);
+    if (!ok)
+      for (int64_t i = 0; i < n_obs; ++i) {
+        if (cam_idx[i] < 0 || cam_idx[i] >= n_cams) return fail(BA_ERR_INVALID, "cam_idx[%lld]=%d out of range", (long long)i, cam_idx[i]);
+        if (pt_idx[i] < 0 || pt_idx[i] >= n_pts) return fail(BA_ERR_INVALID, "pt_idx[%lld]=%d out of range", (long long)i, pt_idx[i]);
+      }
   }
   if ((n_cams + VEC_CAMS - 1) / VEC_CAMS > 16384) return fail(BA_ERR_INVALID, "more than %d cameras are not supported", 16384 * VEC_CAMS);
   stage("validate");
@@ -621,6 +895,30 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   h->have_problem = false;
   h->have_params = false;
   h->linearized = false;
+  h->setup_path = 0;
+  // Large problems whose camera table fits in LDS are laid out ON THE DEVICE (set_problem_device, ba_setup.hpp: one upload
+  // of the caller's arrays, no host sorts; bit-equal result).  BA_SETUP=host / device forces a path (device: whenever the
+  // problem qualifies at all), BA_SETUP_DEVICE_MIN moves the size from which it is chosen.
+  {
+    static const long dev_min = [] { const char* e = getenv("BA_SETUP_DEVICE_MIN"); return e ? atol(e) : 200000L; }();
+    const char* mode = getenv("BA_SETUP");
+    bool try_dev = n_obs > 0 && n_pts > 0 && n_cams > MW_MAX_CAMS && (size_t)n_cams * TA * sizeof(double) <= (size_t)LDS_TAB_BYTES &&
+                   !(getenv("BA_ONE_PART") && atoi(getenv("BA_ONE_PART")) != 0 && h->multi);
+    if (mode && strcmp(mode, "host") == 0) try_dev = false;
+    else if (!(mode && strcmp(mode, "device") == 0) && n_obs < dev_min) try_dev = false;
+    if (try_dev) {
+      h->small_np_pad = -1;
+      const int rc = set_problem_device(h, n_cams, n_pts, (int)n_obs, cam_idx, pt_idx, uv, K4, fixed_cam, timed);
+      if (rc < 0) { const std::string msg = g_err; (void)hipStreamSynchronize(h->stream); h->launch_err = hipSuccess; g_err = msg; return rc; }
+      if (rc == BA_OK) {
+        stage("device build (total)");
+        h->have_problem = true;
+        return BA_OK;
+      }
+      (void)hipStreamSynchronize(h->stream);        // rc == 1: this problem is for the host build
+      h->launch_err = hipSuccess;
+    }
+  }
   // the window solver keeps V = W L resident and only ever writes the columns of points that exist: a new problem on
   // the same handle (fewer landmarks inside the same 16-column padding, or other cameras per point) must not inherit
   // columns of the previous one -> V is cleared again before its next use
@@ -655,25 +953,10 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   // A smaller problem (a sliding window, a shard of a multi-GPU job) gives every point 4, 8 or 16 lanes
   // instead of 2 -- more workgroups, fewer observations per lane -- the most for which the
   // workgroups are still all resident at once.  BA_PT_LANES overrides (tuning only).
-  const size_t full_table = (size_t)Nc * TA * sizeof(double);
-  const bool table_fits = full_table <= (size_t)LDS_TAB_BYTES;
-  const int per_cu = !table_fits ? 1 : (int)std::max<size_t>(1, std::min<size_t>(2048 / PT_THREADS, (size_t)(160 * 1024) / (full_table + 1024)));
-  h->lanes = LPP;
-  for (int ln = 16; ln > LPP; ln >>= 1)
-    if ((Np + PT_THREADS / ln - 1) / (PT_THREADS / ln) <= h->n_cu * per_cu) { h->lanes = ln; break; }
-  if (const char* e = getenv("BA_PT_LANES")) { const int v = atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16) h->lanes = v; }
-  const int pts_per_pass = PT_THREADS / h->lanes;
-  const int want = std::max(1, (Np + pts_per_pass - 1) / pts_per_pass);
-  h->nblkP = std::min(want, 4096);
-  if (table_fits) h->nblkP = std::min(h->nblkP, h->n_cu * per_cu);
-  if (const char* e = getenv("BA_PT_BLOCKS")) h->nblkP = std::max(1, std::min(want, atoi(e)));
-  if (const char* e = getenv("BA_XCD_RANGES")) h->xcd_ranges = atoi(e) != 0;
-  // lanes per (camera, partition) segment in the PCG camera pass: a wave, or a 16-lane row when segments are short
-  // (config 5: ~48 observations per segment -- a wave would walk it in one step with a quarter of its lanes idle and
-  // pay the 64-lane reduction of every sum for it; measured 13.4 -> 12.1 us, C3's ~125-observation segments keep the wave)
-  h->cam_segl = (Nc > 0 && (long long)No / Nc / NPART < 64) ? 16 : 64;
-  if (const char* e = getenv("BA_CAM_SEGL")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) h->cam_segl = v; }
-  h->ppb = std::max(1, (Np + h->nblkP - 1) / h->nblkP);
+  const PtGrid grid = config_point_grid(h, Nc, Np, No);
+  const bool table_fits = grid.table_fits;
+  const int pts_per_pass = grid.pts_per_pass, want = grid.want;
+  (void)pts_per_pass; (void)want;
   // ---- bank-aware visiting order inside a point (2-lane point passes with the camera table in LDS).
   // A point pass reads a camera's 144-byte LDS row with nine ds_read_b128; the hardware serves such a read in groups of
   // 16 lanes, and two lanes of a group collide when their rows fall into the same of 16 bank classes (row mod 16: the
@@ -739,43 +1022,10 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     for (int p = 0; p < Np; ++p) len[p] = pt_off[p + 1] - pt_off[p];
     int med = 0;
     if (Np > 0) { std::nth_element(len.begin(), len.begin() + Np / 2, len.end()); med = len[Np / 2]; }
-    const char* e = getenv("BA_LONG_TRACK");
-    h->long_thr = e ? std::max(1, atoi(e)) : std::max(8, 2 * med);
-    if (h->lanes != LPP) h->long_thr = 0x7fffffff;           // more lanes per point already: no separate long-track rows
+    config_long_threshold(h, med);
   }
   for (int p = 0; p < Np; ++p) if (pt_off[p + 1] - pt_off[p] > h->long_thr) long_pts.push_back(p);
-  h->n_long = (int)long_pts.size();
-  h->long_spb = PT_THREADS / LPP_LONG;
-  if (const char* e = getenv("BA_LONG_SLOTS")) h->long_spb = std::max(1, atoi(e)) * (PT_THREADS / LPP_LONG);
-  h->nblkL = (h->n_long + h->long_spb - 1) / h->long_spb;
-  // A point-pass workgroup is 1024 threads at 128 VGPRs: ONE per compute unit.  When one-round ranges plus one-round
-  // long-track workgroups need somewhat more workgroups than the chip has units (config 5: 306 + 175 on 256), the
-  // second wave of workgroups runs on part of the chip while the rest idles, and every workgroup pays its launch and its
-  // window copy for one round of work.  A round (512 points at 2 lanes, 64 long tracks at 16) is latency-bound and costs
-  // about the same whatever it holds, so the cost of a launch is the largest number of ROUNDS any workgroup walks:
-  // choose the long-track workgroups' size (m rounds) and the ranges' length such that everything is resident at once and
-  // that number is smallest (config 5: 168 ranges of 932 points + 88 x 128 long tracks, two rounds each; Schur point
-  // pass 17.0 -> 15.2 us pinhole, 20.0 -> 18.0 us BAL camera).  Much larger WINDOWED problems (more than two rounds per
-  // unit) keep one-round ranges: narrow windows matter more there.
-  if (!getenv("BA_PT_BLOCKS") && (!table_fits || h->n_long > 0)) {
-    int best_m = 0, best_cost = table_fits ? 0x7fffffff : 3, best_nb = 0;   // (table in LDS: ranges of any length share one fill)
-    const bool pick_m = !getenv("BA_LONG_SLOTS") && h->n_long > 0;
-    for (int m = 1; m <= (pick_m ? 4 : 1); ++m) {
-      const int spb = pick_m ? m * (PT_THREADS / LPP_LONG) : h->long_spb;
-      const int nl = (h->n_long + spb - 1) / spb;
-      const int avail = h->n_cu - nl;
-      if (avail < 1) continue;
-      const int nb = std::min(want, avail);
-      const int rounds = ((Np + nb - 1) / nb + pts_per_pass - 1) / pts_per_pass;
-      const int cost = std::max(rounds, h->n_long > 0 ? spb / (PT_THREADS / LPP_LONG) : 0);
-      if (cost < best_cost) { best_cost = cost; best_m = m; best_nb = nb; }
-    }
-    if (best_m && want + h->nblkL > h->n_cu) {
-      if (pick_m) { h->long_spb = best_m * (PT_THREADS / LPP_LONG); h->nblkL = (h->n_long + h->long_spb - 1) / h->long_spb; }
-      h->nblkP = best_nb;
-      h->ppb = (Np + best_nb - 1) / best_nb;
-    }
-  }
+  config_long_grid(h, grid, Np, (int)long_pts.size());
   const int long_per_blk = h->long_spb;
   // (the visiting order below is laid out for the ranges' final length)
   bank_aware_order(p_cam, p_src, pt_off);
@@ -996,38 +1246,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
       h->mw_ok = h->mw_resident[nt] >= h->mw_G;
     }
   }
-  HIPCHECK(h->c_pt.alloc(nobs1)); HIPCHECK(h->c_orig.alloc(nobs1)); HIPCHECK(h->p_cam.alloc(nobs1));
-  HIPCHECK(h->c_uv.alloc(nobs1)); HIPCHECK(h->p_uv.alloc(nobs1));
-  HIPCHECK(h->c_w[0].alloc(nobs1)); HIPCHECK(h->c_w[1].alloc(nobs1)); HIPCHECK(h->p_w[0].alloc(nobs1)); HIPCHECK(h->p_w[1].alloc(nobs1));
-  HIPCHECK(h->c_ptf[0].alloc(nobs1)); HIPCHECK(h->c_ptf[1].alloc(nobs1)); HIPCHECK(h->p_camf[0].alloc(nobs1)); HIPCHECK(h->p_camf[1].alloc(nobs1));
-  for (int k = 0; k < 2; ++k) {
-    HIPCHECK(h->cams[k].alloc(6 * (size_t)Nc)); HIPCHECK(h->cs[k].alloc(CS * (size_t)Nc));
-    HIPCHECK(h->ptab[k].alloc(PT * np1));     // (k_pack_points writes whole records of set 0; set 1 gets X from the back
-  }                                           //  substitution and y from the point half before either is read)
-  HIPCHECK(h->stage.alloc(3 * np1));
-  // per-camera buffers are sized for the larger camera model (BAL: 9 parameters, 45 + 9 sums, 26-double table rows)
-  constexpr size_t NBX = BalCam::NB, NHX = BalCam::NH, NLX = BalCam::NL;
-  HIPCHECK(h->camA[0].alloc(TA_MAX * (size_t)Nc)); HIPCHECK(h->camA[1].alloc(TA_MAX * (size_t)Nc));
-  HIPCHECK(h->intr[0].alloc(3 * (size_t)Nc)); HIPCHECK(h->intr[1].alloc(3 * (size_t)Nc));
-  HIPCHECK(h->HccBc.alloc(NLX * (size_t)Nc + 8));   // Hcc (NH Nc) | bc (NB Nc): one all-reduce
-  for (int k = 0; k < 2; ++k) {
-    HIPCHECK(h->Hpp[k].alloc(6 * np1)); HIPCHECK(h->bp[k].alloc(3 * np1)); HIPCHECK(h->Hppinv[k].alloc(6 * np1));
-    HIPCHECK(h->y0[k].alloc(3 * np1));
-  }
-  h->pb = 0;
-  HIPCHECK(h->Hccd.alloc(NHX * (size_t)Nc)); HIPCHECK(h->Minv.alloc(NHX * (size_t)Nc));
-  HIPCHECK(h->partR.alloc(2 * (size_t)NPART * Nc));
-  HIPCHECK(h->partL[0].alloc(NLX * (size_t)NPART * Nc)); HIPCHECK(h->partL[1].alloc(NLX * (size_t)NPART * Nc));
-  HIPCHECK(h->part6.alloc(NBX * (size_t)NPART * Nc + 8));   // + the u.y word: one all-reduce carries both
-  HIPCHECK(h->partE.alloc(NHX * (size_t)NPART * Nc));
-  if (h->multi) { HIPCHECK(h->linmsg[0].alloc(8 + NLX * (size_t)Nc)); HIPCHECK(h->linmsg[1].alloc(8 + NLX * (size_t)Nc)); }
-  if (h->multi) HIPCHECK(h->sysmsg.alloc(2 + (size_t)(NBX + NHX) * Nc + (size_t)h->world + 8));
-  HIPCHECK(h->partA.alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partB.alloc(4 * (size_t)(h->nblkP + h->nblkL)));
-  HIPCHECK(h->partC.alloc(5 * nbv_max)); HIPCHECK(h->partV.alloc(4 * nbv_max));
-  HIPCHECK(h->partG[0].alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partG[1].alloc(h->nblkP + h->nblkL)); HIPCHECK(h->partGc.alloc(nbv_max));
-  DBuf<double>* v6[] = {&h->gvec, &h->x, &h->r, &h->p, &h->s, &h->z, &h->vin, &h->vx};
-  for (auto b : v6) HIPCHECK(b->alloc(NBX * (size_t)Nc));
-  HIPCHECK(h->scal.alloc(64));
+  if (int rc = alloc_solver_buffers(h)) return rc;
   if (h->two_level_ok) {
     const size_t nc6 = 6 * (size_t)h->n_agg;
     HIPCHECK(h->run_beg.alloc(run_beg.size())); HIPCHECK(h->run_pt.alloc(run_pt.size())); HIPCHECK(h->run_agg.alloc(run_agg.size()));
@@ -1039,12 +1258,6 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     HIPCHECK(h->coarseU.alloc(18 * (size_t)h->n_runs)); HIPCHECK(h->coarseE.alloc(nc6 * nc6)); HIPCHECK(h->coarseEinv.alloc(nc6 * nc6));
     HIPCHECK(h->coarseEint.alloc(nc6 * nc6)); HIPCHECK(h->coarse_rc.alloc(nc6)); HIPCHECK(h->coarse_info.alloc(8));
   }
-  HIPCHECK(h->st.alloc(2));
-  HIPCHECK(h->verdict.alloc(8));
-  HIPCHECK(hipMemsetAsync(h->verdict.p, 0, 8 * sizeof(double), h->stream));
-  HIPCHECK(h->dev_lam.alloc(2));
-  // (dev_lam is cleared by every back substitution; camA rows: geometry by k_cam_prepare / k_cam_update, vt by the
-  //  PCG setup before any pass reads it)
   h->lb = 0;
   stage("allocations");
   HIPCHECK(upload(h->offk.p, offk.data(), offk.size() * sizeof(int)));
@@ -2261,6 +2474,45 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
 extern "C" int ba_get_stat(ba_handle* h, int32_t which, int64_t* value) {
   if (!h || !value || which < 0 || which >= BA_STAT_COUNT) return fail(BA_ERR_INVALID, "bad argument");
   *value = (int64_t)h->stats[which];
+  return BA_OK;
+}
+// Test hook: the layout ba_set_problem built, copied to the host (tests compare the device build with the host build).
+// which: 0 pt_off (Np+1 ints), 1 p_cam, 2 c_pt, 3 c_orig (Nobs ints each), 4 offk (Nc x 9 ints), 5 long_pts (n_long ints),
+// 6 blk_win ((nblkP + nblkL) x 2 ints), 7 slot (Np ints), 8 scalars (16 ints: lanes, nblkP, ppb, nblkL, long_spb, long_thr,
+// n_long, cam_band, banded, cam_segl, all_lds[0], all_lds[1], lds_bytes[0], lds_bytes[1], build path 0 host / 1 device, mw_ok),
+// 9 p_uv, 10 c_uv (Nobs x 2 doubles each).  *n = elements (ints, or doubles for 9 / 10) written.
+extern "C" int ba_debug_layout(ba_handle* h, int32_t which, void* out, int64_t capacity, int64_t* n) {
+  if (!h || !out || !n) return fail(BA_ERR_INVALID, "null argument");
+  if (!h->have_problem) return fail(BA_ERR_STATE, "ba_set_problem has not been called");
+  if (set_device(h)) return BA_ERR_HIP;
+  const void* src = nullptr;
+  int64_t cnt = 0;
+  size_t esz = sizeof(int);
+  int sc[16];
+  switch (which) {
+    case 0: src = h->pt_off.p; cnt = h->Np + 1; break;
+    case 1: src = h->p_cam.p; cnt = h->Nobs; break;
+    case 2: src = h->c_pt.p; cnt = h->Nobs; break;
+    case 3: src = h->c_orig.p; cnt = h->Nobs; break;
+    case 4: src = h->offk.p; cnt = (int64_t)h->Nc * (NPART + 1); break;
+    case 5: src = h->long_pts.p; cnt = h->n_long; break;
+    case 6: src = h->blk_win.p; cnt = 2 * (int64_t)(h->nblkP + h->nblkL); break;
+    case 7: src = h->slot.p; cnt = h->Np; break;
+    case 8: {
+      const int v[16] = {h->lanes, h->nblkP, h->ppb, h->nblkL, h->long_spb, h->long_thr, h->n_long, h->cam_band, (int)h->banded, h->cam_segl,
+                         (int)h->all_lds_m[0], (int)h->all_lds_m[1], (int)h->lds_bytes_m[0], (int)h->lds_bytes_m[1], h->setup_path, (int)h->mw_ok};
+      memcpy(sc, v, sizeof sc);
+      if (capacity < 16) return fail(BA_ERR_INVALID, "capacity");
+      memcpy(out, sc, sizeof sc); *n = 16; return BA_OK;
+    }
+    case 9: src = h->p_uv.p; cnt = 2 * (int64_t)h->Nobs; esz = sizeof(double); break;
+    case 10: src = h->c_uv.p; cnt = 2 * (int64_t)h->Nobs; esz = sizeof(double); break;
+    default: return fail(BA_ERR_INVALID, "unknown layout array %d", which);
+  }
+  if (capacity < cnt) return fail(BA_ERR_INVALID, "capacity %lld < %lld", (long long)capacity, (long long)cnt);
+  if (cnt > 0) HIPCHECK(hipMemcpyAsync(out, src, (size_t)cnt * esz, hipMemcpyDeviceToHost, h->stream));
+  BA_SYNC(h);
+  *n = cnt;
   return BA_OK;
 }
 // workgroups that hold their compute unit's LDS for a bounded time and do nothing (ba_debug_occupy)

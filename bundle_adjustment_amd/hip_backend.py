@@ -95,6 +95,7 @@ SYMBOLS = {
     "ba_get_trace": (C.c_int, [C.c_void_p, C.POINTER(BAIterRecord), C.c_int32, C.POINTER(C.c_int32)]),
     "ba_get_stat": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "ba_debug_occupy": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double]),
+    "ba_debug_layout": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
 }
 # enum ba_stat (include/ba_hip.h)
 STATS = {"window_mw_launches": 0, "window_lm_launches": 1, "window_fallbacks": 2, "precond_builds": 3, "precond_reuses": 4, "banded": 5,
@@ -364,6 +365,21 @@ class Solver:
             _check(self._lib.ba_get_stat(self._h, which, C.byref(v)))
             out[name] = v.value
         return out
+
+    LAYOUT = {"pt_off": 0, "p_cam": 1, "c_pt": 2, "c_orig": 3, "offk": 4, "long_pts": 5, "blk_win": 6, "slot": 7, "scalars": 8,
+              "p_uv": 9, "c_uv": 10}
+    LAYOUT_SCALARS = ("lanes", "nblkP", "ppb", "nblkL", "long_spb", "long_thr", "n_long", "cam_band", "banded", "cam_segl",
+                      "all_lds_pinhole", "all_lds_bal", "lds_bytes_pinhole", "lds_bytes_bal", "build_path", "mw_ok")
+
+    def debug_layout(self, name):
+        """Test hook (ba_debug_layout): one array of the layout ba_set_problem built, as numpy (scalars: a dict)."""
+        which = self.LAYOUT[name]
+        cap = max(2 * self.n_obs, 9 * self.n_cams, self.n_pts + 1, 16384)
+        buf = np.empty(cap, dtype=np.float64 if which >= 9 else np.int32)
+        n = C.c_int64(0)
+        _check(self._lib.ba_debug_layout(self._h, which, buf.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+        out = buf[:n.value].copy()
+        return dict(zip(self.LAYOUT_SCALARS, (int(v) for v in out))) if name == "scalars" else out
 
     def debug_occupy(self, n_workgroups, lds_bytes, milliseconds):
         """Test hook (ba_debug_occupy): idle workgroups on a second stream hold compute units' LDS for a bounded time."""

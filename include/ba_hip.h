@@ -166,6 +166,10 @@ int ba_get_stat(ba_handle* h, int32_t which, int64_t* value);
  * lds_bytes of LDS each idle for `milliseconds` (at most 2000) of the device's wall clock, then leave.  Returns at once.
  * Lets a test hold the units the window solver's workgroups would need (tests/test_gpu_small.py). */
 int ba_debug_occupy(ba_handle* h, int32_t n_workgroups, int32_t lds_bytes, double milliseconds);
+/* Test hook: one array of the layout ba_set_problem built (the two observation orderings, their offsets, windows, grid
+ * scalars), copied to out; `which` as listed in csrc/ba_hip.hip.  Lets a test compare the device build of large problems
+ * (csrc/ba_setup.hpp) with the host build (BA_SETUP=host) element by element. */
+int ba_debug_layout(ba_handle* h, int32_t which, void* out, int64_t capacity, int64_t* n);
 /* Batched two-view triangulation + cheirality test: replaces VisualOdometryPipeline._triangulate_points,
  * src/pipeline.py:315-336 (cv2.triangulatePoints on P1 = K [I|0], P2 = K [R_rel|t_rel], division by (w + 1e-6),
  * z > 0 in both cameras).  K, R_rel row-major 3x3; pts1 / pts2 double[n][2] pixels in the two views; xyz double[n][3]
