@@ -347,7 +347,8 @@ def main():
         kw["precond_lag"] = args.precond_lag
 
     # the PCG model test in effect (ba_options.pcg_model_tol = -1 resolves inside the library; mirrored here for the line)
-    model_tol_eff = args.pcg_model_tol if args.pcg_model_tol >= 0 else (0.5 if (solver.stats()["banded"] and world == 1 and not os.environ.get("BA_COMM_FORCE")) else 0.0)
+    # (the automatic default needs a loose outer tolerance, ftol >= 1e-6; the bench runs with ftol = 0: off)
+    model_tol_eff = args.pcg_model_tol if args.pcg_model_tol >= 0 else 0.0
 
     def run_solve(**k):
         if intr0 is not None:

@@ -206,6 +206,8 @@ struct ba_handle {
   DBuf<int> setup_i;                      // scratch of the device build of ba_set_problem (ba_setup.hpp)
   char* h_setup = nullptr;                // pinned: what that build reads back (track-length histogram, statistics, windows)
   int setup_path = 0;                     // how the current problem's layout was built: 0 host, 1 device
+  DBuf<double> stat2;                     // multi-rank: the band statistic (span sum, tracks) summed over the shards
+  bool banded_known = false;              // ... already decided for the problem being set (device build that fell back to the host build)
   // two-level preconditioner for band-structured problems (ba_coarse.hpp): structures built by ba_set_problem
   bool banded = false;         // mean camera span of a track <= Nc / 8 (sequential captures): pcg_model_tol's automatic default
   bool two_level_ok = false;   // this problem has them
@@ -395,6 +397,7 @@ extern "C" int ba_destroy(ba_handle* h) {
   if (h->h_up) (void)hipHostFree(h->h_up);
   if (h->h_setup) (void)hipHostFree(h->h_setup);
   h->setup_i.release();
+  h->stat2.release();
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -598,6 +601,25 @@ static int allreduce(ba_handle* h, double* buf, size_t count, bool is_max = fals
 }
 
 // ---------------------------------------------------------------------------- problem
+// The band statistic behind pcg_model_tol's automatic default (mean camera span of a track <= Nc / 8).  Tracks are split
+// over the ranks of a multi-rank job by landmark, so the sums of the shards are the whole problem's: one small all-reduce
+// makes every rank decide what a single rank would.  Collective: every rank's ba_set_problem calls it exactly once.
+static int decide_banded(ba_handle* h, double span_sum, double tracks, int Nc) {
+  if (h->multi) {
+    HIPCHECK(h->stat2.alloc(2));
+    const double v[2] = {span_sum, tracks};
+    HIPCHECK(hipMemcpyAsync(h->stat2.p, v, sizeof v, hipMemcpyHostToDevice, h->stream));
+    if (int rc = allreduce(h, h->stat2.p, 2)) return rc;
+    double w[2];
+    HIPCHECK(hipMemcpyAsync(w, h->stat2.p, sizeof w, hipMemcpyDeviceToHost, h->stream));
+    BA_SYNC(h);
+    span_sum = w[0]; tracks = w[1];
+  }
+  h->banded = tracks > 0 && span_sum / tracks <= Nc / 8.0;
+  h->stats[BA_STAT_BANDED] = h->banded ? 1 : 0;
+  h->banded_known = true;
+  return BA_OK;
+}
 // Point-pass grid, part 1 (needs the problem's dimensions only): lanes per point, number and length of the point ranges,
 // lanes per segment of the PCG camera pass.  Shared by the host and the device build of ba_set_problem.
 struct PtGrid { bool table_fits; int per_cu, pts_per_pass, want; };
@@ -792,8 +814,7 @@ static int set_problem_device(ba_handle* h, int Nc, int Np, int No, const int32_
   int n_long = 0;
   if (h->long_thr != 0x7fffffff) for (int L = h->long_thr + 1; L < SETUP_HIST_BINS; ++L) n_long += hh[L];
   config_long_grid(h, grid, Np, n_long);
-  h->banded = n_tracks > 0 && (double)span_sum / n_tracks <= Nc / 8.0;
-  h->stats[BA_STAT_BANDED] = h->banded ? 1 : 0;
+  if (int rc = decide_banded(h, (double)span_sum, (double)n_tracks, Nc)) return rc;
   {   // problems the two-level preconditioner's structures would be built for: the host build (it also re-sorts every track by camera)
     bool want = h->banded && !h->multi;
     if (const char* e = getenv("BA_TWO_LEVEL")) want = atoi(e) != 0 && !h->multi;
@@ -896,6 +917,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   h->have_params = false;
   h->linearized = false;
   h->setup_path = 0;
+  h->banded_known = false;
   // Large problems whose camera table fits in LDS are laid out ON THE DEVICE (set_problem_device, ba_setup.hpp: one upload
   // of the caller's arrays, no host sorts; bit-equal result).  BA_SETUP=host / device forces a path (device: whenever the
   // problem qualifies at all), BA_SETUP_DEVICE_MIN moves the size from which it is chosen.
@@ -1103,8 +1125,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
       span_sum += hi - lo;
       ++tracks;
     }
-    h->banded = tracks > 0 && span_sum / tracks <= Nc / 8.0;
-    h->stats[BA_STAT_BANDED] = h->banded ? 1 : 0;
+    if (!h->banded_known) { if (int rc = decide_banded(h, span_sum, (double)tracks, Nc)) return rc; }
     bool want = h->banded && !h->multi;
     if (const char* e = getenv("BA_TWO_LEVEL")) want = atoi(e) != 0 && !h->multi;
     if (want && Nc >= 2 * VEC_CAMS && Np > 0 && No > 0) {
@@ -2198,7 +2219,9 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   const int Nc = h->Nc;
   h->profile = opts->profile != 0;
   const double tol2 = opts->pcg_tol * opts->pcg_tol;
-  const double model_tol = opts->pcg_model_tol >= 0.0 ? opts->pcg_model_tol : ((h->banded && !h->multi) ? 0.5 : 0.0);
+  // (automatic: the model test trades inner accuracy for outer iterations -- on band-structured problems a large gain at
+  // loose outer tolerances like the reference's ftol = 1e-5, a loss where the caller asks for tight convergence)
+  const double model_tol = opts->pcg_model_tol >= 0.0 ? opts->pcg_model_tol : ((h->banded && opts->ftol >= 1e-6) ? 0.5 : 0.0);
 
   BA_SYNC(h);
   const double t_begin = now_s();

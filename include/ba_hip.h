@@ -79,10 +79,12 @@ typedef struct ba_options {
                               iterating long after the step has stopped improving the model: BASELINE config 5 on the
                               BAL camera at the reference's tolerances 1148 -> 557 PCG iterations, 39 -> 20 ms; on the
                               well-conditioned C3 it truncates useful iterations (a run to convergence needs 54 LM
-                              iterations instead of 22).  Hence the default -1 = AUTOMATIC: 0.5 when ba_set_problem found
+                              iterations instead of 22), and on a chain driven to ftol = 1e-8 the truncated steps
+                              stall the outer iteration.  Hence the default -1 = AUTOMATIC: 0.5 when ba_set_problem found
                               the problem band-structured (mean camera span of a track <= Nc / 8: sequential captures;
-                              BA_STAT_BANDED) on a single rank, off otherwise (every rank of a multi-rank job must run
-                              the same test, and a rank only sees its shard: pass an explicit value there). */
+                              BA_STAT_BANDED; the statistic is summed over the landmark shards of a multi-rank job, so
+                              every rank decides what a single rank would) AND the outer tolerance is loose (ftol >= 1e-6,
+                              e.g. the reference's 1e-5); off otherwise. */
   int32_t pcg_model_min_iters; /* default 5 */
   int32_t precond_lag;     /* Schur-Jacobi only: how many consecutive damped systems may KEEP the preconditioner blocks
                               (M^-1 = blockdiag(S)^-1) built for an earlier one instead of rebuilding them (a preconditioner

@@ -540,8 +540,9 @@ def lm_solve(cams, pts, cam_idx, pt_idx, uv, K4, fixed_cam=-1, loss='linear',
     Returns dict(cams, pts, iterations, accepted, sse0, sse, cost0, cost, pcg_iters,
     history)."""
     nb = 9 if model == 'bal' else 6
-    if pcg_model_tol < 0:           # the device's automatic default (ba_options.pcg_model_tol = -1): on for band-structured problems
-        pcg_model_tol = 0.5 if band_structured(cam_idx, pt_idx, np.asarray(cams).reshape(-1, nb).shape[0]) else 0.0
+    if pcg_model_tol < 0:           # the device's automatic default (ba_options.pcg_model_tol = -1): on for band-structured
+        # problems solved to a loose outer tolerance (ftol >= 1e-6)
+        pcg_model_tol = 0.5 if (ftol >= 1e-6 and band_structured(cam_idx, pt_idx, np.asarray(cams).reshape(-1, nb).shape[0])) else 0.0
     cams = np.array(cams, dtype=np.float64).reshape(-1, nb)
     pts = np.array(pts, dtype=np.float64).reshape(-1, 3)
     lam, nu = lam0, 2.0

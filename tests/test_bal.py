@@ -266,13 +266,17 @@ def test_config5_bal_residuals_and_blocks_at_full_size():
 
 
 @pytest.mark.gpu
-def test_config5_bal_solve_reaches_the_noise_floor_at_full_size():
+@pytest.mark.parametrize("extra,budget", [(dict(), 40), (dict(pcg_model_tol=0.5), 30)])
+def test_config5_bal_solve_reaches_the_noise_floor_at_full_size(extra, budget):
     """ba_solve_bal on config 5: poses, points, f, k1, k2 adjusted from a 6.8 px start to the pixel noise (0.5 px per
     coordinate; with ~4 views per point the fit sits at ~0.56 px per observation); the summary's SSE and cost are the
-    oracle's BAL residual of the returned parameters; the held camera did not move; a second solve gives the same bits."""
+    oracle's BAL residual of the returned parameters; the held camera did not move; a second solve gives the same bits.
+    The solve must END ON A CONVERGENCE TEST (ftol = 1e-7) inside its budget: with the library's defaults (measured: 32 LM
+    iterations, the last twenty at ~165 PCG iterations each once the cap-aware damping floor has settled) and with the
+    PCG model test on (21 LM iterations; round 3's budget of 30)."""
     from bundle_adjustment_amd import hip_backend
     p = _config5()
-    kw = dict(fixed_cam=0, loss="huber", max_iters=30, ftol=1e-7, xtol=1e-10, gtol=1e-10, pcg_tol=0.1, pcg_max_iters=300)
+    kw = dict(fixed_cam=0, loss="huber", max_iters=budget, ftol=1e-7, xtol=1e-10, gtol=1e-10, pcg_tol=0.1, pcg_max_iters=300, **extra)
     with hip_backend.Solver(0) as s:
         out, cams, pts = s.solve_bal(p, **kw)
         tr = s.trace()
@@ -280,9 +284,9 @@ def test_config5_bal_solve_reaches_the_noise_floor_at_full_size():
         again, cams2, pts2 = s.solve_bal(p, **kw)
     assert np.sqrt(out["initial_sse"] / p.n_obs) > 5.0 and np.sqrt(out["final_sse"] / p.n_obs) < 0.60
     # The solve has to STOP ON A CONVERGENCE TEST within its budget.  (Round 3 could not: the late inner solves of this chain
-    # ran into the PCG cap at ever smaller dampings and the run ended on max_iters; what stops it now is the library's default
-    # behaviour on such problems -- the PCG model test, switched on where ba_set_problem finds band structure, and the
-    # cap-aware damping floor.)
+    # ran into the PCG cap at ever smaller dampings and the run ended on max_iters; what stops it now is the cap-aware
+    # damping floor -- an inner solve that hits pcg_max_iters keeps the damping from falling any further.  The PCG model
+    # test, automatic on band-structured problems at loose outer tolerances, is off at this ftol.)
     assert out["status_name"] in ("ftol", "xtol", "gtol") and out["accepted"] >= 5, (out, [t["pcg_iterations"] for t in tr])
     assert st["banded"] == 1
     assert len(tr) == out["iterations"] and all(t["pcg_iterations"] >= 1 for t in tr)
@@ -332,12 +336,16 @@ def test_bal_fp32_jacobian_mode_reaches_the_fp64_solution():
     with hip_backend.Solver(0) as s:
         a, ca, pa = s.solve_bal(p, **kw)
         b, cb, pb = s.solve_bal(p, jacobian_precision=1, **kw)
-    assert abs(a["final_cost"] - b["final_cost"]) <= 1e-7 * a["final_cost"]
+    assert abs(a["final_cost"] - b["final_cost"]) <= 1e-10 * a["final_cost"]
     # (only camera 0 is held: the scale of the scene is free, the minimiser is a one-parameter family and the two runs
     # stop at different members of it -- rotations, focal lengths and distortion are scale-free and agree)
-    assert np.abs(ca[:, :3] - cb[:, :3]).max() <= 1e-5 and np.abs(ca[:, 6:] / cb[:, 6:] - 1).max() <= 1e-4
+    # Tolerances = about ten times what TWO FP64 RUNS of this very problem differ by when only a solver setting changes
+    # (initial damping 1e-3, PCG tolerance 1e-3, kept preconditioner blocks off; tools/fp32_spread.py, round 4:
+    # rotations 2e-9 .. 3e-8, intrinsics 2e-7 .. 7e-7 relative, scale 3e-6 .. 1e-3, points after removing the scale
+    # 1e-8 .. 5e-6 relative; the fp32-Jacobian run sits inside that spread at 5e-9 / 2e-7 / 3e-4 / 2e-6).
+    assert np.abs(ca[:, :3] - cb[:, :3]).max() <= 3e-7 and np.abs(ca[:, 6:] / cb[:, 6:] - 1).max() <= 1e-5
     sc = np.linalg.norm(ca[1:, 3:6]) / np.linalg.norm(cb[1:, 3:6])
-    assert abs(sc - 1) < 1e-2 and np.abs(sc * pb - pa).max() <= 1e-3 * np.abs(pa).max()
+    assert abs(sc - 1) < 1e-2 and np.abs(sc * pb - pa).max() <= 5e-5 * np.abs(pa).max()
 
 
 @pytest.mark.gpu

@@ -1,6 +1,6 @@
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bundle_adjustment_amd import hip_backend
 from tests.test_bal import _synthetic_bal
 p = _synthetic_bal(40, 2000, 5, seed=12)
