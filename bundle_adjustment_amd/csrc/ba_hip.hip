@@ -242,6 +242,8 @@ struct ba_handle {
   // host-staged shared-memory transport (BA_COMM=shm): a test vehicle that lets several ranks
   // share ONE GPU (RCCL refuses that), so the multi-rank control flow can be exercised end to end
   struct ShmComm* shm = nullptr;
+  // device-side exchange of the per-PCG-iteration message through IPC-mapped peer buffers (BA_IPC=1; ba_kernels.hpp)
+  struct IpcComm* ipc = nullptr;
   // first failed kernel launch since the last check (hipGetLastError right behind every launch)
   hipError_t launch_err = hipSuccess;
   char launch_what[160] = {0};
@@ -354,13 +356,16 @@ extern "C" int ba_create(int device_id, ba_handle** out) {
 
 static void flush_profile(ba_handle* h);
 static void shm_destroy(ba_handle* h);
+static void ipc_destroy(ba_handle* h);
 static int shm_init(ba_handle* h, int rank, int world, const void* id128);
+static int ipc_init(ba_handle* h, int rank, int world, const void* id128);
 
 extern "C" int ba_destroy(ba_handle* h) {
   if (!h) return BA_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->nccl && g_rccl.CommDestroy) g_rccl.CommDestroy(h->nccl);
+  ipc_destroy(h);
   shm_destroy(h);
   for (auto e : h->ev) (void)hipEventDestroy(e);
   DBuf<int>* ib[] = {&h->offk, &h->c_pt, &h->c_orig, &h->pt_off, &h->p_cam, &h->slot, &h->long_pts, &h->c_ptf[0], &h->c_ptf[1],
@@ -439,6 +444,9 @@ extern "C" int ba_comm_init(ba_handle* h, int rank, int world, const void* id128
   if (!h->multi) return BA_OK;
   if (!id128) return fail(BA_ERR_INVALID, "null id buffer");
   if (set_device(h)) return BA_ERR_HIP;
+  // BA_IPC=1: the per-PCG-iteration exchange goes through IPC-mapped peer buffers (device-side stores + flags, consumed
+  // inside k_pcg_step) instead of the base transport's all-reduce; everything else stays on the base transport
+  if (const char* e = getenv("BA_IPC")) if (atoi(e) != 0) { if (int rc = ipc_init(h, rank, world, id128)) return rc; }
   { const char* e = getenv("BA_COMM"); if (e && strcmp(e, "shm") == 0) return shm_init(h, rank, world, id128); }
   if (int rc = load_rccl()) return rc;
   ncclUniqueId id;
@@ -588,6 +596,110 @@ static int shm_allreduce(ba_handle* h, double* buf, size_t count, bool is_max) {
   if (c->barrier()) return fail(BA_ERR_COMM, "shm barrier timed out");
   HIPCHECK(hipMemcpyAsync(buf, c->stage, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
   BA_SYNC(h);      // the staging buffer is reused by the next call
+  return BA_OK;
+}
+
+// ------------------------------------------------------ device-side exchange over IPC-mapped peer buffers (BA_IPC=1)
+// Every rank allocates a receive buffer ([2 parities][world][stride] doubles + flag lines) in fine-grained device memory,
+// exports it with hipIpcGetMemHandle and opens every peer's; the handles travel through a small POSIX shared-memory
+// board named after the communicator id (one node: what bench.py --gpus N runs on).  Used for the Schur product's
+// exchange inside the PCG loop (k_ipc_fold_send -> k_pcg_step); every other collective keeps the base transport.
+struct IpcComm {
+  static constexpr size_t STRIDE = 32768;             // doubles per (parity, sender) slot: messages up to 256 KB (3600 BAL cameras)
+  int rank = 0, world = 1;
+  char name[64] = {0};
+  unsigned char* board = nullptr;                     // shm: [64-byte counter line][64-byte sense line][world x 128 bytes of handle]
+  size_t board_bytes = 0;
+  unsigned gen = 0;
+  void* local = nullptr;                              // own receive buffer (recv doubles, then the flag lines)
+  void* opened[IPC_MAX_WORLD] = {nullptr};
+  IpcPeers peers;
+  int* ticket = nullptr;
+  long long seq = 0;
+  size_t recv_doubles() const { return (size_t)2 * world * STRIDE; }
+  size_t bytes() const { return recv_doubles() * sizeof(double) + (size_t)2 * world * IPC_FLAG_STRIDE * sizeof(unsigned long long); }
+  std::atomic<unsigned>* counter() { return reinterpret_cast<std::atomic<unsigned>*>(board); }
+  std::atomic<unsigned>* sense() { return reinterpret_cast<std::atomic<unsigned>*>(board + 64); }
+  int barrier() {
+    const unsigned my = ++gen;
+    if (counter()->fetch_add(1, std::memory_order_acq_rel) + 1 == (unsigned)world) {
+      counter()->store(0, std::memory_order_relaxed);
+      sense()->store(my, std::memory_order_release);
+    } else {
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (sense()->load(std::memory_order_acquire) < my)
+        if ((++spins & 0xffff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0) return -1;
+    }
+    return 0;
+  }
+};
+static void ipc_destroy(ba_handle* h) {
+  if (!h->ipc) return;
+  IpcComm* c = h->ipc;
+  if (c->board) (void)c->barrier();                   // nobody unmaps a buffer a peer may still be storing into
+  for (int r = 0; r < c->world; ++r) if (c->opened[r]) (void)hipIpcCloseMemHandle(c->opened[r]);
+  if (c->local) (void)hipFree(c->local);
+  if (c->ticket) (void)hipFree(c->ticket);
+  if (c->board) { munmap(c->board, c->board_bytes); if (c->rank == 0) shm_unlink(c->name); }
+  delete c;
+  h->ipc = nullptr;
+}
+static int ipc_init(ba_handle* h, int rank, int world, const void* id128) {
+  if (world > IPC_MAX_WORLD) return fail(BA_ERR_COMM, "BA_IPC: at most %d ranks", IPC_MAX_WORLD);
+  IpcComm* c = new IpcComm();
+  h->ipc = c;
+  c->rank = rank; c->world = world;
+  const unsigned char* id = (const unsigned char*)id128;
+  unsigned long long tag = 1469598103934665603ULL;
+  for (int i = 0; i < 128; ++i) tag = (tag ^ id[i]) * 1099511628211ULL;
+  snprintf(c->name, sizeof c->name, "/ba_ipc_%016llx", tag);
+  c->board_bytes = 128 + (size_t)world * 128;
+  int fd = shm_open(c->name, O_CREAT | O_RDWR, 0600);
+  if (fd < 0) return fail(BA_ERR_COMM, "shm_open(%s) failed", c->name);
+  if (ftruncate(fd, (off_t)c->board_bytes) != 0) { close(fd); return fail(BA_ERR_COMM, "ftruncate failed"); }
+  void* m = mmap(nullptr, c->board_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) return fail(BA_ERR_COMM, "mmap failed");
+  c->board = (unsigned char*)m;
+  // fine-grained device memory: peer stores are visible to this device's loads without cache maintenance
+  if (hipExtMallocWithFlags(&c->local, c->bytes(), hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(BA_ERR_COMM, "BA_IPC: fine-grained device memory for the receive buffer is not available");
+  }
+  HIPCHECK(hipMemset(c->local, 0, c->bytes()));
+  HIPCHECK(hipMalloc((void**)&c->ticket, sizeof(int)));
+  HIPCHECK(hipMemset(c->ticket, 0, sizeof(int)));
+  HIPCHECK(hipDeviceSynchronize());
+  hipIpcMemHandle_t mine;
+  if (hipIpcGetMemHandle(&mine, c->local) != hipSuccess) { (void)hipGetLastError(); return fail(BA_ERR_COMM, "hipIpcGetMemHandle failed"); }
+  static_assert(sizeof(hipIpcMemHandle_t) <= 120, "handle does not fit its board slot");
+  memcpy(c->board + 128 + (size_t)rank * 128, &mine, sizeof mine);
+  const int dev_of_rank = h->device;
+  memcpy(c->board + 128 + (size_t)rank * 128 + 120, &dev_of_rank, sizeof(int));
+  if (c->barrier()) return fail(BA_ERR_COMM, "BA_IPC: board barrier timed out");
+  for (int r = 0; r < world; ++r) {
+    void* base = c->local;
+    if (r != rank) {
+      hipIpcMemHandle_t hd;
+      memcpy(&hd, c->board + 128 + (size_t)r * 128, sizeof hd);
+      int peer_dev = 0;
+      memcpy(&peer_dev, c->board + 128 + (size_t)r * 128 + 120, sizeof(int));
+      if (peer_dev != h->device) {                      // another GPU of the node: its memory has to be reachable from this one
+        int can = 0;
+        (void)hipDeviceCanAccessPeer(&can, h->device, peer_dev);
+        if (can) { const hipError_t e = hipDeviceEnablePeerAccess(peer_dev, 0); if (e != hipSuccess) (void)hipGetLastError(); }
+      }
+      if (hipIpcOpenMemHandle(&base, hd, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(BA_ERR_COMM, "BA_IPC: hipIpcOpenMemHandle of rank %d's buffer failed", r);
+      }
+      c->opened[r] = base;
+    }
+    c->peers.recv[r] = (double*)base;
+    c->peers.flags[r] = (unsigned long long*)((double*)base + c->recv_doubles());
+  }
+  if (c->barrier()) return fail(BA_ERR_COMM, "BA_IPC: board barrier timed out");
   return BA_OK;
 }
 
@@ -2330,14 +2442,36 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       launch_pt_schur(h, robust, 0, kk, tol2, opts->pcg_min_iters, base,
                       (kk == 0 && gtol_pending) ? h->d_scal_host + GMAX_HOST_SLOT : (double*)nullptr, fuse ? &cu : nullptr);
     };
+    const bool use_ipc = h->ipc && h->multi && !h->two_level && 2 + (size_t)nb_of(h) * Nc <= IpcComm::STRIDE;
     auto launch_rest = [&](int kk) -> int {
       launch_cam_schur(h, robust, false, true, kk, tol2, opts->pcg_min_iters);
-      if (int rc = exchange_schur(h)) return rc;
+      // the Schur product of the reduced camera system, summed over the ranks: device-side stores into every peer's receive
+      // buffer (consumed inside k_pcg_step), or fold + all-reduce on the base transport
+      const double* p6_src = p6_ptr(h);
+      int p6_parts = nparts_of(h);
+      const unsigned long long* ipc_flags = nullptr;
+      int ipc_parity = 0;
+      long long ipc_seq = 0;
+      if (use_ipc) {
+        IpcComm* c = h->ipc;
+        ipc_seq = ++c->seq;
+        ipc_parity = (int)(ipc_seq & 1);
+        const size_t n6 = (size_t)nb_of(h) * Nc;
+        {
+          Scope sc(h, BA_K_ALLREDUCE);
+          BA_LAUNCH(k_ipc_fold_send, dim3((unsigned)((n6 + 255) / 256)), dim3(256), 0, h->stream, (const double*)uy_ptr(h), (const double*)p6_ptr(h), n6,
+                    h->one_part ? 1 : NPART, c->peers, c->rank, c->world, ipc_parity, IpcComm::STRIDE, ipc_seq, c->ticket);
+        }
+        p6_src = c->peers.recv[c->rank] + (size_t)ipc_parity * c->world * IpcComm::STRIDE + 2;
+        p6_parts = c->world;
+        ipc_flags = c->peers.flags[c->rank];
+        h->stats[BA_STAT_IPC_EXCHANGES]++;
+      } else if (int rc = exchange_schur(h)) return rc;
       Scope sc(h, BA_K_PCG_UPDATE);
-#define STEP_ARGS kk, p6_ptr(h), nparts_of(h), (const double*)uy_ptr(h), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc, h->fixed, tol2,       \
+#define STEP_ARGS kk, p6_src, p6_parts, (const double*)uy_ptr(h), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc, h->fixed, tol2,       \
                   opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA[h->cur].p, h->partV.p, nbv(h), h->st.p, \
                   h->d_flags, base, (const double*)h->verdict.p
-#define STEP_TAIL h->vx.p, model_tol, opts->pcg_model_min_iters
+#define STEP_TAIL h->vx.p, model_tol, opts->pcg_model_min_iters, ipc_flags, IpcComm::STRIDE, ipc_parity, ipc_seq, h->d_flags + 6
       if (h->two_level) {
         BA_LAUNCH((k_pcg_step<Pinhole, true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, h->coarse_rc.p, STEP_TAIL);
         BA_LAUNCH(k_pcg_coarse, dim3(h->n_agg), dim3(VEC_BLOCK), 0, h->stream, kk, (const double*)h->coarseEinv.p,
@@ -2357,6 +2491,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     launch_point_pass(0);
     while (true) {
       if (int rc = wait_flag(h, 0, base + k + 1)) return rc;
+      if (h->h_flags[6] == 2) { h->h_flags[6] = 0; return fail(BA_ERR_COMM, "LM iteration %d: a peer's share of the reduced camera system's product did not arrive (BA_IPC)", it); }
       // the gradient maximum was written by a kernel ahead of this probe: visible now
       if (gtol_pending) {
         gtol_pending = false;

@@ -157,6 +157,7 @@ enum ba_stat {
   BA_STAT_PRECOND_REUSES = 4,       /* damped systems that kept the previous blocks (ba_options.precond_lag) */
   BA_STAT_BANDED = 5,               /* 1: ba_set_problem found the current problem band-structured (pcg_model_tol's automatic default) */
   BA_STAT_CAP_FLOOR_RAISES = 6,     /* LM iterations whose inner solve ran into pcg_max_iters and raised the damping floor */
+  BA_STAT_IPC_EXCHANGES = 7,        /* PCG iterations whose reduced-system product was exchanged through IPC-mapped peer buffers (BA_IPC=1) */
   BA_STAT_COUNT = 8
 };
 

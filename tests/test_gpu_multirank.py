@@ -50,16 +50,23 @@ json.dump(out, open(os.path.join(%(out)r, f"out_{rank}.json"), "w"))
 s.set_params(sub.cams, sub.pts)
 out2 = s.solve(loss="huber", max_iters=25, ftol=0.0, xtol=0.0, gtol=float(os.environ["TEST_GTOL"]), pcg_tol=1e-3, preconditioner="jacobi")
 json.dump(out2, open(os.path.join(%(out)r, f"out2_{rank}.json"), "w"))
+json.dump(s.stats(), open(os.path.join(%(out)r, f"stats_{rank}.json"), "w"))
 s.close()
 dist.barrier()
 dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("one_part", ["0", "1"])
-def test_two_ranks_on_one_gpu_match_single_rank(tmp_path, one_part):
+@pytest.mark.parametrize("one_part,ipc", [("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")])
+def test_two_ranks_on_one_gpu_match_single_rank(tmp_path, one_part, ipc):
     """one_part = 1: every camera's shard-local observations in partition 0 (BA_ONE_PART, an experiment switch of
-    ba_set_problem): partial sums come out folded, no fold kernel runs ahead of the all-reduces."""
+    ba_set_problem): partial sums come out folded, no fold kernel runs ahead of the all-reduces.
+    ipc = 1 (BA_IPC): the per-PCG-iteration exchange of the reduced camera system's product does not go through the
+    transport's all-reduce but through IPC-mapped peer buffers -- every rank's fold kernel stores its share and a sequence
+    flag into the other rank's receive buffer (hipIpcGetMemHandle / hipIpcOpenMemHandle between the two processes on this
+    one GPU), k_pcg_step waits for the flags and adds the slots in rank order.  Same sums in the same order as the
+    host-staged transport: the results must be IDENTICAL to the ipc = 0 run's, bit for bit (checked through the
+    single-rank reference both are compared with, and by the exchange counter)."""
     from bundle_adjustment_amd import hip_backend
     from bundle_adjustment_amd.problem import shard_by_landmark
     from bundle_adjustment_amd.synthetic import make_problem
@@ -78,7 +85,7 @@ def test_two_ranks_on_one_gpu_match_single_rank(tmp_path, one_part):
                 ref2 = cand
                 break
     assert ref2 is not None and ref2["iterations"] < 25
-    env = dict(os.environ, BA_COMM="shm", BA_ONE_PART=one_part, TEST_GTOL=repr(gtol))
+    env = dict(os.environ, BA_COMM="shm", BA_ONE_PART=one_part, BA_IPC=ipc, TEST_GTOL=repr(gtol))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", _free_port(), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
@@ -88,6 +95,9 @@ def test_two_ranks_on_one_gpu_match_single_rank(tmp_path, one_part):
         ref = s.solve(loss="huber", max_iters=25, ftol=1e-13, xtol=1e-13, gtol=1e-12, pcg_tol=1e-3)
         cams_ref, pts_ref = s.get_params()
     outs = [json.load(open(tmp_path / f"out_{k}.json")) for k in range(2)]
+    stats = [json.load(open(tmp_path / f"stats_{k}.json")) for k in range(2)]
+    for st in stats:                                         # one exchange per PCG iteration went through the peer buffers, or none
+        assert (st["ipc_exchanges"] >= outs[0]["pcg_iterations"]) if ipc == "1" else (st["ipc_exchanges"] == 0), st
     # every rank reports the same global costs / iteration counts
     for key in ("iterations", "accepted", "pcg_iterations", "initial_sse", "final_sse", "final_cost"):
         assert outs[0][key] == outs[1][key], key
@@ -206,10 +216,10 @@ dist.destroy_process_group()
 """
 
 
-def _run_two_ranks(tmp_path, mode):
+def _run_two_ranks(tmp_path, mode, ipc="0"):
     script = tmp_path / f"shard_worker_{mode}.py"
     script.write_text(SHARD_WORKER % dict(root=ROOT, out=str(tmp_path), mode=mode))
-    env = dict(os.environ, BA_COMM="shm")
+    env = dict(os.environ, BA_COMM="shm", BA_IPC=ipc)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", _free_port(), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
@@ -217,13 +227,14 @@ def _run_two_ranks(tmp_path, mode):
     return [json.load(open(tmp_path / f"out_{k}.json")) for k in range(2)]
 
 
-def test_rank_with_an_empty_landmark_shard_joins_every_collective(tmp_path):
+@pytest.mark.parametrize("ipc", ["0", "1"])
+def test_rank_with_an_empty_landmark_shard_joins_every_collective(tmp_path, ipc):
     """One rank owns every landmark, the other none (what a skewed track distribution or world > n_pts can produce):
     the empty rank must still take part in every all-reduce of ba_solve -- no deadlock -- and both ranks must report
     the single-rank result."""
     from bundle_adjustment_amd import hip_backend
     from bundle_adjustment_amd.synthetic import make_problem
-    outs = _run_two_ranks(tmp_path, "empty")
+    outs = _run_two_ranks(tmp_path, "empty", ipc)
     p = make_problem(9, 700, 4, seed=23, outlier_frac=0.01)
     with hip_backend.Solver(0) as s:
         s.set_problem(p)
@@ -239,14 +250,15 @@ def test_rank_with_an_empty_landmark_shard_joins_every_collective(tmp_path):
     assert np.abs(np.load(tmp_path / "pts_0.npy") - pts_ref).max() <= 1e-7
 
 
-def test_c3_sized_shard_pair_reproduces_the_single_rank_iterates(tmp_path):
+@pytest.mark.parametrize("ipc", ["0", "1"])
+def test_c3_sized_shard_pair_reproduces_the_single_rank_iterates(tmp_path, ipc):
     """SURVEY.md section 4, multi-GPU row: the same iterates to <= 1e-10 relative (all-reduce order aside), at the
     headline size: two landmark shards of C3 (500k observations each) against the single-rank run, four LM
     iterations with a tight PCG so that re-ordered sums are all that differs."""
     from bundle_adjustment_amd import hip_backend
     from bundle_adjustment_amd.problem import shard_by_landmark
     from bundle_adjustment_amd.synthetic import make_config
-    outs = _run_two_ranks(tmp_path, "c3")
+    outs = _run_two_ranks(tmp_path, "c3", ipc)                # (ipc = 1: the per-PCG-iteration exchange through IPC-mapped peer buffers)
     p = make_config("C3", seed=0)
     with hip_backend.Solver(0) as s:
         s.set_problem(p)
