@@ -204,6 +204,8 @@ struct ba_handle {
   int mw_resident[3] = {-1, -1, -1};   // workgroups of k_small_mw<2 / 3 / 4> the device holds at once (occupancy query, once per handle)
   long long stats[BA_STAT_COUNT] = {0};   // ba_get_stat
   DBuf<int> setup_i;                      // scratch of the device build of ba_set_problem (ba_setup.hpp)
+  DBuf<char> up_dev;                      // device copy of the pinned upload arena of a window-sized problem (k_unpack_problem)
+  hipEvent_t up_event = nullptr; bool up_pending = false;   // ... and its last copy (ba_set_problem returns without waiting for it)
   char* h_setup = nullptr;                // pinned: what that build reads back (track-length histogram, statistics, windows)
   int setup_path = 0;                     // how the current problem's layout was built: 0 host, 1 device
   DBuf<double> stat2;                     // multi-rank: the band statistic (span sum, tracks) summed over the shards
@@ -387,6 +389,8 @@ extern "C" int ba_destroy(ba_handle* h) {
   h->mw_woff.release(); h->mw_buf.release();
   if (h->h_par) { (void)hipStreamSynchronize(h->stream); (void)hipHostFree(h->h_par); h->h_par = nullptr; h->h_par_cap = 0; }
   if (h->par_event) { (void)hipEventDestroy(h->par_event); h->par_event = nullptr; }
+  if (h->up_event) { (void)hipEventDestroy(h->up_event); h->up_event = nullptr; }
+  h->up_pending = false;
   h->par_pending = false;
   h->intr[0].release(); h->intr[1].release();
   h->small_gS.release();
@@ -402,6 +406,7 @@ extern "C" int ba_destroy(ba_handle* h) {
   if (h->h_up) (void)hipHostFree(h->h_up);
   if (h->h_setup) (void)hipHostFree(h->h_setup);
   h->setup_i.release();
+  h->up_dev.release();
   h->stat2.release();
   if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1318,21 +1323,34 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   size_t up_used = 0;
   const size_t up_need = ((size_t)No * (4 * 4 + 16) + (size_t)Np * 12 + (size_t)Nc * 40 + win.size() * 8 + 4096) * 1;
   const bool staged = up_need <= ((size_t)4 << 20);
+  if (h->up_pending) { (void)hipEventSynchronize(h->up_event); h->up_pending = false; }      // the arena's last upload has landed
   if (staged && h->h_up_cap < up_need) {       // grow-only, with headroom: consecutive windows differ a little in size
     if (h->h_up) { (void)hipHostFree(h->h_up); h->h_up = nullptr; h->h_up_cap = 0; }
     const size_t cap = std::min<size_t>((size_t)4 << 20, std::max<size_t>(2 * up_need, (size_t)256 << 10));
     HIPCHECK(hipHostMalloc((void**)&h->h_up, cap, hipHostMallocDefault));
     h->h_up_cap = cap;
   }
+  // (staged: the sections are only collected here; ONE copy of the arena and ONE kernel deal them out at the end)
+  UnpackArgs ua;
+  memset(&ua, 0, sizeof ua);
   auto upload = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
     if (bytes == 0) return hipSuccess;
-    if (staged && up_used + bytes <= h->h_up_cap) {
+    if (staged && up_used + bytes <= h->h_up_cap && ua.n_sections < UNPACK_MAX_SECTIONS && bytes % 4 == 0) {
       memcpy(h->h_up + up_used, src, bytes);
-      const hipError_t e = hipMemcpyAsync(dst, h->h_up + up_used, bytes, hipMemcpyHostToDevice, h->stream);
+      ua.off[ua.n_sections] = up_used; ua.dst[ua.n_sections] = (int*)dst; ua.words[ua.n_sections] = (int)(bytes / 4);
+      ++ua.n_sections;
       up_used += (bytes + 63) & ~(size_t)63;
-      return e;
+      return hipSuccess;
     }
     return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream);
+  };
+  // a section that only the unpack kernel reads (no array of its own): returns its arena offset, or (size_t)-1
+  auto stash = [&](const void* src, size_t bytes) -> size_t {
+    if (!(staged && up_used + bytes <= h->h_up_cap)) return (size_t)-1;
+    memcpy(h->h_up + up_used, src, bytes);
+    const size_t o = up_used;
+    up_used += (bytes + 63) & ~(size_t)63;
+    return o;
   };
   HIPCHECK(h->offk.alloc((size_t)Nc * (NPART + 1))); HIPCHECK(h->pt_off.alloc(Np + 1));
   HIPCHECK(h->slot.alloc(np1));
@@ -1395,7 +1413,33 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   stage("allocations");
   HIPCHECK(upload(h->offk.p, offk.data(), offk.size() * sizeof(int)));
   HIPCHECK(upload(h->pt_off.p, pt_off.data(), (Np + 1) * sizeof(int)));
-  if (No > 0) {
+  bool packed = false;         // the window-sized form: everything through the arena and k_unpack_problem
+  if (No > 0 && staged) {
+    const int s_cpt = ua.n_sections;
+    HIPCHECK(upload(h->c_pt.p, c_pt.data(), No * sizeof(int)));
+    const int s_corig = ua.n_sections;
+    HIPCHECK(upload(h->c_orig.p, c_orig.data(), No * sizeof(int)));
+    const int s_pcam = ua.n_sections;
+    HIPCHECK(upload(h->p_cam.p, p_cam.data(), No * sizeof(int)));
+    const size_t o_uv = stash(uv, 2 * (size_t)No * sizeof(double)), o_psrc = stash(p_src.data(), No * sizeof(int));
+    if (ua.n_sections == s_pcam + 1 && s_pcam == s_corig + 1 && s_corig == s_cpt + 1 && o_uv != (size_t)-1 && o_psrc != (size_t)-1) {
+      ua.n_obs = No; ua.off_uv = o_uv; ua.off_psrc = o_psrc;
+      ua.off_cpt = ua.off[s_cpt]; ua.off_corig = ua.off[s_corig]; ua.off_pcam = ua.off[s_pcam];
+      ua.p_uv = h->p_uv.p; ua.c_uv = h->c_uv.p;
+      ua.c_ptf0 = h->c_ptf[0].p; ua.c_ptf1 = h->c_ptf[1].p; ua.p_camf0 = h->p_camf[0].p; ua.p_camf1 = h->p_camf[1].p;
+      packed = true;
+    } else {
+      return fail(BA_ERR_STATE, "ba_set_problem: the staging arena was sized too small (internal)");
+    }
+  }
+  if (ua.n_sections > 0) {     // the arena's one copy and the one kernel that deals it out
+    HIPCHECK(h->up_dev.alloc(up_used));
+    HIPCHECK(hipMemcpyAsync(h->up_dev.p, h->h_up, up_used, hipMemcpyHostToDevice, h->stream));
+    ua.arena = h->up_dev.p;
+    const int nthreads = std::max(No, 4096);
+    BA_LAUNCH(k_unpack_problem, dim3((nthreads + 255) / 256), dim3(256), 0, h->stream, ua);
+  }
+  if (No > 0 && !packed) {
     HIPCHECK(upload(h->c_pt.p, c_pt.data(), No * sizeof(int)));
     HIPCHECK(upload(h->c_orig.p, c_orig.data(), No * sizeof(int)));
     HIPCHECK(upload(h->p_cam.p, p_cam.data(), No * sizeof(int)));
@@ -1412,7 +1456,17 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     BA_LAUNCH(k_init_flagged, gg, gb, 0, h->stream, (const int*)h->c_pt.p, (const int*)h->p_cam.p, No, h->c_ptf[0].p, h->c_ptf[1].p,
               h->p_camf[0].p, h->p_camf[1].p);
   }
-  BA_SYNC(h);   // host vectors go out of scope
+  if (packed || (staged && No == 0 && ua.n_sections > 0)) {
+    // everything the device still reads sits in the pinned arena (the host vectors were copied into it): no need to wait
+    // for the copy and the kernel -- whatever comes next is ordered behind them on the stream; the arena's next use
+    // (the next ba_set_problem) waits for this event first
+    if (!h->up_event) HIPCHECK(hipEventCreateWithFlags(&h->up_event, hipEventDisableTiming));
+    HIPCHECK(hipEventRecord(h->up_event, h->stream));
+    h->up_pending = true;
+    if (int rc = check_launches(h)) return rc;
+  } else {
+    BA_SYNC(h);   // host vectors go out of scope
+  }
   stage("upload");
   h->have_problem = true;
   h->have_params = false;

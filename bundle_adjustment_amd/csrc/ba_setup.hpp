@@ -307,6 +307,47 @@ k_setup_windows(const int* __restrict__ pt_off, const int* __restrict__ p_cam, i
     win[b] = make_int2(l, h2 - l + 1);
   }
 }
+// ---- window-sized problems (host build): ONE upload, ONE kernel --------------------------------------------------------
+// The host build of a sliding window (the reference's own use, src/pipeline.py:99: a few thousand observations) ships a
+// dozen small arrays; as separate copies each is a DMA packet of its own and the three kernels behind them three more
+// launches -- more device time than the window's solve.  They travel as ONE pinned arena and ONE copy instead, and this
+// kernel deals the sections to their arrays and does what k_gather_uv (x 2) and k_init_flagged did, reading the arena.
+constexpr int UNPACK_MAX_SECTIONS = 12;
+struct UnpackArgs {
+  const char* arena;                       // device copy of the pinned arena
+  int n_sections;
+  size_t off[UNPACK_MAX_SECTIONS];         // byte offset of a section in the arena (64-byte aligned)
+  int* dst[UNPACK_MAX_SECTIONS];           // its array
+  int words[UNPACK_MAX_SECTIONS];          // its length in 4-byte words
+  // pixels and flagged index copies (n_obs > 0): offsets of uv (double2[n_obs], caller's order), p_src, c_orig, c_pt, p_cam
+  int n_obs;
+  size_t off_uv, off_psrc, off_corig, off_cpt, off_pcam;
+  double2 *p_uv, *c_uv;
+  int *c_ptf0, *c_ptf1, *p_camf0, *p_camf1;
+};
+__global__ void __launch_bounds__(256)
+k_unpack_problem(UnpackArgs a) {
+  const int stride = gridDim.x * 256;
+  const int t0 = blockIdx.x * 256 + threadIdx.x;
+  for (int sct = 0; sct < a.n_sections; ++sct) {
+    const int* src = (const int*)(a.arena + a.off[sct]);
+    for (int i = t0; i < a.words[sct]; i += stride) a.dst[sct][i] = src[i];
+  }
+  if (a.n_obs > 0) {
+    const double2* uv = (const double2*)(a.arena + a.off_uv);
+    const int* psrc = (const int*)(a.arena + a.off_psrc);
+    const int* corig = (const int*)(a.arena + a.off_corig);
+    const int* cpt = (const int*)(a.arena + a.off_cpt);
+    const int* pcam = (const int*)(a.arena + a.off_pcam);
+    for (int j = t0; j < a.n_obs; j += stride) {
+      a.p_uv[j] = uv[psrc[j]];
+      a.c_uv[j] = uv[corig[j]];
+      const int x = cpt[j], y = pcam[j];
+      a.c_ptf0[j] = x; a.c_ptf1[j] = x; a.p_camf0[j] = y; a.p_camf1[j] = y;
+    }
+  }
+}
+
 // slot[p] = p (the caller's numbering is kept when the whole camera table fits in LDS)
 __global__ void __launch_bounds__(256)
 k_setup_iota(int* __restrict__ a, int n) {
