@@ -1278,7 +1278,12 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
         const int cc = ROBUST ? (c & IDX_MASK) : c;
         if (cc != fixed_cam) {
           double rowd[CM::SCH_ROW];
+#ifdef BA_EXP_NOCONFLICT
+          // diagnostic build only (wrong results): every 16 consecutive lanes read rows of 16 distinct bank classes
+          load_cam_row<CM::SCH_ROW, CM::TA>(use_lds, tab, camA, win.x, win.x + (int)(threadIdx.x & 15) + 16 * (cc & 31), rowd);
+#else
           load_cam_row<CM::SCH_ROW, CM::TA>(use_lds, tab, camA, win.x, cc, rowd);
+#endif
           JT row[CM::SCH_ROW];                   // Jacobian blocks in JT (double, or float for config 5)
 #pragma unroll
           for (int q = 0; q < CM::SCH_ROW; ++q) row[q] = (JT)rowd[q];

@@ -188,7 +188,7 @@ k_setup_bank_order(const int* __restrict__ pt_off, int n_pts, int nblk, int ppb,
   const int p0 = min(n_pts, b * ppb), p1 = min(n_pts, (b + 1) * ppb);
   const int c0 = p0 + 16 * chunk;
   if (c0 >= p1) return;
-  const int group_of_pair[16] = {0, 0, 1, 1, 1, 1, 0, 0, 1, 1, 0, 0, 0, 0, 1, 1};
+  const int group_of_pair[16] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1};
   int pts[8], npts = 0;
   for (int q = 0; q < 16 && c0 + q < p1; ++q)
     if (group_of_pair[q] == g) pts[npts++] = c0 + q;
