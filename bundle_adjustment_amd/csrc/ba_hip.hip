@@ -61,7 +61,7 @@ extern "C" const char* ba_last_error(void) { return g_err.c_str(); }
 
 static const char* kKernelNames[BA_PROFILE_SLOTS] = {
     "cam_prepare", "residual_cam", "linearize_cam", "linearize_pt", "point_invert", "schur_pt",
-    "schur_cam", "pcg_step", "precond", "backsub_pt", "misc", "allreduce", "", "", "", ""};
+    "schur_cam", "pcg_step", "precond", "backsub_pt", "misc", "allreduce", "schur_pt_then_backsub", "", "", ""};
 extern "C" const char* ba_kernel_name(int slot) {
   return (slot >= 0 && slot < BA_PROFILE_SLOTS) ? kKernelNames[slot] : "";
 }
@@ -2561,7 +2561,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
         pcg_done_iters = (int)payload - 1;
         if (fuse) {                   // the launch that published this verdict is doing the back substitution
           backsub_done = true;
-          if (h->profile && probe_flushes == h->n_flushes && probe_ev < h->ev_slot.size()) h->ev_slot[probe_ev] = BA_K_BACKSUB;
+          if (h->profile && probe_flushes == h->n_flushes && probe_ev < h->ev_slot.size()) h->ev_slot[probe_ev] = BA_K_SCHUR_PT_BACKSUB;
         }
         break;
       }

@@ -143,7 +143,8 @@ typedef struct ba_profile {
 enum ba_kernel_slot {
   BA_K_CAM_PREPARE = 0, BA_K_RESIDUAL = 1, BA_K_LINEARIZE_CAM = 2, BA_K_LINEARIZE_PT = 3,
   BA_K_POINT_INVERT = 4, BA_K_SCHUR_PT = 5, BA_K_SCHUR_CAM = 6, BA_K_PCG_UPDATE = 7,
-  BA_K_PRECOND = 8, BA_K_BACKSUB = 9, BA_K_MISC = 10, BA_K_ALLREDUCE = 11
+  BA_K_PRECOND = 8, BA_K_BACKSUB = 9, BA_K_MISC = 10, BA_K_ALLREDUCE = 11,
+  BA_K_SCHUR_PT_BACKSUB = 12   /* launches of the PCG point pass that found PCG finished and went on as the back substitution */
 };
 
 /* Event counters of a handle (ba_get_stat): which implementation served the window-sized solves, how often the
