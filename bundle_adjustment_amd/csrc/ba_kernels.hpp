@@ -1360,8 +1360,8 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
 // The workgroups in front of the point workgroups of a back-substitution launch (MODE 1), or of a PCG point pass that may
 // turn into one (MODE 0, cu.fuse): the camera update (riders).  True: this workgroup was a rider and is done.
 //   MODE 1: workgroup 0 also clears the riding verdict's damping word (ScalarsArgs::lam_slot).
-//   MODE 0: wave 0 runs the PCG probe like every point workgroup (workgroup 0, now a rider, is the one that publishes the
-//           verdict); the camera update runs only in the launch that finds PCG finished -- together with the cleared word.
+//   MODE 0: wave 0 runs the PCG probe like every point workgroup; the camera update runs only in the launch that finds PCG
+//           finished -- together with the cleared word.
 template <class CM, int MODE>
 __device__ __forceinline__ bool
 pt_schur_rider(int n_rider, int kit, const PcgState* __restrict__ st, const double* __restrict__ partV, int nblkV, double tol2,
@@ -1369,7 +1369,11 @@ pt_schur_rider(int n_rider, int kit, const PcgState* __restrict__ st, const doub
                const double* __restrict__ partG, int nG, const double* __restrict__ partGc, int nGc, double* __restrict__ gmax_out,
                const CamUpdateArgs& cu) {
   if (MODE == 1 && blockIdx.x == 0 && threadIdx.x == 0 && cu.lam_slot) cu.lam_slot[0] = 0.0;
-  if ((int)blockIdx.x >= n_rider) return false;
+  // MODE 1: the riders are the FIRST workgroups of the launch.  MODE 0 (a PCG point pass that may go on as the back
+  // substitution): the LAST ones -- in all but one launch per LM iteration they only probe and leave, and at the front they
+  // held the point workgroups' dispatch back (0.6 us per launch); workgroup 0, a point workgroup again, publishes the verdict
+  const int ridx = (MODE == 0) ? (int)blockIdx.x - ((int)gridDim.x - n_rider) : (int)blockIdx.x;
+  if (ridx < 0 || ridx >= n_rider) return false;
   extern __shared__ __align__(16) double tab[];
   if (MODE == 0) {
     __shared__ int r_fin;
@@ -1379,18 +1383,18 @@ pt_schur_rider(int n_rider, int kit, const PcgState* __restrict__ st, const doub
     }
     __syncthreads();
     if (!r_fin) return true;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && cu.lam_slot) cu.lam_slot[0] = 0.0;
+    if (ridx == 0 && threadIdx.x == 0 && cu.lam_slot) cu.lam_slot[0] = 0.0;
   }
-  cam_update_rider<CM>(cu, blockIdx.x, tab);
+  cam_update_rider<CM>(cu, ridx, tab);
   return true;
 }
 template <class CM, bool ROBUST, int MODE, bool ALL_LDS, int LANES, typename JT>
 __global__ void __launch_bounds__(PT_THREADS)
 k_pt_schur(BA_SCH_PARAMS, PtWork wk, BA_SCH_TAIL) {
-  const int n_rider = (MODE == 1 || cu.fuse) ? cu.n_blocks : 0;           // the camera update's workgroups: the FIRST ones of the launch
+  const int n_rider = (MODE == 1 || cu.fuse) ? cu.n_blocks : 0;           // the camera update's workgroups (pt_schur_rider: where they sit)
   if (pt_schur_rider<CM, MODE>(n_rider, BA_SCH_RIDER_ARGS)) return;
-  pt_schur_body<CM, ROBUST, MODE, ALL_LDS, LANES, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk, (int)blockIdx.x - n_rider,
-                                                  (int)gridDim.x - n_rider, BA_SCH_TAIL_ARGS);
+  pt_schur_body<CM, ROBUST, MODE, ALL_LDS, LANES, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk,
+                                                  (int)blockIdx.x - (MODE == 1 ? n_rider : 0), (int)gridDim.x - n_rider, BA_SCH_TAIL_ARGS);
 }
 // short and long tracks in one launch (see k_pt_linearize_both)
 template <class CM, bool ROBUST, int MODE, bool ALL_LDS, typename JT>
@@ -1398,7 +1402,7 @@ __global__ void __launch_bounds__(PT_THREADS)
 k_pt_schur_both(BA_SCH_PARAMS, PtWork wk, int nblk_short, PtWork wl, BA_SCH_TAIL) {
   const int n_rider = (MODE == 1 || cu.fuse) ? cu.n_blocks : 0;
   if (pt_schur_rider<CM, MODE>(n_rider, BA_SCH_RIDER_ARGS)) return;
-  const int bid = (int)blockIdx.x - n_rider;
+  const int bid = (int)blockIdx.x - (MODE == 1 ? n_rider : 0);
   if (bid < nblk_short)
     pt_schur_body<CM, ROBUST, MODE, ALL_LDS, LPP, JT>(camA, ptab, pt_off, p_cam, p_w, Hppinv, blk_win, wk, bid, nblk_short,
                                                   BA_SCH_TAIL_ARGS);
