@@ -169,6 +169,7 @@ struct ba_handle {
   int n_long = 0, nblkL = 0;   // points with more than LONG_TRACK observations: one DPP row each, own launch
   int long_spb = PT_THREADS / LPP_LONG;   // long-track points per workgroup (a multiple of one round's 64)
   DBuf<int2> blk_win;          // per point-pass workgroup: first camera and number of cameras its points see
+  bool uv_f32 = false;         // c_uv / p_uv hold float2 (every pixel of the problem is a float32 value: UvArr, ba_kernels.hpp)
   DBuf<double2> c_uv, p_uv, c_w[2], p_w[2];   // both halves of the linearisation are double-buffered: the next one is
                                               // computed speculatively at the trial point while the host decides
                                               // (camera half: c_w, c_ptf, partL [lb]; point half: p_w, p_camf, Hpp, bp, Hppinv, y0 [pb])
@@ -857,6 +858,12 @@ static int alloc_solver_buffers(ba_handle* h) {
 // point numbering is kept then); bit-equal to the host build (tests/test_gpu_setup.py).
 constexpr int SETUP_HIST_BINS = 4096;
 constexpr size_t SETUP_PINNED_BYTES = 128 * 1024;
+// BA_PIXELS=f64 keeps the pixel streams double2 whatever the values (A / B measurements, tests)
+static bool uv_f32_wanted() {
+  const char* e = getenv("BA_PIXELS");
+  return !(e && strcmp(e, "f64") == 0);
+}
+static inline UvArr uv_arr(const ba_handle* h, const DBuf<double2>& b) { return UvArr{b.p, h->uv_f32 ? 1 : 0}; }
 static int dev_scan(ba_handle* h, const int* in, int n, int* bsum, int* out) {
   const int nb = (n + SETUP_SCAN_BLOCK - 1) / SETUP_SCAN_BLOCK;
   BA_LAUNCH(k_scan_block_sums, dim3(nb), dim3(1024), 0, h->stream, in, n, bsum);
@@ -903,7 +910,9 @@ static int set_problem_device(ba_handle* h, int Nc, int Np, int No, const int32_
   HIPCHECK(hipMemsetAsync(S + o_words, 0x7f, sizeof(int), h->stream));                   // bad = 0x7f7f7f7f: "none"
   stage("upload");
   const dim3 go((No + 255) / 256), gp((Np + 255) / 256), b256(256);
-  BA_LAUNCH(k_setup_hist, go, b256, 0, h->stream, (const int*)d_cam, (const int*)d_pt, No, Nc, Np, S + o_cnt, S + o_words);
+  // (words: 0 first bad observation, 1 tracks, 2 big points, 3 "some pixel is not a float32 value")
+  BA_LAUNCH(k_setup_hist, go, b256, 0, h->stream, (const int*)d_cam, (const int*)d_pt, No, Nc, Np, S + o_cnt, S + o_words,
+            (uv_f32_wanted() && Nc > SMALL_MAX_CAMS) ? (const double2*)h->rbuf.p : (const double2*)nullptr, S + o_words + 3);
   dev_scan(h, S + o_cnt, Np, S + o_bsum, h->pt_off.p);
   BA_LAUNCH(k_setup_scatter_pt, go, b256, 0, h->stream, (const int*)d_pt, No, (const int*)h->pt_off.p, S + o_fill, seg);
   BA_LAUNCH(k_setup_sort_pt, gp, b256, 0, h->stream, (const int*)h->pt_off.p, Np, (const int*)seg, (const int*)d_cam, p_src, h->p_cam.p, p_pt,
@@ -921,6 +930,7 @@ static int set_problem_device(ba_handle* h, int Nc, int Np, int No, const int32_
     if (cam_idx[bad] < 0 || cam_idx[bad] >= Nc) return fail(BA_ERR_INVALID, "cam_idx[%lld]=%d out of range", (long long)bad, cam_idx[bad]);
     return fail(BA_ERR_INVALID, "pt_idx[%lld]=%d out of range", (long long)bad, pt_idx[bad]);
   }
+  h->uv_f32 = uv_f32_wanted() && Nc > SMALL_MAX_CAMS && hh[SETUP_HIST_BINS + 3] == 0;
   unsigned long long span_sum;
   memcpy(&span_sum, hh + SETUP_HIST_BINS + 16, sizeof span_sum);
   // median track length = element Np / 2 of the sorted lengths
@@ -968,8 +978,8 @@ static int set_problem_device(ba_handle* h, int Nc, int Np, int No, const int32_
   HIPCHECK(hipMemcpyAsync(h->h_setup, u64 + 1, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipMemcpyAsync(h->h_setup + 64, h->blk_win.p, (size_t)nwin * sizeof(int2), hipMemcpyDeviceToHost, h->stream));
   // pixels into both orderings, flagged index copies, identity point numbering
-  BA_LAUNCH(k_gather_uv, go, b256, 0, h->stream, (const double2*)h->rbuf.p, (const int*)p_src, No, h->p_uv.p);
-  BA_LAUNCH(k_gather_uv, go, b256, 0, h->stream, (const double2*)h->rbuf.p, (const int*)h->c_orig.p, No, h->c_uv.p);
+  BA_LAUNCH(k_gather_uv, go, b256, 0, h->stream, (const double2*)h->rbuf.p, (const int*)p_src, No, h->p_uv.p, (int)h->uv_f32);
+  BA_LAUNCH(k_gather_uv, go, b256, 0, h->stream, (const double2*)h->rbuf.p, (const int*)h->c_orig.p, No, h->c_uv.p, (int)h->uv_f32);
   BA_LAUNCH(k_init_flagged, go, b256, 0, h->stream, (const int*)h->c_pt.p, (const int*)h->p_cam.p, No, h->c_ptf[0].p, h->c_ptf[1].p,
             h->p_camf[0].p, h->p_camf[1].p);
   BA_LAUNCH(k_setup_iota, gp, b256, 0, h->stream, h->slot.p, Np);
@@ -1027,6 +1037,9 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   }
   if ((n_cams + VEC_CAMS - 1) / VEC_CAMS > 16384) return fail(BA_ERR_INVALID, "more than %d cameras are not supported", 16384 * VEC_CAMS);
   stage("validate");
+  // float2 pixel streams (UvArr): only problems the window solvers never take (they read double2), and only when every
+  // pixel is a float32 value; the device build looks for itself (k_setup_hist), the host build sweeps them below
+  const bool uv_f32_eligible = uv_f32_wanted() && n_cams > SMALL_MAX_CAMS && n_obs > 0;
   if (set_device(h)) return BA_ERR_HIP;
   // From here on the previous problem is gone: should anything below fail (allocation, copy), the handle is left
   // WITHOUT a problem rather than with new sizes over old buffers.
@@ -1035,6 +1048,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   h->linearized = false;
   h->setup_path = 0;
   h->banded_known = false;
+  h->uv_f32 = false;
   // Large problems whose camera table fits in LDS are laid out ON THE DEVICE (set_problem_device, ba_setup.hpp: one upload
   // of the caller's arrays, no host sorts; bit-equal result).  BA_SETUP=host / device forces a path (device: whenever the
   // problem qualifies at all), BA_SETUP_DEVICE_MIN moves the size from which it is chosen.
@@ -1063,6 +1077,12 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   // columns of the previous one -> V is cleared again before its next use
   h->small_np_pad = -1;
   const int Nc = n_cams, Np = n_pts, No = (int)n_obs;
+  if (uv_f32_eligible) {       // every pixel a float32 value?  (branch-free sweep; NaN compares unequal: stays double)
+    int all = 1;
+    for (int64_t i = 0; i < 2 * n_obs; ++i) all &= (int)((double)(float)uv[i] == uv[i]);
+    h->uv_f32 = all != 0;
+    stage("pixel value sweep");
+  }
   // internal point numbering.  When the whole camera table fits in LDS nothing is gained by
   // moving points, so the caller's order is kept.  Otherwise points are sorted by the mean index of
   // the cameras that observe them: consecutive points are then seen from a narrow window of cameras
@@ -1428,7 +1448,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     if (ua.n_sections == s_pcam + 1 && s_pcam == s_corig + 1 && s_corig == s_cpt + 1 && o_uv != (size_t)-1 && o_psrc != (size_t)-1) {
       ua.n_obs = No; ua.off_uv = o_uv; ua.off_psrc = o_psrc;
       ua.off_cpt = ua.off[s_cpt]; ua.off_corig = ua.off[s_corig]; ua.off_pcam = ua.off[s_pcam];
-      ua.p_uv = h->p_uv.p; ua.c_uv = h->c_uv.p;
+      ua.p_uv = h->p_uv.p; ua.c_uv = h->c_uv.p; ua.uv_f32 = h->uv_f32 ? 1 : 0;
       ua.c_ptf0 = h->c_ptf[0].p; ua.c_ptf1 = h->c_ptf[1].p; ua.p_camf0 = h->p_camf[0].p; ua.p_camf1 = h->p_camf[1].p;
       packed = true;
     } else {
@@ -1452,8 +1472,8 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     HIPCHECK(upload(h->rbuf.p, uv, 2 * (size_t)No * sizeof(double)));
     HIPCHECK(upload(h->c_ptf[0].p, p_src.data(), No * sizeof(int)));
     const dim3 gg((No + 255) / 256), gb(256);
-    BA_LAUNCH(k_gather_uv, gg, gb, 0, h->stream, (const double2*)h->rbuf.p, (const int*)h->c_ptf[0].p, No, h->p_uv.p);
-    BA_LAUNCH(k_gather_uv, gg, gb, 0, h->stream, (const double2*)h->rbuf.p, (const int*)h->c_orig.p, No, h->c_uv.p);
+    BA_LAUNCH(k_gather_uv, gg, gb, 0, h->stream, (const double2*)h->rbuf.p, (const int*)h->c_ptf[0].p, No, h->p_uv.p, (int)h->uv_f32);
+    BA_LAUNCH(k_gather_uv, gg, gb, 0, h->stream, (const double2*)h->rbuf.p, (const int*)h->c_orig.p, No, h->c_uv.p, (int)h->uv_f32);
     // the flagged copies of the index streams start as the plain streams: a robust linearisation reads them and stores
     // an entry only where its "weights are not (1, 1)" flag changes
     BA_LAUNCH(k_init_flagged, gg, gb, 0, h->stream, (const int*)h->c_pt.p, (const int*)h->p_cam.p, No, h->c_ptf[0].p, h->c_ptf[1].p,
@@ -1605,12 +1625,12 @@ static void launch_residual(ba_handle* h, int which, bool robust, double fscale,
   if (h->model) {
     auto kern = robust ? k_cam_residual_bal<true> : k_cam_residual_bal<false>;
     BA_LAUNCH(kern, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[which].p, (const double*)h->intr[which].p, h->ptab[which].p,
-              h->offk.p, h->c_pt.p, h->c_uv.p, h->c_orig.p, fscale, h->Nc, h->cam_band, r_out, h->partR.p);
+              h->offk.p, h->c_pt.p, uv_arr(h, h->c_uv), h->c_orig.p, fscale, h->Nc, h->cam_band, r_out, h->partR.p);
     return;
   }
   auto kern = robust ? k_cam_residual<true> : k_cam_residual<false>;
   BA_LAUNCH(kern, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[which].p, h->ptab[which].p, h->offk.p,
-                     h->c_pt.p, h->c_uv.p, h->c_orig.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, h->cam_band, r_out,
+                     h->c_pt.p, uv_arr(h, h->c_uv), h->c_orig.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc, h->cam_band, r_out,
                      h->partR.p);
 }
 // fold the partial arrays of a step into `scal` (residual always; point / camera parts optional)
@@ -1672,7 +1692,7 @@ static void launch_lin_cam_t(ba_handle* h, int which, int buf, bool robust, doub
   auto kern = robust ? (cost ? k_camrow_linearize<CM, true, true> : k_camrow_linearize<CM, true, false>)
                      : (cost ? k_camrow_linearize<CM, false, true> : k_camrow_linearize<CM, false, false>);
   BA_LAUNCH(kern, dim3(row_grid(h)), dim3(ROW_LANES * ROWS), 0, h->stream, h->cs[which].p, (const double*)h->intr[which].p,
-                     h->ptab[which].p, h->offk.p, h->c_pt.p, h->c_uv.p, h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc,
+                     h->ptab[which].p, h->offk.p, h->c_pt.p, uv_arr(h, h->c_uv), h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, h->Nc,
                      h->cam_band, h->c_w[buf].p, h->c_ptf[buf].p, h->partL[buf].p, h->partR.p);
 }
 static void launch_lin_cam(ba_handle* h, int which, int buf, bool robust, double fscale, bool cost = false) {
@@ -1698,7 +1718,7 @@ template <class CM>
 static void launch_lin_pt_t(ba_handle* h, int w, int pbuf, bool robust, double fscale, double lambda, const double* lam_dev,
                             const ScalarsArgs& sa) {
   const int ride = sa.on * NPART;                      // the step's scalar fold + verdict as workgroup 0 of this launch (+ NPART - 1 idle ones)
-#define LP_HEAD h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, h->p_uv.p, h->blk_win.p
+#define LP_HEAD h->camA[w].p, h->ptab[w].p, h->pt_off.p, h->p_cam.p, uv_arr(h, h->p_uv), h->blk_win.p
 #define LP_TAIL h->K4[0], h->K4[1], h->K4[2], h->K4[3], fscale, lambda, lam_dev, h->Hpp[pbuf].p, h->bp[pbuf].p, h->p_w[pbuf].p,      \
                 h->p_camf[pbuf].p, h->Hppinv[pbuf].p, h->y0[pbuf].p, h->partG[pbuf].p, sa
 #define LP_LAUNCH(R, L, LN, G, WK) BA_LAUNCH((k_pt_linearize<CM, R, L, LN>), dim3((G) + ride), dim3(PT_THREADS), lds_of(h), h->stream, LP_HEAD, WK, LP_TAIL)
@@ -1808,7 +1828,7 @@ static void launch_pt_schur_t(ba_handle* h, bool robust, int mode, int k, double
 #define PS_TAIL h->K4[0], h->K4[1], h->fixed, h->partA.p, k, h->st.p, h->partV.p, nbv(h), tol2, min_iters, h->y0[h->pb].p,     \
                 h->Hpp[h->pb].p, h->bp[h->pb].p, h->ptab[1 - w].p, h->partB.p, flag, flag_base, h->verdict.p,                      \
                 gmax_parts(h), gmax_count(h), (const double*)h->partGc.p, nbv(h), gmax_out, cu
-  const size_t lds = std::max(lds_of(h), ride ? CU_GROUPS * cam_update_lds_doubles<CM>() * sizeof(double) : (size_t)0) + (size_t)h->debug_lds_extra;
+  const size_t lds = std::max(lds_of(h), ride ? cu.groups * cam_update_lds_doubles<CM>() * sizeof(double) : (size_t)0) + (size_t)h->debug_lds_extra;
   long long* flag = (mode == 0 && flag_base > 0) ? h->d_flags : (long long*)nullptr;
   // data with long tracks: short and long tracks in one launch (workgroup 0 publishes the verdict)
 #define PS_ONE(R, M, L, LN, JT) \
@@ -1967,7 +1987,7 @@ extern "C" int ba_residuals_bal(ba_handle* h, const double* intr, int32_t loss, 
     Scope sc(h, BA_K_RESIDUAL);
     auto kern = loss == BA_LOSS_HUBER ? k_cam_residual_bal<true> : k_cam_residual_bal<false>;
     BA_LAUNCH(kern, dim3(cam_grid(h)), dim3(64 * WPB), 0, h->stream, h->cs[h->cur].p, (const double*)h->tri.p, h->ptab[h->cur].p,
-              h->offk.p, h->c_pt.p, h->c_uv.p, h->c_orig.p, f_scale, h->Nc, h->cam_band, rdev, h->partR.p);
+              h->offk.p, h->c_pt.p, uv_arr(h, h->c_uv), h->c_orig.p, f_scale, h->Nc, h->cam_band, rdev, h->partR.p);
   }
   launch_scalars(h, false);
   if (int rc = allreduce(h, h->scal.p, 2)) return rc;
@@ -2418,6 +2438,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
   // have been kept since, and what the inner solves cost with them.  Host-side and deterministic: the rule reads options,
   // dampings and PCG iteration counts only (identical on every rank of a multi-rank job).
   const bool cap_floor = getenv("BA_NO_CAP_FLOOR") == nullptr;      // (switch for A / B measurements)
+  const int cu_groups = getenv("BA_CU_GROUPS") ? std::min(8, std::max(1, atoi(getenv("BA_CU_GROUPS")))) : CU_GROUPS;
   double lam_floor = 0.0;
   bool have_precond = false;
   double lam_built = 0.0;
@@ -2485,7 +2506,8 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     cu.vx = h->vx.p;
     cu.lam_slot = h->dev_lam.p;
     // (riding workgroups: a multiple of NPART, so that the point workgroups behind them keep their XCD = index mod NPART)
-    cu.n_cams = Nc; cu.fixed_cam = h->fixed; cu.n_blocks = (((nbv(h) + CU_GROUPS - 1) / CU_GROUPS + NPART - 1) / NPART) * NPART;
+    cu.n_cams = Nc; cu.fixed_cam = h->fixed; cu.groups = cu_groups;
+    cu.n_blocks = (((nbv(h) + cu.groups - 1) / cu.groups + NPART - 1) / NPART) * NPART;
     const bool ride = (riders & 1) && all_lds_of(h) && h->Np > 0;
     // The probe that finds PCG finished goes on as the back substitution (pt_schur_body, cu.fuse): riders in front of
     // every PCG point pass, so only while everything is still resident at once; fp64 blocks only (the back substitution
@@ -2688,7 +2710,7 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
 // ------------------------------------------------------------------ counters, test hooks
 extern "C" int ba_get_stat(ba_handle* h, int32_t which, int64_t* value) {
   if (!h || !value || which < 0 || which >= BA_STAT_COUNT) return fail(BA_ERR_INVALID, "bad argument");
-  *value = (int64_t)h->stats[which];
+  *value = which == BA_STAT_PIXELS_F32 ? (int64_t)(h->have_problem && h->uv_f32) : (int64_t)h->stats[which];
   return BA_OK;
 }
 // Test hook: the layout ba_set_problem built, copied to the host (tests compare the device build with the host build).
@@ -2725,6 +2747,14 @@ extern "C" int ba_debug_layout(ba_handle* h, int32_t which, void* out, int64_t c
     default: return fail(BA_ERR_INVALID, "unknown layout array %d", which);
   }
   if (capacity < cnt) return fail(BA_ERR_INVALID, "capacity %lld < %lld", (long long)capacity, (long long)cnt);
+  if ((which == 9 || which == 10) && h->uv_f32) {          // float2 streams: widened here, the caller sees the doubles it gave
+    std::vector<float> tmp((size_t)cnt);
+    if (cnt > 0) HIPCHECK(hipMemcpyAsync(tmp.data(), src, (size_t)cnt * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    BA_SYNC(h);
+    for (int64_t i = 0; i < cnt; ++i) ((double*)out)[i] = (double)tmp[i];
+    *n = cnt;
+    return BA_OK;
+  }
   if (cnt > 0) HIPCHECK(hipMemcpyAsync(out, src, (size_t)cnt * esz, hipMemcpyDeviceToHost, h->stream));
   BA_SYNC(h);
   *n = cnt;

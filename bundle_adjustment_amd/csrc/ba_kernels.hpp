@@ -174,10 +174,25 @@ k_fold_lin(const double* __restrict__ scal6, const double* __restrict__ partL, s
   if (blockIdx.x == 0 && threadIdx.x < 8) msg[threadIdx.x] = (scal6 && threadIdx.x < 6) ? scal6[threadIdx.x] : 0.0;
 }
 
-// out[j] = uv[idx[j]]: the caller-order pixels into point order / camera order (ba_set_problem)
-__global__ void k_gather_uv(const double2* __restrict__ uv, const int* __restrict__ idx, int n, double2* __restrict__ out) {
+// The pixel streams (c_uv / p_uv) of the multi-kernel path.  The reference's measurements are cv2 keypoints (kp.pt,
+// /root/reference/src/bundle_adjuster.py:216): float32 values handed over as doubles.  When EVERY pixel of a problem is such
+// a value (ba_set_problem checks all of them) the two streams are stored as float2 -- half the bytes of the linearisation
+// passes' largest input -- and widened on load: exactly the doubles the caller gave, so every result stays bit-identical.
+struct UvArr {
+  const void* p;
+  int f32;
+  __device__ __forceinline__ double2 operator[](size_t i) const {
+    if (f32) { const float2 v = ((const float2*)p)[i]; return make_double2((double)v.x, (double)v.y); }
+    return ((const double2*)p)[i];
+  }
+};
+// out[j] = uv[idx[j]]: the caller-order pixels into point order / camera order (ba_set_problem); f32: stored as float2
+__global__ void k_gather_uv(const double2* __restrict__ uv, const int* __restrict__ idx, int n, double2* __restrict__ out, int f32) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < n) out[j] = uv[idx[j]];
+  if (j >= n) return;
+  const double2 v = uv[idx[j]];
+  if (f32) ((float2*)out)[j] = make_float2((float)v.x, (float)v.y);
+  else out[j] = v;
 }
 
 // the flagged copies of the two index streams start as the plain streams (a robust linearisation stores an entry only
@@ -258,7 +273,7 @@ __device__ inline void wave_store_sums(double (&acc)[N], int lane, double* __res
 template <bool ROBUST>
 __global__ void __launch_bounds__(64 * WPB)
 k_cam_residual(const double* __restrict__ cs, const double* __restrict__ ptab, const int* __restrict__ offk,
-               const int* __restrict__ c_pt, const double2* __restrict__ c_uv, const int* __restrict__ c_orig,
+               const int* __restrict__ c_pt, const UvArr c_uv, const int* __restrict__ c_orig,
                double fx, double fy, double cx, double cy, double hub_c, int n_cams, int band,
                double* __restrict__ r_out, double* __restrict__ partR) {
   Seg s;
@@ -296,7 +311,7 @@ k_cam_residual(const double* __restrict__ cs, const double* __restrict__ ptab, c
 template <bool ROBUST>
 __global__ void __launch_bounds__(64 * WPB)
 k_cam_residual_bal(const double* __restrict__ cs, const double* __restrict__ intr, const double* __restrict__ ptab,
-                   const int* __restrict__ offk, const int* __restrict__ c_pt, const double2* __restrict__ c_uv,
+                   const int* __restrict__ offk, const int* __restrict__ c_pt, const UvArr c_uv,
                    const int* __restrict__ c_orig, double hub_c, int n_cams, int band,
                    double* __restrict__ r_out, double* __restrict__ partR) {
   Seg s;
@@ -582,7 +597,7 @@ __device__ inline double row_sum_dpp(double x) {     // the last lane of every s
 template <class CM, bool ROBUST, bool COST>
 __global__ void __launch_bounds__(ROW_LANES * ROWS)
 k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ intr, const double* __restrict__ ptab,
-                   const int* __restrict__ offk, const int* __restrict__ c_pt, const double2* __restrict__ c_uv,
+                   const int* __restrict__ offk, const int* __restrict__ c_pt, const UvArr c_uv,
                    double fx, double fy, double cx, double cy, double hub_c, int n_cams, int band,
                    double2* __restrict__ c_w, int* __restrict__ c_ptf, double* __restrict__ partL,
                    double* __restrict__ partR) {
@@ -864,6 +879,7 @@ struct CamUpdateArgs {
   const double* vx;              // (M x_r, x_t, ..) of the PCG iterate, NB per camera, kept current by k_pcg_setup / k_pcg_step
   double *cams_trial, *intr_trial, *cs_trial, *vtil, *camA_trial, *partC;
   int n_cams, fixed_cam, n_blocks;
+  int groups;                    // camera groups (of CM::VC cameras, one wave each) per riding 1024-thread workgroup (CU_GROUPS; <= 16)
   int fuse;                      // a PCG point pass (MODE 0) that finds PCG finished goes on as the back substitution in the SAME launch
                                  // (n_blocks camera-update workgroups ride in front, as in a MODE 1 launch): see pt_schur_body
 };
@@ -926,7 +942,7 @@ __device__ inline double lanes_sum(double x) {      // last lane of every LANES-
 template <class CM, bool ROBUST, bool ALL_LDS, int LANES>
 __device__ __forceinline__ void
 pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,
-                  const int* __restrict__ p_cam, const double2* __restrict__ p_uv, const int2* __restrict__ blk_win,
+                  const int* __restrict__ p_cam, const UvArr p_uv, const int2* __restrict__ blk_win,
                   const PtWork& wk, int bid, int nblk, double fx, double fy, double cx, double cy, double hub_c,
                   double lambda_arg, const double* __restrict__ lam_dev, double* __restrict__ Hpp, double* __restrict__ bp,
                   double2* __restrict__ p_w, int* __restrict__ p_camf, double* __restrict__ Hppinv, double* __restrict__ y0,
@@ -1045,7 +1061,7 @@ pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, co
 }
 
 #define BA_LIN_PARAMS const double* __restrict__ camA, double* __restrict__ ptab, const int* __restrict__ pt_off,               \
-                      const int* __restrict__ p_cam, const double2* __restrict__ p_uv, const int2* __restrict__ blk_win
+                      const int* __restrict__ p_cam, const UvArr p_uv, const int2* __restrict__ blk_win
 #define BA_LIN_TAIL double fx, double fy, double cx, double cy, double hub_c, double lambda, const double* __restrict__ lam_dev, \
                     double* __restrict__ Hpp, double* __restrict__ bp, double2* __restrict__ p_w, int* __restrict__ p_camf,      \
                     double* __restrict__ Hppinv, double* __restrict__ y0, double* __restrict__ partG, ScalarsArgs sa
@@ -1973,13 +1989,13 @@ k_cam_update(CamUpdateArgs a) {
   __shared__ __align__(16) double lds[cam_update_lds_doubles<CM>()];
   cam_update_body<CM>(a, blockIdx.x, true, lds);
 }
-// the same as riding workgroup `rb` of a 1024-thread launch: waves 0 .. CU_GROUPS-1 take one camera group each
+// the same as riding workgroup `rb` of a 1024-thread launch: waves 0 .. groups-1 take one camera group each
 template <class CM>
 __device__ __forceinline__ void cam_update_rider(const CamUpdateArgs& a, int rb, double* __restrict__ dyn_lds) {
   const int wv = threadIdx.x >> 6;
-  const int grp = rb * CU_GROUPS + wv;
+  const int grp = rb * a.groups + wv;
   const int n_groups = (a.n_cams + CM::VC - 1) / CM::VC;
-  cam_update_body<CM>(a, grp, wv < CU_GROUPS && grp < n_groups, dyn_lds + (wv < CU_GROUPS ? wv : 0) * cam_update_lds_doubles<CM>());
+  cam_update_body<CM>(a, grp, wv < a.groups && grp < n_groups, dyn_lds + (wv < a.groups ? wv : 0) * cam_update_lds_doubles<CM>());
 }
 
 // One workgroup folds every partial-sum array of an LM step into the scalar block `scal`

@@ -31,10 +31,14 @@ constexpr int SETUP_RANK_LDS = 12288;                    // keys of a segment st
 // bad[0] = smallest observation number with an index out of range (INT_MAX: none)
 __global__ void __launch_bounds__(256)
 k_setup_hist(const int* __restrict__ cam_idx, const int* __restrict__ pt_idx, int n_obs, int n_cams, int n_pts,
-             int* __restrict__ cnt, int* __restrict__ bad) {
+             int* __restrict__ cnt, int* __restrict__ bad, const double2* __restrict__ uv, int* __restrict__ wide) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_obs) return;
   const int c = cam_idx[i], p = pt_idx[i];
+  if (uv) {                                   // a pixel that is not a float32 value: the streams stay double2 (UvArr)
+    const double2 v = uv[i];
+    if (!((double)(float)v.x == v.x && (double)(float)v.y == v.y)) *wide = 1;
+  }
   if (c < 0 || c >= n_cams || p < 0 || p >= n_pts) { atomicMin(bad, i); return; }
   atomicAdd(cnt + p, 1);
 }
@@ -323,6 +327,7 @@ struct UnpackArgs {
   int n_obs;
   size_t off_uv, off_psrc, off_corig, off_cpt, off_pcam;
   double2 *p_uv, *c_uv;
+  int uv_f32;                              // the pixel streams are stored as float2 (UvArr, ba_kernels.hpp)
   int *c_ptf0, *c_ptf1, *p_camf0, *p_camf1;
 };
 __global__ void __launch_bounds__(256)
@@ -340,8 +345,14 @@ k_unpack_problem(UnpackArgs a) {
     const int* cpt = (const int*)(a.arena + a.off_cpt);
     const int* pcam = (const int*)(a.arena + a.off_pcam);
     for (int j = t0; j < a.n_obs; j += stride) {
-      a.p_uv[j] = uv[psrc[j]];
-      a.c_uv[j] = uv[corig[j]];
+      const double2 up = uv[psrc[j]], uc = uv[corig[j]];
+      if (a.uv_f32) {
+        ((float2*)a.p_uv)[j] = make_float2((float)up.x, (float)up.y);
+        ((float2*)a.c_uv)[j] = make_float2((float)uc.x, (float)uc.y);
+      } else {
+        a.p_uv[j] = up;
+        a.c_uv[j] = uc;
+      }
       const int x = cpt[j], y = pcam[j];
       a.c_ptf0[j] = x; a.c_ptf1[j] = x; a.p_camf0[j] = y; a.p_camf1[j] = y;
     }

@@ -99,7 +99,7 @@ SYMBOLS = {
 }
 # enum ba_stat (include/ba_hip.h)
 STATS = {"window_mw_launches": 0, "window_lm_launches": 1, "window_fallbacks": 2, "precond_builds": 3, "precond_reuses": 4, "banded": 5,
-         "cap_floor_raises": 6, "ipc_exchanges": 7}
+         "cap_floor_raises": 6, "ipc_exchanges": 7, "pixels_f32": 8}
 
 
 def load_library():

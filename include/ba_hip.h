@@ -159,7 +159,10 @@ enum ba_stat {
   BA_STAT_BANDED = 5,               /* 1: ba_set_problem found the current problem band-structured (pcg_model_tol's automatic default) */
   BA_STAT_CAP_FLOOR_RAISES = 6,     /* LM iterations whose inner solve ran into pcg_max_iters and raised the damping floor */
   BA_STAT_IPC_EXCHANGES = 7,        /* PCG iterations whose reduced-system product was exchanged through IPC-mapped peer buffers (BA_IPC=1) */
-  BA_STAT_COUNT = 8
+  BA_STAT_PIXELS_F32 = 8,           /* 1: every pixel of the current problem is a float32 value (as cv2 keypoints are) and the
+                                       multi-kernel path keeps its two pixel streams as float2, widened on load: same results,
+                                       8 bytes per observation and pass less (BA_PIXELS=f64 switches it off) */
+  BA_STAT_COUNT = 9
 };
 
 const char* ba_last_error(void);

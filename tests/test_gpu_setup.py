@@ -78,3 +78,49 @@ def test_device_build_reports_a_bad_index_like_the_host_build(monkeypatch):
         assert rc == -1 and b"pt_idx[1234]" in s._lib.ba_last_error()
         out = s.solve(max_iters=3)                            # rejected before anything was touched: the old problem stands
         assert out["iterations"] == 3
+
+
+@pytest.mark.parametrize("build", ["host", "device"])
+def test_float32_valued_pixels_are_stored_as_float2_and_change_no_bit(build, monkeypatch):
+    """cv2 keypoints are float32 values (/root/reference/src/bundle_adjuster.py:216): when every pixel of a problem is one,
+    the multi-kernel path keeps its two pixel streams as float2 and widens on load (UvArr, csrc/ba_kernels.hpp) -- the same
+    doubles reach the arithmetic, so every bit of the result is the one of the double2 streams (BA_PIXELS=f64).  One pixel
+    that is NOT a float32 value keeps the whole problem on double2."""
+    monkeypatch.setenv("BA_SETUP", build)
+    p = make_problem(400, 40000, 6, seed=5, outlier_frac=0.01)
+    assert np.array_equal(p.uv, p.uv.astype(np.float32).astype(np.float64))
+
+    def run(prob, pixels):
+        if pixels: monkeypatch.setenv("BA_PIXELS", pixels)
+        else: monkeypatch.delenv("BA_PIXELS", raising=False)
+        with hip_backend.Solver(0) as s:
+            s.set_problem(prob)
+            f32 = s.stats()["pixels_f32"]
+            lay = {k: s.debug_layout(k) for k in ("p_uv", "c_uv")}
+            out = s.solve(loss="huber", max_iters=5, ftol=0.0, xtol=0.0, gtol=0.0)
+            cams, pts = s.get_params()
+            r = s.residuals()[0]
+        return f32, lay, out, cams, pts, r
+
+    f_a, lay_a, out_a, cams_a, pts_a, r_a = run(p, None)
+    f_b, lay_b, out_b, cams_b, pts_b, r_b = run(p, "f64")
+    assert f_a == 1 and f_b == 0
+    for k in lay_a:
+        assert np.array_equal(lay_a[k], lay_b[k]), k
+    assert out_a["final_cost"] == out_b["final_cost"] and out_a["pcg_iterations"] == out_b["pcg_iterations"]
+    assert np.array_equal(cams_a, cams_b) and np.array_equal(pts_a, pts_b) and np.array_equal(r_a, r_b)
+    # one pixel between two float32 values
+    uv = p.uv.copy()
+    uv[777, 1] += 1e-9
+    q = BAProblem(p.cams, p.pts, p.cam_idx, p.pt_idx, uv, p.K4, 0)
+    f_c, lay_c, out_c, *_ = run(q, None)
+    assert f_c == 0 and out_c["status"] == 0
+    src = np.flatnonzero(np.all(lay_c["p_uv"].reshape(-1, 2) == uv[777], axis=1))
+    assert src.size >= 1                                      # (the odd pixel arrived intact)
+
+
+def test_window_sized_problems_keep_double_pixels():
+    p = make_config("C1", seed=0)
+    with hip_backend.Solver(0) as s:
+        s.set_problem(p)
+        assert s.stats()["pixels_f32"] == 0
