@@ -1077,6 +1077,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   // columns of the previous one -> V is cleared again before its next use
   h->small_np_pad = -1;
   const int Nc = n_cams, Np = n_pts, No = (int)n_obs;
+  h->uv_f32 = false;           // (a device build that handed the problem back may have decided already: decided again here)
   if (uv_f32_eligible) {       // every pixel a float32 value?  (branch-free sweep; NaN compares unequal: stays double)
     int all = 1;
     for (int64_t i = 0; i < 2 * n_obs; ++i) all &= (int)((double)(float)uv[i] == uv[i]);

@@ -178,12 +178,30 @@ k_fold_lin(const double* __restrict__ scal6, const double* __restrict__ partL, s
 // /root/reference/src/bundle_adjuster.py:216): float32 values handed over as doubles.  When EVERY pixel of a problem is such
 // a value (ba_set_problem checks all of them) the two streams are stored as float2 -- half the bytes of the linearisation
 // passes' largest input -- and widened on load: exactly the doubles the caller gave, so every result stays bit-identical.
+// Loads of the observation streams (index, pixel and weight arrays: every element is read once per pass, in order).
+// BA_STREAM_NT=1 marks them non-temporal, so that they do not push the gathered point records out of the XCD's L2.
+#ifndef BA_STREAM_NT
+#define BA_STREAM_NT 0
+#endif
+typedef double ba_d2v __attribute__((ext_vector_type(2)));
+typedef float ba_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int ld_stream(const int* p) { return BA_STREAM_NT ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ double2 ld_stream(const double2* p) {
+  if (!BA_STREAM_NT) return *p;
+  const ba_d2v v = __builtin_nontemporal_load((const ba_d2v*)p);
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ float2 ld_stream(const float2* p) {
+  if (!BA_STREAM_NT) return *p;
+  const ba_f2v v = __builtin_nontemporal_load((const ba_f2v*)p);
+  return make_float2(v.x, v.y);
+}
 struct UvArr {
   const void* p;
   int f32;
   __device__ __forceinline__ double2 operator[](size_t i) const {
-    if (f32) { const float2 v = ((const float2*)p)[i]; return make_double2((double)v.x, (double)v.y); }
-    return ((const double2*)p)[i];
+    if (f32) { const float2 v = ld_stream((const float2*)p + i); return make_double2((double)v.x, (double)v.y); }
+    return ld_stream((const double2*)p + i);
   }
 };
 // out[j] = uv[idx[j]]: the caller-order pixels into point order / camera order (ba_set_problem); f32: stored as float2
@@ -281,7 +299,7 @@ k_cam_residual(const double* __restrict__ cs, const double* __restrict__ ptab, c
   const double* cam = cs + CS * s.c;
   double acc[2] = {0.0, 0.0};
   for (int i = s.beg + s.lane; i < s.end; i += 64) {
-    const int p = c_pt[i];
+    const int p = ld_stream(c_pt + i);
     const double2 uv = c_uv[i];
     const double4 X = *(const double4*)(ptab + PT * (size_t)p);
     double xh, yh;
@@ -320,7 +338,7 @@ k_cam_residual_bal(const double* __restrict__ cs, const double* __restrict__ int
   const double f = intr[3 * s.c], k1 = intr[3 * s.c + 1], k2 = intr[3 * s.c + 2];
   double acc[2] = {0.0, 0.0};
   for (int i = s.beg + s.lane; i < s.end; i += 64) {
-    const int p = c_pt[i];
+    const int p = ld_stream(c_pt + i);
     const double2 uv = c_uv[i];
     const double4 X = *(const double4*)(ptab + PT * (size_t)p);
     double xh, yh;
@@ -521,12 +539,12 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ intr, cons
   for (int q = 0; q < NB; ++q) acc[q] = 0.0;
   if (live && c != fixed_cam) {
     int i = beg + lane;
-    int pf = (i < end) ? c_pt[i] : 0;          // ROBUST: the flagged copy of c_pt
+    int pf = (i < end) ? ld_stream(c_pt + i) : 0;          // ROBUST: the flagged copy of c_pt
     double2 w = make_double2(1.0, 1.0);
-    if (ROBUST && pf < 0) w = c_w[i];
+    if (ROBUST && pf < 0) w = ld_stream(c_w + i);
     while (i < end) {
       const int in = i + SEGL;
-      const int pn = (in < end) ? c_pt[in] : 0;          // prefetch the next index
+      const int pn = (in < end) ? ld_stream(c_pt + in) : 0;          // prefetch the next index
       int p = ROBUST ? (pf & IDX_MASK) : pf;
 #ifdef BA_STAMPS
       const int dbg = g_dbg_mode;
@@ -539,7 +557,7 @@ k_cam_schur(const double* __restrict__ cs, const double* __restrict__ intr, cons
       if (dbg == 2) Yd = Xd;                                 // one 32-byte half of the record only
 #endif
       double2 wn = make_double2(1.0, 1.0);                 // next weight, only where it is not (1, 1)
-      if (ROBUST && pn < 0) wn = c_w[in];
+      if (ROBUST && pn < 0) wn = ld_stream(c_w + in);
       const JT X0 = (JT)Xd.x, X1 = (JT)Xd.y, X2 = (JT)Xd.z, Y0 = (JT)Yd.x, Y1 = (JT)Yd.y, Y2 = (JT)Yd.z;
       typename CM::template Obs<JT> g;
       CM::template geom<true, JT, JT>(cam, X0, X1, X2, fxj, fyj, g);
@@ -616,11 +634,11 @@ k_camrow_linearize(const double* __restrict__ cs, const double* __restrict__ int
     // and the 4-byte-per-observation store stream disappears from the pass's traffic
     const int* __restrict__ idx_in = ROBUST ? (const int*)c_ptf : c_pt;
     int i = s.beg + s.l16;
-    int pr = (i < s.end) ? idx_in[i] : 0;
+    int pr = (i < s.end) ? ld_stream(idx_in + i) : 0;
     double2 uv = (i < s.end) ? c_uv[i] : make_double2(0, 0);
     while (i < s.end) {
       const int in = i + ROW_LANES;
-      const int pn = (in < s.end) ? idx_in[in] : 0;
+      const int pn = (in < s.end) ? ld_stream(idx_in + in) : 0;
       const double2 uvn = (in < s.end) ? c_uv[in] : make_double2(0, 0);
       const int p = ROBUST ? (pr & IDX_MASK) : pr;
       const double4 X = *(const double4*)(ptab + PT * (size_t)p);
@@ -682,17 +700,17 @@ k_camrow_schur_diag(const double* __restrict__ cs, const double* __restrict__ in
     double cam[CM::CAM];
     CM::load_cam_vec(cs, intr, s.c, cam);
     int i = s.beg + s.l16;
-    int pf = (i < s.end) ? c_pt[i] : 0;          // ROBUST: the flagged copy of c_pt
+    int pf = (i < s.end) ? ld_stream(c_pt + i) : 0;          // ROBUST: the flagged copy of c_pt
     double2 w = make_double2(1.0, 1.0);
-    if (ROBUST && pf < 0) w = c_w[i];
+    if (ROBUST && pf < 0) w = ld_stream(c_w + i);
     while (i < s.end) {
       const int in = i + ROW_LANES;
-      const int pn = (in < s.end) ? c_pt[in] : 0;
+      const int pn = (in < s.end) ? ld_stream(c_pt + in) : 0;
       const int p = ROBUST ? (pf & IDX_MASK) : pf;
       const double4 X = *(const double4*)(ptab + PT * (size_t)p);
       const double4 Y = *(const double4*)(ptab + PT * (size_t)p + 4);
       double2 wn = make_double2(1.0, 1.0);
-      if (ROBUST && pn < 0) wn = c_w[in];
+      if (ROBUST && pn < 0) wn = ld_stream(c_w + in);
       typename CM::template Obs<double> g;
       CM::template geom<false, double, double>(cam, X.x, X.y, X.z, fx, fy, g);
       const double* Pm = CM::pm(g);
@@ -975,11 +993,11 @@ pt_linearize_body(const double* __restrict__ camA, double* __restrict__ ptab, co
       // (ROBUST: index stream from the flagged copy, stored back only where the flag changes -- see k_camrow_linearize)
       const int* __restrict__ idx_in = ROBUST ? (const int*)p_camf : p_cam;
       int j = beg + sub;
-      int cr = (j < end) ? idx_in[j] : 0;
+      int cr = (j < end) ? ld_stream(idx_in + j) : 0;
       double2 uv = (j < end) ? p_uv[j] : make_double2(0, 0);
       while (j < end) {
         const int jn = j + LANES;
-        const int cn = (jn < end) ? idx_in[jn] : 0;
+        const int cn = (jn < end) ? ld_stream(idx_in + jn) : 0;
         const double2 uvn = (jn < end) ? p_uv[jn] : make_double2(0, 0);
         const int c = ROBUST ? (cr & IDX_MASK) : cr;
         double row[CM::LIN_ROW];
@@ -1233,9 +1251,9 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
       else {
         X = *(const double4*)(ptab + PT * (size_t)p);
         j = beg + sub;
-        c = (j < end) ? p_cam[j] : 0;
-        cn = (j + LANES < end) ? p_cam[j + LANES] : 0;
-        if (ROBUST && c < 0) w = p_w[j];
+        c = (j < end) ? ld_stream(p_cam + j) : 0;
+        cn = (j + LANES < end) ? ld_stream(p_cam + (j + LANES)) : 0;
+        if (ROBUST && c < 0) w = ld_stream(p_w + j);
         if (sub == LANES - 1) {
           const double2* hp = (const double2*)(Hppinv + 6 * (size_t)p);
           const double2 h01 = hp[0], h23 = hp[1], h45 = hp[2];
@@ -1288,9 +1306,9 @@ pt_schur_body(const double* __restrict__ camA, double* __restrict__ ptab, const 
       while (j < end) {
         // index two observations ahead, weight (only where it is not (1, 1)) one ahead
         const int jn = j + LANES, jnn = jn + LANES;
-        const int cnn = (jnn < end) ? p_cam[jnn] : 0;
+        const int cnn = (jnn < end) ? ld_stream(p_cam + jnn) : 0;
         double2 wn = make_double2(1.0, 1.0);
-        if (ROBUST && cn < 0) wn = p_w[jn];
+        if (ROBUST && cn < 0) wn = ld_stream(p_w + jn);
         const int cc = ROBUST ? (c & IDX_MASK) : c;
         if (cc != fixed_cam) {
           double rowd[CM::SCH_ROW];
