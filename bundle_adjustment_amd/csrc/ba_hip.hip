@@ -609,7 +609,7 @@ static int shm_allreduce(ba_handle* h, double* buf, size_t count, bool is_max) {
 // Every rank allocates a receive buffer ([2 parities][world][stride] doubles + flag lines) in fine-grained device memory,
 // exports it with hipIpcGetMemHandle and opens every peer's; the handles travel through a small POSIX shared-memory
 // board named after the communicator id (one node: what bench.py --gpus N runs on).  Used for the Schur product's
-// exchange inside the PCG loop (k_ipc_fold_send -> k_pcg_step); every other collective keeps the base transport.
+// exchange inside the PCG loop (inside k_pcg_step); every other collective keeps the base transport.
 struct IpcComm {
   static constexpr size_t STRIDE = 32768;             // doubles per (parity, sender) slot: messages up to 256 KB (3600 BAL cameras)
   int rank = 0, world = 1;
@@ -620,10 +620,9 @@ struct IpcComm {
   void* local = nullptr;                              // own receive buffer (recv doubles, then the flag lines)
   void* opened[IPC_MAX_WORLD] = {nullptr};
   IpcPeers peers;
-  int* ticket = nullptr;
   long long seq = 0;
   size_t recv_doubles() const { return (size_t)2 * world * STRIDE; }
-  size_t bytes() const { return recv_doubles() * sizeof(double) + (size_t)2 * world * IPC_FLAG_STRIDE * sizeof(unsigned long long); }
+  size_t bytes() const { return recv_doubles() * sizeof(double) + (size_t)2 * world * IPC_MAX_BLOCKS * sizeof(unsigned long long); }
   std::atomic<unsigned>* counter() { return reinterpret_cast<std::atomic<unsigned>*>(board); }
   std::atomic<unsigned>* sense() { return reinterpret_cast<std::atomic<unsigned>*>(board + 64); }
   int barrier() {
@@ -646,7 +645,6 @@ static void ipc_destroy(ba_handle* h) {
   if (c->board) (void)c->barrier();                   // nobody unmaps a buffer a peer may still be storing into
   for (int r = 0; r < c->world; ++r) if (c->opened[r]) (void)hipIpcCloseMemHandle(c->opened[r]);
   if (c->local) (void)hipFree(c->local);
-  if (c->ticket) (void)hipFree(c->ticket);
   if (c->board) { munmap(c->board, c->board_bytes); if (c->rank == 0) shm_unlink(c->name); }
   delete c;
   h->ipc = nullptr;
@@ -674,8 +672,6 @@ static int ipc_init(ba_handle* h, int rank, int world, const void* id128) {
     return fail(BA_ERR_COMM, "BA_IPC: fine-grained device memory for the receive buffer is not available");
   }
   HIPCHECK(hipMemset(c->local, 0, c->bytes()));
-  HIPCHECK(hipMalloc((void**)&c->ticket, sizeof(int)));
-  HIPCHECK(hipMemset(c->ticket, 0, sizeof(int)));
   HIPCHECK(hipDeviceSynchronize());
   hipIpcMemHandle_t mine;
   if (hipIpcGetMemHandle(&mine, c->local) != hipSuccess) { (void)hipGetLastError(); return fail(BA_ERR_COMM, "hipIpcGetMemHandle failed"); }
@@ -2522,36 +2518,31 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
       launch_pt_schur(h, robust, 0, kk, tol2, opts->pcg_min_iters, base,
                       (kk == 0 && gtol_pending) ? h->d_scal_host + GMAX_HOST_SLOT : (double*)nullptr, fuse ? &cu : nullptr);
     };
-    const bool use_ipc = h->ipc && h->multi && !h->two_level && 2 + (size_t)nb_of(h) * Nc <= IpcComm::STRIDE;
+    // BA_IPC: the exchange of the Schur product happens inside k_pcg_step, workgroup by workgroup (ba_kernels.hpp,
+    // "device-side all-reduce"); every workgroup's record has to fit its slot of the receive buffers
+    const bool use_ipc = h->ipc && h->multi && !h->two_level && nbv(h) <= IPC_MAX_BLOCKS &&
+                         (size_t)nbv(h) * (2 + (size_t)nb_of(h) * (h->model ? BalCam::VC : Pinhole::VC)) <= IpcComm::STRIDE;
     auto launch_rest = [&](int kk) -> int {
       launch_cam_schur(h, robust, false, true, kk, tol2, opts->pcg_min_iters);
       // the Schur product of the reduced camera system, summed over the ranks: device-side stores into every peer's receive
-      // buffer (consumed inside k_pcg_step), or fold + all-reduce on the base transport
-      const double* p6_src = p6_ptr(h);
-      int p6_parts = nparts_of(h);
-      const unsigned long long* ipc_flags = nullptr;
-      int ipc_parity = 0;
-      long long ipc_seq = 0;
+      // buffer (inside k_pcg_step), or fold + all-reduce on the base transport
+      IpcStep ipc;
+      memset(&ipc, 0, sizeof ipc);
       if (use_ipc) {
         IpcComm* c = h->ipc;
-        ipc_seq = ++c->seq;
-        ipc_parity = (int)(ipc_seq & 1);
-        const size_t n6 = (size_t)nb_of(h) * Nc;
-        {
-          Scope sc(h, BA_K_ALLREDUCE);
-          BA_LAUNCH(k_ipc_fold_send, dim3((unsigned)((n6 + 255) / 256)), dim3(256), 0, h->stream, (const double*)uy_ptr(h), (const double*)p6_ptr(h), n6,
-                    h->one_part ? 1 : NPART, c->peers, c->rank, c->world, ipc_parity, IpcComm::STRIDE, ipc_seq, c->ticket);
-        }
-        p6_src = c->peers.recv[c->rank] + (size_t)ipc_parity * c->world * IpcComm::STRIDE + 2;
-        p6_parts = c->world;
-        ipc_flags = c->peers.flags[c->rank];
+        ipc.P = c->peers; ipc.on = 1; ipc.rank = c->rank; ipc.world = c->world;
+        ipc.seq = ++c->seq;
+        ipc.parity = (int)(ipc.seq & 1);
+        ipc.stride = IpcComm::STRIDE;
         h->stats[BA_STAT_IPC_EXCHANGES]++;
       } else if (int rc = exchange_schur(h)) return rc;
       Scope sc(h, BA_K_PCG_UPDATE);
-#define STEP_ARGS kk, p6_src, p6_parts, (const double*)uy_ptr(h), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc, h->fixed, tol2,       \
+      // (device-side exchange: k_cam_schur's raw partitions, folded inside the kernel; else partition 0 holds the all-reduced sums)
+      const int step_parts = use_ipc ? (h->one_part ? 1 : NPART) : nparts_of(h);
+#define STEP_ARGS kk, (const double*)p6_ptr(h), step_parts, (const double*)uy_ptr(h), h->Hccd.p, h->Minv.p, h->cs[h->cur].p, Nc, h->fixed, tol2,       \
                   opts->pcg_min_iters, h->x.p, h->r.p, h->p.p, h->s.p, h->z.p, h->camA[h->cur].p, h->partV.p, nbv(h), h->st.p, \
                   h->d_flags, base, (const double*)h->verdict.p
-#define STEP_TAIL h->vx.p, model_tol, opts->pcg_model_min_iters, ipc_flags, IpcComm::STRIDE, ipc_parity, ipc_seq, h->d_flags + 6
+#define STEP_TAIL h->vx.p, model_tol, opts->pcg_model_min_iters, ipc, h->d_flags + 6
       if (h->two_level) {
         BA_LAUNCH((k_pcg_step<Pinhole, true>), dim3(h->nblkV), dim3(VEC_BLOCK), 0, h->stream, STEP_ARGS, h->coarse_rc.p, STEP_TAIL);
         BA_LAUNCH(k_pcg_coarse, dim3(h->n_agg), dim3(VEC_BLOCK), 0, h->stream, kk, (const double*)h->coarseEinv.p,

@@ -1455,70 +1455,45 @@ k_pt_schur_both(BA_SCH_PARAMS, PtWork wk, int nblk_short, PtWork wl, BA_SCH_TAIL
 // ---- device-side all-reduce of the reduced camera system's product (multi-rank jobs, BA_IPC=1) ----------------------
 // Once per PCG iteration every rank owes every other rank its folded Schur product W y (NB Nc doubles) and its u.y word:
 // 48 KB at the headline size, a message whose all-reduce is pure latency (an RCCL launch + a ring over xGMI: 10-20 us).
-// Here every rank STORES its folded partition straight into a slot of every peer's receive buffer (buffers exported
-// with hipIpcGetMemHandle when the communicator comes up, fine-grained device memory: stores go through to the fabric,
-// loads are not cached) and then a sequence number into the peer's flag word for (parity, sender); the consumer --
-// k_pcg_step itself, no kernel of its own -- waits for the `world` flag words of its own buffer and adds the `world` slots
-// in RANK ORDER, so every rank computes the same bits (and the same as the host-staged test transport, which also adds
-// in rank order).  Slots are double-buffered by the parity of the exchange number: a rank can be at most one exchange
-// ahead of a peer (its next consumer waits for that peer's flag), so the slot it overwrites two exchanges later has been read.
+// Here the exchange happens INSIDE the vector kernel (k_pcg_step), workgroup by workgroup, with no kernel of its own:
+// workgroup b owns VC consecutive cameras on every rank, so it only ever needs the other ranks' workgroup b.  It folds its
+// cameras' partitions (fixed order), STORES the record [u.y, 0 | NB VC sums] straight into slot (parity, own rank, b) of
+// every peer's receive buffer (buffers exported with hipIpcGetMemHandle when the communicator comes up, fine-grained
+// device memory: stores go through to the fabric, loads are not cached), fences, stores the exchange's sequence number
+// into the peers' flag word for (parity, own rank, b), waits for the `world` flag words of its own buffer and adds the
+// `world` records in RANK ORDER -- every rank computes the same bits (and the same as the host-staged test transport,
+// which also adds in rank order).  Slots are double-buffered by the parity of the exchange number: workgroup b of a rank
+// can be at most one exchange ahead of a peer's workgroup b (its next wait needs that peer's next flag, stored only after
+// the peer's previous k_pcg_step has finished), so the record it overwrites two exchanges later has been read.
 constexpr int IPC_MAX_WORLD = 8;
-constexpr int IPC_FLAG_STRIDE = 16;             // flag words (u64) per (parity, sender): one 128-byte line each
+constexpr int IPC_MAX_BLOCKS = 512;             // camera-vector workgroups a flag array holds per (parity, sender)
 struct IpcPeers {
   double* recv[IPC_MAX_WORLD];                  // every rank's receive buffer as mapped in THIS process ([rank]: the own one)
   unsigned long long* flags[IPC_MAX_WORLD];
 };
+struct IpcStep {                                // one exchange (k_pcg_step); on == 0: single rank or the base transport
+  IpcPeers P;
+  int on, rank, world, parity;
+  long long seq;
+  size_t stride;                                // doubles per (parity, sender) slot of a receive buffer
+};
 constexpr long long IPC_WAIT_TICKS = 1000000000; // 10 s of the 100 MHz wall clock: a peer that never sends
-// fold the nparts partitions of part6 (fixed order) and send: slot (parity, rank) of every peer <- [u.y, 0 | folded part6]
-__global__ void __launch_bounds__(256)
-k_ipc_fold_send(const double* __restrict__ uy_src, const double* __restrict__ part6, size_t n6, int nparts, IpcPeers P, int rank,
-                int world, int parity, size_t stride, long long seq, int* __restrict__ ticket) {
-  __shared__ int s_last;
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const size_t slot = ((size_t)parity * world + rank) * stride;
-  if (i < n6) {
-    double v[NPART];
-#pragma unroll
-    for (int k = 0; k < NPART; ++k) v[k] = (k < nparts) ? part6[(size_t)k * n6 + i] : 0.0;
-    double a = v[0];
-#pragma unroll
-    for (int k = 1; k < NPART; ++k) a += v[k];
-    for (int d = 0; d < world; ++d) __hip_atomic_store(P.recv[d] + slot + 2 + i, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  if (i == 0) {
-    const double u = uy_src[0];
-    for (int d = 0; d < world; ++d) __hip_atomic_store(P.recv[d] + slot, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  // every store of this workgroup has left for the fabric before its ticket is drawn; the workgroup that draws the last
-  // ticket publishes the sequence number to every peer (release, system scope)
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == (int)gridDim.x - 1) ? 1 : 0;
-    if (s_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the next launch is ordered behind this one)
-  }
-  __syncthreads();
-  if (s_last && (int)threadIdx.x < world)
-    __hip_atomic_store(P.flags[threadIdx.x] + ((size_t)parity * world + rank) * IPC_FLAG_STRIDE, (unsigned long long)seq,
-                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// consumer side (whole wave): lane s < world waits for sender s's flag of this parity to reach seq; false = timed out
-__device__ inline bool ipc_wait(const unsigned long long* __restrict__ flags, int world, int parity, long long seq) {
+// consumer side (whole wave): lane s < world waits for sender s's flag of (parity, workgroup b) to reach seq; false = timed out
+__device__ inline bool ipc_wait(const unsigned long long* __restrict__ flags, int world, int parity, int b, long long seq) {
   bool ok = true;
   const int s = threadIdx.x & 63;
   if (s < world) {
-    const unsigned long long* f = flags + ((size_t)parity * world + s) * IPC_FLAG_STRIDE;
+    const unsigned long long* f = flags + ((size_t)parity * world + s) * IPC_MAX_BLOCKS + b;
     if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < (unsigned long long)seq) {
       const long long t0 = (long long)wall_clock64();
       int spins = 0;
       while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < (unsigned long long)seq) {
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(2);
         if ((++spins & 255) == 0 && (long long)wall_clock64() - t0 > IPC_WAIT_TICKS) { ok = false; break; }
       }
     }
   }
-  asm volatile("" ::: "memory");                 // (the slot loads are issued behind the loop that saw the flags)
+  asm volatile("" ::: "memory");                 // (the record loads are issued behind the loop that saw the flags)
   return __all(ok);
 }
 
@@ -1754,12 +1729,11 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
            double* __restrict__ z, double* __restrict__ vtil, double* __restrict__ partV, int nblkV,
            PcgState* __restrict__ st, long long* __restrict__ host_flag, long long flag_base,
            const double* __restrict__ verdict, double* __restrict__ rc, double* __restrict__ vx,
-           double model_tol, int model_min_iters,
-           const unsigned long long* __restrict__ ipc_flags, size_t ipc_stride, int ipc_parity, long long ipc_seq,
-           long long* __restrict__ err_flag) {
-  // ipc_flags != null (multi-rank, device-side exchange): part6 points at slot (parity, rank 0) of the receive buffer's
-  // payload, `nparts` = world senders ipc_stride doubles apart, the u.y words sit two doubles in front of each payload
+           double model_tol, int model_min_iters, IpcStep ipc, long long* __restrict__ err_flag) {
+  // ipc.on (multi-rank, device-side exchange): part6 / uy_src are this rank's own sums; the other ranks' arrive in the
+  // receive buffer while the kernel runs (see "device-side all-reduce" above)
   constexpr int NB = CM::NB, NH = CM::NH, VC = CM::VC;
+  static_assert(VEC_BLOCK == 64, "the in-kernel exchange fences and flags from ONE wave");
   // LDS image of the workgroup's cameras: Hccd | Minv | z p s r x | part6[NPART] | cs
   __shared__ double l_h[NH * VC], l_mi[NH * VC], l_v[5][NB * VC], l_p6[NPART][NB * VC], l_cs[CS * VC];
   BA_STAMP(2, 0); BA_STAMP(2, 1);
@@ -1769,7 +1743,7 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
   const bool live = c < n_cams && c != fixed_cam;
   // every operand is fetched before the verdict is known (one round trip for the whole kernel; an
   // early-exit launch wastes the loads)
-  double uy = ipc_flags ? 0.0 : uy_src[0];
+  double uy = uy_src[0];
   {
     double2 vh[slice_chunks(NH * VC)], vm[slice_chunks(NH * VC)], vv[5][slice_chunks(NB * VC)], vp[NPART][slice_chunks(NB * VC)],
         vc[slice_chunks(CS * VC)];
@@ -1779,14 +1753,7 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
 #pragma unroll
     for (int q = 0; q < 5; ++q) slice_load(VecSlice{vecs[q] + NB * (size_t)c0, NB * nc}, vv[q]);
     slice_load(VecSlice{cs + CS * (size_t)c0, CS * nc}, vc);
-    // partition stride of the Schur product's partial sums: local partitions, or the senders' slots of the receive buffer
-    size_t p6_stride = (size_t)n_cams * NB;
-    if (ipc_flags) {
-      p6_stride = ipc_stride;
-      if (!ipc_wait(ipc_flags, nparts, ipc_parity, ipc_seq) && err_flag && threadIdx.x == 0)
-        __hip_atomic_store(err_flag, 2ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      for (int kk = 0; kk < nparts; ++kk) uy += (part6 + (size_t)kk * p6_stride)[-2];     // the senders' u.y words, rank order
-    }
+    const size_t p6_stride = (size_t)n_cams * NB;           // partition stride of the Schur product's partial sums
 #pragma unroll
     for (int kk = 0; kk < NPART; ++kk)
       slice_load(VecSlice{part6 + (size_t)kk * p6_stride + (size_t)c0 * NB, kk < nparts ? NB * nc : 0}, vp[kk]);
@@ -1812,6 +1779,37 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
     return;
   }
   BA_STAMP(2, 2);
+  int nfold = nparts;                                   // partitions the per-camera fold below adds
+  if (ipc.on) {
+    __syncthreads();                                    // the LDS image (the partitions) is complete
+    constexpr int REC = 2 + NB * VC;
+    const int lane = threadIdx.x;
+    const size_t mine = ((size_t)ipc.parity * ipc.world + ipc.rank) * ipc.stride + (size_t)blockIdx.x * REC;
+    for (int e = lane; e < NB * VC; e += 64) {
+      double a = 0.0;
+      for (int kk = 0; kk < nparts; ++kk) a += l_p6[kk][e];
+      for (int d = 0; d < ipc.world; ++d) __hip_atomic_store(ipc.P.recv[d] + mine + 2 + e, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (lane < ipc.world) __hip_atomic_store(ipc.P.recv[lane] + mine, uy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // every store of this wave has left for the fabric before the sequence number follows it (release, system scope)
+    __threadfence_system();
+    if (lane < ipc.world)
+      __hip_atomic_store(ipc.P.flags[lane] + ((size_t)ipc.parity * ipc.world + ipc.rank) * IPC_MAX_BLOCKS + blockIdx.x,
+                         (unsigned long long)ipc.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!ipc_wait(ipc.P.flags[ipc.rank], ipc.world, ipc.parity, (int)blockIdx.x, ipc.seq) && err_flag && lane == 0)
+      __hip_atomic_store(err_flag, 2ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const double* own = ipc.P.recv[ipc.rank] + (size_t)ipc.parity * ipc.world * ipc.stride + (size_t)blockIdx.x * REC;
+    uy = 0.0;
+    for (int sdr = 0; sdr < ipc.world; ++sdr)           // the senders' records, rank order
+      uy += __hip_atomic_load(own + (size_t)sdr * ipc.stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int e = lane; e < NB * VC; e += 64) {
+      double a = 0.0;
+      for (int sdr = 0; sdr < ipc.world; ++sdr)
+        a += __hip_atomic_load(own + (size_t)sdr * ipc.stride + 2 + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      l_p6[0][e] = a;
+    }
+    nfold = 1;
+  }
   const double delta = zeta - uy;
   const double beta = (k == 0) ? 0.0 : gamma / sin.gamma_prev;
   const double denom = (k == 0) ? delta : delta - beta * gamma / sin.alpha_prev;
@@ -1848,7 +1846,7 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
       double a[NB];
 #pragma unroll
       for (int q = 0; q < NB; ++q) a[q] = 0.0;
-      for (int kk = 0; kk < nparts; ++kk) {
+      for (int kk = 0; kk < nfold; ++kk) {
 #pragma unroll
         for (int q = 0; q < NB; ++q) a[q] += l_p6[kk][NB * t + q];
       }
