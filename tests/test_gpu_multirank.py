@@ -377,6 +377,7 @@ out = s.solve_bal_resident(intr, loss="huber", max_iters=12, ftol=0.0, xtol=0.0,
 cams, pts = s.get_params()
 np.save(os.path.join(%(out)r, f"cams_{rank}.npy"), np.concatenate([cams, intr], axis=1))
 np.save(os.path.join(%(out)r, f"pts_{rank}.npy"), pts)
+out["ipc_exchanges"] = s.stats()["ipc_exchanges"]
 json.dump(out, open(os.path.join(%(out)r, f"out_{rank}.json"), "w"))
 s.close()
 dist.barrier()
@@ -384,15 +385,17 @@ dist.destroy_process_group()
 """
 
 
-def test_two_ranks_bal_camera_match_single_rank(tmp_path):
+@pytest.mark.parametrize("ipc", ["0", "1"])
+def test_two_ranks_bal_camera_match_single_rank(tmp_path, ipc):
     """The BAL 9-parameter camera shards by landmark like the pinhole (fold / all-reduce sizes follow the camera model: 9 and
     45 + 9 sums per camera): two ranks on one GPU (shm transport) against the single-rank ba_solve_bal -- same global costs on
-    both ranks, cameras (f, k1, k2 included) bitwise identical across ranks, and the single-rank iterates to round-off."""
+    both ranks, cameras (f, k1, k2 included) bitwise identical across ranks, and the single-rank iterates to round-off.
+    ipc = 1: the per-PCG-iteration exchange inside k_pcg_step (records of 2 + 9 x 16 doubles per workgroup here)."""
     from bundle_adjustment_amd import hip_backend
     from bundle_adjustment_amd.synthetic import make_bal_problem
     script = tmp_path / "worker_bal.py"
     script.write_text(BAL_WORKER % dict(root=ROOT, out=str(tmp_path)))
-    env = dict(os.environ, BA_COMM="shm")
+    env = dict(os.environ, BA_COMM="shm", BA_IPC=ipc)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", _free_port(), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
@@ -404,6 +407,7 @@ def test_two_ranks_bal_camera_match_single_rank(tmp_path):
     outs = [json.load(open(tmp_path / f"out_{k}.json")) for k in range(2)]
     for key in ("iterations", "accepted", "pcg_iterations", "initial_sse", "final_sse", "final_cost"):
         assert outs[0][key] == outs[1][key], key
+    assert (outs[0]["ipc_exchanges"] >= outs[0]["pcg_iterations"]) if ipc == "1" else (outs[0]["ipc_exchanges"] == 0)
     assert abs(outs[0]["initial_cost"] - ref["initial_cost"]) <= 1e-10 * ref["initial_cost"]
     assert abs(outs[0]["final_cost"] - ref["final_cost"]) <= 1e-8 * ref["final_cost"]
     assert outs[0]["final_cost"] < 0.05 * outs[0]["initial_cost"]
