@@ -2506,10 +2506,15 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     cu.n_cams = Nc; cu.fixed_cam = h->fixed; cu.groups = cu_groups;
     cu.n_blocks = (((nbv(h) + cu.groups - 1) / cu.groups + NPART - 1) / NPART) * NPART;
     const bool ride = (riders & 1) && all_lds_of(h) && h->Np > 0;
-    // The probe that finds PCG finished goes on as the back substitution (pt_schur_body, cu.fuse): riders in front of
-    // every PCG point pass, so only while everything is still resident at once; fp64 blocks only (the back substitution
-    // is never computed with the PCG passes' fp32 blocks)
-    const bool fuse = ride && (riders & 4) && !h->jac_f32 && h->nblkP + h->nblkL + cu.n_blocks <= h->n_cu;
+    // The probe that finds PCG finished goes on as the back substitution (pt_schur_body, cu.fuse): the camera-update riders
+    // then sit behind the point workgroups of EVERY PCG point pass (they only run in the launch that finds PCG finished), so
+    // only where they do not add a round of workgroups to those launches -- a point-pass workgroup has a compute unit to
+    // itself (config 5: 256 workgroups, one round; 16 more would be a second one in each of ~100 launches per LM iteration);
+    // fp64 blocks only (the back substitution is never computed with the PCG passes' fp32 blocks).  Nothing in the launch
+    // waits for a rider, so residency is a matter of speed, not of correctness.
+    const int pt_wgs = h->nblkP + h->nblkL;
+    const bool fuse = ride && (riders & 4) && !h->jac_f32 &&
+                      (pt_wgs + cu.n_blocks + h->n_cu - 1) / h->n_cu == (pt_wgs + h->n_cu - 1) / h->n_cu;
     cu.fuse = fuse ? 1 : 0;
     bool backsub_done = false;
     size_t probe_ev = (size_t)-1, probe_flushes = 0;
