@@ -2513,7 +2513,10 @@ static int solve_impl(ba_handle* h, const ba_options* opts, ba_summary* sum) {
     // fp64 blocks only (the back substitution is never computed with the PCG passes' fp32 blocks).  Nothing in the launch
     // waits for a rider, so residency is a matter of speed, not of correctness.
     const int pt_wgs = h->nblkP + h->nblkL;
-    const bool fuse = ride && (riders & 4) && !h->jac_f32 &&
+    // ... and where the inner solves are short: every PCG point pass carries the riders (0.6 us each at C3), the launch they
+    // save comes once per LM iteration (5 - 8 us) -- beyond ~16 PCG iterations per LM iteration the separate launch is cheaper
+    // (decided from the last inner solve's count: host-side, deterministic, identical on every rank; the bits do not depend on it)
+    const bool fuse = ride && (riders & 4) && !h->jac_f32 && (pcg_last < 0 || pcg_last <= 16) &&
                       (pt_wgs + cu.n_blocks + h->n_cu - 1) / h->n_cu == (pt_wgs + h->n_cu - 1) / h->n_cu;
     cu.fuse = fuse ? 1 : 0;
     bool backsub_done = false;
