@@ -1076,7 +1076,7 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
   h->uv_f32 = false;           // (a device build that handed the problem back may have decided already: decided again here)
   if (uv_f32_eligible) {       // every pixel a float32 value?  (branch-free sweep; NaN compares unequal: stays double)
     int all = 1;
-    for (int64_t i = 0; i < 2 * n_obs; ++i) all &= (int)((double)(float)uv[i] == uv[i]);
+    for (int64_t i = 0; i < 2 * n_obs; ++i) all &= (int)pixel_is_f32(uv[i]);
     h->uv_f32 = all != 0;
     stage("pixel value sweep");
   }

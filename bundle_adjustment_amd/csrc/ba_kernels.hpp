@@ -196,6 +196,12 @@ __device__ __forceinline__ float2 ld_stream(const float2* p) {
   const ba_f2v v = __builtin_nontemporal_load((const ba_f2v*)p);
   return make_float2(v.x, v.y);
 }
+// "this double is a float32 value" (finite; out-of-range values are clamped first: a double -> float conversion outside
+// float's range is undefined in C++; NaN, infinities and anything beyond FLT_MAX keep the problem on double2)
+__host__ __device__ inline bool pixel_is_f32(double u) {
+  const double c = fmin(fmax(u, -3.4028234663852886e38), 3.4028234663852886e38);
+  return (double)(float)c == u;
+}
 struct UvArr {
   const void* p;
   int f32;
@@ -1493,7 +1499,9 @@ __device__ inline bool ipc_wait(const unsigned long long* __restrict__ flags, in
       }
     }
   }
-  asm volatile("" ::: "memory");                 // (the record loads are issued behind the loop that saw the flags)
+  // (the record loads are system-scope atomic loads of fine-grained memory -- never served from a cache -- issued behind the
+  // loop that saw the flags: no acquire fence, whose L2 invalidate the rest of the kernel would pay for)
+  asm volatile("" ::: "memory");
   return __all(ok);
 }
 
@@ -1791,8 +1799,10 @@ k_pcg_step(int k, const double* __restrict__ part6, int nparts, const double* __
       for (int d = 0; d < ipc.world; ++d) __hip_atomic_store(ipc.P.recv[d] + mine + 2 + e, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (lane < ipc.world) __hip_atomic_store(ipc.P.recv[lane] + mine, uy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // every store of this wave has left for the fabric before the sequence number follows it (release, system scope)
+    // every store of this workgroup (one wave) has left for the fabric before the sequence number follows it (release,
+    // system scope); the barrier orders the OTHER lanes' fenced stores before the lanes that publish
     __threadfence_system();
+    __syncthreads();
     if (lane < ipc.world)
       __hip_atomic_store(ipc.P.flags[lane] + ((size_t)ipc.parity * ipc.world + ipc.rank) * IPC_MAX_BLOCKS + blockIdx.x,
                          (unsigned long long)ipc.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

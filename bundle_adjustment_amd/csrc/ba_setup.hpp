@@ -37,7 +37,7 @@ k_setup_hist(const int* __restrict__ cam_idx, const int* __restrict__ pt_idx, in
   const int c = cam_idx[i], p = pt_idx[i];
   if (uv) {                                   // a pixel that is not a float32 value: the streams stay double2 (UvArr)
     const double2 v = uv[i];
-    if (!((double)(float)v.x == v.x && (double)(float)v.y == v.y)) __hip_atomic_store(wide, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!(pixel_is_f32(v.x) && pixel_is_f32(v.y))) __hip_atomic_store(wide, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (c < 0 || c >= n_cams || p < 0 || p >= n_pts) { atomicMin(bad, i); return; }
   atomicAdd(cnt + p, 1);
