@@ -959,13 +959,15 @@ static int set_problem_device(ba_handle* h, int Nc, int Np, int No, const int32_
   }
   stage("long tracks + visiting order");
   // camera order (keys: positions of the point-ordered list)
-  BA_LAUNCH(k_setup_hist_cam, go, b256, 0, h->stream, (const int*)h->p_cam.p, No, S + o_ccnt);
+  const dim3 gt((No + SETUP_CAM_TILE - 1) / SETUP_CAM_TILE);
+  BA_LAUNCH(k_setup_hist_cam, gt, b256, (size_t)Nc * sizeof(int), h->stream, (const int*)h->p_cam.p, No, Nc, S + o_ccnt);
   dev_scan(h, S + o_ccnt, Nc, S + o_bsum, S + o_coff);
-  BA_LAUNCH(k_setup_scatter_cam, go, b256, 0, h->stream, (const int*)h->p_cam.p, No, (const int*)(S + o_coff), S + o_cfill, seg);
+  BA_LAUNCH(k_setup_scatter_cam, gt, b256, 2 * (size_t)Nc * sizeof(int), h->stream, (const int*)h->p_cam.p, No, Nc, (const int*)(S + o_coff),
+            S + o_cfill, seg);
   BA_LAUNCH(k_setup_sort_cam, dim3(Nc), b256, 0, h->stream, (const int*)(S + o_coff), (const int*)seg, (const int*)p_pt, (const int*)p_src,
             h->c_pt.p, h->c_orig.p);
   BA_LAUNCH(k_setup_offk, dim3((Nc * (NPART + 1) + 255) / 256), b256, 0, h->stream, (const int*)(S + o_coff), Nc, h->offk.p);
-  BA_LAUNCH(k_setup_xcd_stat, dim3((Nc * NPART + 3) / 4), b256, 0, h->stream, (const int*)h->offk.p, (const int*)h->c_pt.p, Nc, Np, u64 + 1);
+  BA_LAUNCH(k_setup_xcd_stat, dim3(std::min((Nc * NPART + 3) / 4, 2 * h->n_cu)), b256, 0, h->stream, (const int*)h->offk.p, (const int*)h->c_pt.p, Nc, Np, u64 + 1);
   const int nwin = h->nblkP + h->nblkL;
   if ((size_t)nwin * sizeof(int2) + 64 > SETUP_PINNED_BYTES) return 1;
   HIPCHECK(h->blk_win.alloc(nwin));

@@ -119,20 +119,52 @@ k_setup_sort_pt(const int* __restrict__ pt_off, int n_pts, const int* __restrict
   const int p = blockIdx.x * 256 + threadIdx.x;
   long long span = 0;
   int tracks = 0;
+  int b = 0, n = 0;
+  if (p < n_pts) { b = pt_off[p]; n = pt_off[p + 1] - b; }
+  {   // track-length histogram, one atomic per DISTINCT length in the wave (synthetic data: every track has the same length --
+      // a hundred thousand atomics on one word took most of this kernel's millisecond)
+    const int bin = p < n_pts ? min(n, hist_bins - 1) : -1;
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(bin >= 0);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int lb = __shfl(bin, leader, 64);
+      const unsigned long long same = __ballot(bin == lb);
+      if (lane == leader) atomicAdd(len_hist + lb, (int)__popcll(same));
+      todo &= ~same;
+    }
+  }
   if (p < n_pts) {
-    const int b = pt_off[p], n = pt_off[p + 1] - b;
-    atomicAdd(len_hist + min(n, hist_bins - 1), 1);
     if (n > 64) {
       big[atomicAdd(n_big, 1)] = p;
     } else if (n > 0) {
       int lo = 0x7fffffff, hi = -1;
-      for (int a = 0; a < n; ++a) {
-        const int e = seg[b + a];
-        int r = 0;
-        for (int q = 0; q < n; ++q) r += seg[b + q] < e;
-        const int c = cam_idx[e];
-        p_src[b + r] = e; p_cam[b + r] = c; p_pt[b + r] = p;
-        lo = min(lo, c); hi = max(hi, c);
+      if (n <= 16) {
+        // the usual track: the segment once into registers (the quadratic rank loop below reads it n times from memory, one
+        // cache line per lane and load), ranks by compare-and-count, pads (INT_MAX) never count
+        int e[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) e[a] = a < n ? seg[b + a] : 0x7fffffff;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+          if (a < n) {
+            int r = 0;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) r += e[q] < e[a];
+            const int c = cam_idx[e[a]];
+            p_src[b + r] = e[a]; p_cam[b + r] = c; p_pt[b + r] = p;
+            lo = min(lo, c); hi = max(hi, c);
+          }
+        }
+      } else {
+        for (int a = 0; a < n; ++a) {
+          const int e = seg[b + a];
+          int r = 0;
+          for (int q = 0; q < n; ++q) r += seg[b + q] < e;
+          const int c = cam_idx[e];
+          p_src[b + r] = e; p_cam[b + r] = c; p_pt[b + r] = p;
+          lo = min(lo, c); hi = max(hi, c);
+        }
       }
       span = hi - lo; tracks = 1;
     }
@@ -219,17 +251,50 @@ k_setup_bank_order(const int* __restrict__ pt_off, int n_pts, int nblk, int ppb,
 }
 
 // ---- camera order ---------------------------------------------------------------------------------------------------
+// A million atomics on a thousand counters are served one at a time per counter: both kernels first count in LDS over a
+// tile of SETUP_CAM_TILE positions (one camera counter each in dynamic LDS, n_cams ints -- twice that for the scatter) and
+// then touch every global counter once per tile.
+constexpr int SETUP_CAM_ITEMS = 16;
+constexpr int SETUP_CAM_TILE = 256 * SETUP_CAM_ITEMS;
 __global__ void __launch_bounds__(256)
-k_setup_hist_cam(const int* __restrict__ p_cam, int n_obs, int* __restrict__ cnt) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j < n_obs) atomicAdd(cnt + p_cam[j], 1);
+k_setup_hist_cam(const int* __restrict__ p_cam, int n_obs, int n_cams, int* __restrict__ cnt) {
+  extern __shared__ int l_cnt[];
+  for (int c = threadIdx.x; c < n_cams; c += 256) l_cnt[c] = 0;
+  __syncthreads();
+  const int j0 = blockIdx.x * SETUP_CAM_TILE + threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < SETUP_CAM_ITEMS; ++q) {
+    const int j = j0 + 256 * q;
+    if (j < n_obs) atomicAdd(&l_cnt[p_cam[j]], 1);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < n_cams; c += 256) { const int v = l_cnt[c]; if (v) atomicAdd(cnt + c, v); }
 }
+// seg: every camera's segment holds its positions in ANY order (k_setup_sort_cam sorts them)
 __global__ void __launch_bounds__(256)
-k_setup_scatter_cam(const int* __restrict__ p_cam, int n_obs, const int* __restrict__ cam_off, int* __restrict__ fill, int* __restrict__ seg) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n_obs) return;
-  const int c = p_cam[j];
-  seg[cam_off[c] + atomicAdd(fill + c, 1)] = j;
+k_setup_scatter_cam(const int* __restrict__ p_cam, int n_obs, int n_cams, const int* __restrict__ cam_off, int* __restrict__ fill,
+                    int* __restrict__ seg) {
+  extern __shared__ int l_cnt[];                 // [n_cams] counts of the tile, then [n_cams] the tile's first slot per camera
+  int* l_base = l_cnt + n_cams;
+  for (int c = threadIdx.x; c < n_cams; c += 256) l_cnt[c] = 0;
+  __syncthreads();
+  const int j0 = blockIdx.x * SETUP_CAM_TILE + threadIdx.x;
+  int cam[SETUP_CAM_ITEMS], loc[SETUP_CAM_ITEMS];
+#pragma unroll
+  for (int q = 0; q < SETUP_CAM_ITEMS; ++q) {
+    const int j = j0 + 256 * q;
+    cam[q] = j < n_obs ? p_cam[j] : -1;
+    loc[q] = cam[q] >= 0 ? atomicAdd(&l_cnt[cam[q]], 1) : 0;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < n_cams; c += 256) {
+    const int v = l_cnt[c];
+    l_base[c] = v ? cam_off[c] + atomicAdd(fill + c, v) : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < SETUP_CAM_ITEMS; ++q)
+    if (cam[q] >= 0) seg[l_base[cam[q]] + loc[q]] = j0 + 256 * q;
 }
 // one workgroup per camera: its segment of positions sorted ascending (rank sort, keys unique), then
 // c_pt = point of the position, c_orig = caller's row of the position
@@ -265,10 +330,11 @@ k_setup_offk(const int* __restrict__ cam_off, int n_cams, int* __restrict__ offk
 // of their camera's range.  stat[0] += in_partition, stat[1] += in_band.
 __global__ void __launch_bounds__(256)
 k_setup_xcd_stat(const int* __restrict__ offk, const int* __restrict__ c_pt, int n_cams, int n_pts, unsigned long long* __restrict__ stat) {
-  // one wave per (camera, partition) segment
-  const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // one wave per (camera, partition) segment, grid-stride; one pair of atomics per WORKGROUP (two words for everybody)
+  __shared__ long long s_a[4], s_b[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   long long a = 0, bnd = 0;
-  if (seg < n_cams * NPART) {
+  for (int seg = blockIdx.x * 4 + wv; seg < n_cams * NPART; seg += gridDim.x * 4) {
     const int c = seg / NPART, k = seg % NPART;
     const int cam_slice = (int)(((long long)c * NPART) / n_cams);
     for (int i = offk[c * (NPART + 1) + k] + lane; i < offk[c * (NPART + 1) + k + 1]; i += 64) {
@@ -282,7 +348,12 @@ k_setup_xcd_stat(const int* __restrict__ offk, const int* __restrict__ c_pt, int
     }
   }
   for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); bnd += __shfl_down(bnd, o, 64); }
-  if (lane == 0 && (a | bnd)) { atomicAdd(stat, (unsigned long long)a); atomicAdd(stat + 1, (unsigned long long)bnd); }
+  if (lane == 0) { s_a[wv] = a; s_b[wv] = bnd; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const long long ta = s_a[0] + s_a[1] + s_a[2] + s_a[3], tb = s_b[0] + s_b[1] + s_b[2] + s_b[3];
+    if (ta | tb) { atomicAdd(stat, (unsigned long long)ta); atomicAdd(stat + 1, (unsigned long long)tb); }
+  }
 }
 // camera window [lo, hi] of every point-pass workgroup: ranges of ppb points, then long-track workgroups of long_spb entries
 __global__ void __launch_bounds__(256)
