@@ -1094,10 +1094,32 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     std::vector<double> sum(Np, 0.0);
     std::vector<int> n(Np, 0);
     for (int i = 0; i < No; ++i) { sum[pt_idx[i]] += cam_idx[i]; n[pt_idx[i]]++; }
-    std::vector<int> order(Np);
-    for (int p = 0; p < Np; ++p) { order[p] = p; sum[p] = n[p] ? sum[p] / n[p] : (double)Nc; }
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sum[a] < sum[b]; });
-    for (int r = 0; r < Np; ++r) slot[order[r]] = r;
+    // The order a stable sort of the points by key gives, in two linear steps instead of a comparison sort with an indirect
+    // key load per comparison (config 5: 9 of this stage's 13 ms): the keys lie in [0, Nc], so a stable counting sort by
+    // floor(16 key) -- monotone in the key -- leaves a handful of points per bucket, finished by a stable insertion sort on
+    // the exact keys
+    constexpr int BK = 16;
+    const size_t nbk = (size_t)(Nc + 1) * BK + 2;
+    std::vector<int> bfirst(nbk + 1, 0);
+    std::vector<std::pair<double, int>> order(Np);
+    for (int p = 0; p < Np; ++p) {
+      const double key = n[p] ? sum[p] / n[p] : (double)Nc;
+      sum[p] = key;
+      bfirst[(size_t)(key * BK) + 1]++;
+    }
+    for (size_t q = 0; q < nbk; ++q) bfirst[q + 1] += bfirst[q];
+    {
+      std::vector<int> fill(bfirst.begin(), bfirst.end() - 1);
+      for (int p = 0; p < Np; ++p) order[fill[(size_t)(sum[p] * BK)]++] = std::make_pair(sum[p], p);
+    }
+    for (size_t q = 0; q < nbk; ++q)
+      for (int a = bfirst[q] + 1; a < bfirst[q + 1]; ++a) {
+        const std::pair<double, int> v = order[a];
+        int w = a;
+        while (w > bfirst[q] && order[w - 1].first > v.first) { order[w] = order[w - 1]; --w; }
+        order[w] = v;
+      }
+    for (int r = 0; r < Np; ++r) slot[order[r].second] = r;
   }
   std::vector<int> pt_new(No);
   for (int i = 0; i < No; ++i) pt_new[i] = slot[pt_idx[i]];
@@ -1270,12 +1292,22 @@ extern "C" int ba_set_problem(ba_handle* h, int32_t n_cams, int32_t n_pts, int64
     if (want && Nc >= 2 * VEC_CAMS && Np > 0 && No > 0) {
       std::vector<std::pair<int, int>> tmp;
       int bwa = 0;
+      run_beg.reserve(No / 2 + 16); run_pt.reserve(No / 2 + 16); run_agg.reserve(No / 2 + 16); run_pairs.reserve(No);
       for (int p = 0; p < Np; ++p) {
         const int b = pt_off[p], e = pt_off[p + 1];
-        tmp.resize(e - b);
-        for (int j = b; j < e; ++j) tmp[j - b] = std::make_pair(p_cam[j], p_src[j]);
-        std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first < y.first; });
-        for (int j = b; j < e; ++j) { p_cam[j] = tmp[j - b].first; p_src[j] = tmp[j - b].second; }
+        if (e - b <= 32) {             // the usual track: stable insertion sort by camera, in place
+          for (int j = b + 1; j < e; ++j) {
+            const int c = p_cam[j], sidx = p_src[j];
+            int q = j;
+            while (q > b && p_cam[q - 1] > c) { p_cam[q] = p_cam[q - 1]; p_src[q] = p_src[q - 1]; --q; }
+            p_cam[q] = c; p_src[q] = sidx;
+          }
+        } else {
+          tmp.resize(e - b);
+          for (int j = b; j < e; ++j) tmp[j - b] = std::make_pair(p_cam[j], p_src[j]);
+          std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first < y.first; });
+          for (int j = b; j < e; ++j) { p_cam[j] = tmp[j - b].first; p_src[j] = tmp[j - b].second; }
+        }
         const int first_run = (int)run_pt.size();
         for (int j = b; j < e;) {
           const int a = p_cam[j] / VEC_CAMS;
