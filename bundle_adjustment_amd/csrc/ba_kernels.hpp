@@ -1416,13 +1416,10 @@ pt_schur_rider(int n_rider, int kit, const PcgState* __restrict__ st, const doub
   if (ridx < 0 || ridx >= n_rider) return false;
   extern __shared__ __align__(16) double tab[];
   if (MODE == 0) {
-    __shared__ int r_fin;
-    if (threadIdx.x < 64) {
-      const bool fin = pcg_probe(kit, st, partV, nblkV, tol2, min_iters, host_flag, flag_base, verdict, partG, nG, partGc, nGc, gmax_out);
-      if (threadIdx.x == 0) r_fin = fin ? 1 : 0;
-    }
-    __syncthreads();
-    if (!r_fin) return true;
+    // the waves without a camera group leave at once; each of the others probes for itself (the same words, the same
+    // verdict in every wave) -- no workgroup barrier in the launches that only probe
+    if ((int)(threadIdx.x >> 6) >= cu.groups) return true;
+    if (!pcg_probe(kit, st, partV, nblkV, tol2, min_iters, host_flag, flag_base, verdict, partG, nG, partGc, nGc, gmax_out)) return true;
     if (ridx == 0 && threadIdx.x == 0 && cu.lam_slot) cu.lam_slot[0] = 0.0;
   }
   cam_update_rider<CM>(cu, ridx, tab);
